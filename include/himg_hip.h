@@ -1,0 +1,146 @@
+/*
+ * himg_hip.h -- C ABI of the MI355X-native HIMG encode/decode engine.
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes
+ * only, int status returns, no C++/torch types.  The reference has no FFI of
+ * its own; the interface a binding would wrap is the public surface of
+ *   himg::Encoder  (reference src/lib/encoder.h:20-64, encoder.cpp:59-109)
+ *   himg::Decoder  (reference src/lib/decoder.h:22-67, decoder.cpp:87-138)
+ * and every entry point below names the member it replaces.  The C++ classes
+ * in include/encoder.h / include/decoder.h are thin wrappers over this ABI, so
+ * reference callers (src/chimg.cpp:140-163, src/dhimg.cpp:45-65,
+ * src/benchmark.cpp:108-125) compile unchanged.
+ *
+ * All device work is hand-written HIP for gfx950; there is NO CPU fallback:
+ * without a usable GPU every compute entry point returns HIMG_ERR_HIP.
+ */
+#ifndef HIMG_HIP_H_
+#define HIMG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+#define HIMG_OK 0
+#define HIMG_ERR_ARG (-1)         /* bad argument */
+#define HIMG_ERR_HIP (-2)         /* HIP runtime failure / no device */
+#define HIMG_ERR_UNSUPPORTED (-3) /* geometry or stream outside the built scope */
+#define HIMG_ERR_FORMAT (-4)      /* decode: the reference would return false */
+#define HIMG_ERR_CAPACITY (-5)    /* output buffer too small */
+
+typedef struct himg_hip_ctx himg_hip_ctx;
+
+/* One context per device per host thread.  It owns the device workspace
+ * (intermediate planes, symbol buffers, scan scratch) sized lazily for the
+ * largest geometry/batch seen.  Not re-entrant; distinct contexts are
+ * independent (mirrors "distinct Decoder objects are independent",
+ * decoder.cpp:292-326). */
+int himg_hip_create(int device, himg_hip_ctx **ctx);
+void himg_hip_destroy(himg_hip_ctx *ctx);
+const char *himg_hip_last_error(const himg_hip_ctx *ctx);
+
+/* Upper bound of the packed size of one frame (bytes), a multiple of 256.
+ * Replaces HuffmanEnc::MaxCompressedSize (huffman_enc.cpp:242-244) plus the
+ * container overhead of encoder.cpp:111-256. */
+size_t himg_hip_max_packed_size(int width, int height, int num_channels);
+
+/* ---- host-buffer API (what the C++ wrapper classes call) ---------------- */
+
+/* Replaces himg::Encoder::Encode + packed_data()/packed_size()
+ * (encoder.h:24-34).  `data`: tightly packed rows of width*pixel_stride
+ * bytes, channel c of pixel (x,y) at (y*width+x)*pixel_stride+c
+ * (encoder.cpp:297).  *out is malloc'ed; release with himg_hip_free.
+ * Every call has fresh-Encoder semantics (SURVEY.md trap T4). */
+int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
+                    int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                    uint8_t **out, size_t *out_size);
+
+/* Replaces himg::Decoder::Decode + unpacked_data()/width()/height()/
+ * num_channels() (decoder.h:26-33).  Returns HIMG_ERR_FORMAT exactly where
+ * the reference returns false (including trap T2 streams). *out is malloc'ed
+ * width*height*channels bytes. */
+int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size,
+                    uint8_t **out, int *width, int *height, int *num_channels);
+
+void himg_hip_free(void *p);
+
+/* ---- device-resident batched API (roofline measurements, pipelines) ----- */
+
+/* Encode `batch` frames that already live in HBM.
+ *   d_frames : device pointer, batch * height*width*pixel_stride bytes
+ *   d_out    : device pointer, batch * out_stride bytes (out_stride a multiple
+ *              of 256 and >= himg_hip_max_packed_size)
+ *   d_sizes  : device pointer, batch x uint32 packed sizes (0 on failure)
+ *   d_status : device pointer, batch x int32 (HIMG_OK or an error code)
+ *   stream   : hipStream_t (NULL = default stream).  Asynchronous: nothing is
+ *              synchronised with the host.  Same per-frame semantics as
+ *              himg_hip_encode. */
+int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, int batch,
+                           int width, int height, int pixel_stride,
+                           int num_channels, int quality, int use_ycbcr,
+                           void *d_out, size_t out_stride, uint32_t *d_sizes,
+                           int32_t *d_status, void *stream);
+
+/* Decode `batch` streams that already live in HBM; all must have the stated
+ * geometry (it is validated on the device against each stream's FRMT chunk).
+ *   d_packed : device pointer, stream f starts at d_packed + f*in_stride
+ *   h_sizes  : HOST array, batch packed sizes
+ *   d_out    : device pointer, batch * width*height*num_channels bytes
+ *   d_status : device pointer, batch x int32 */
+int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, size_t in_stride,
+                           const uint32_t *h_sizes, int batch, int width, int height,
+                           int num_channels, void *d_out, int32_t *d_status,
+                           void *stream);
+
+/* ---- introspection for parity tests and bench.py ------------------------ */
+
+/* Intermediate device buffers of the LAST encode/decode on this context
+ * (frame index f of the batch), copied to host.  Synchronises the stream. */
+enum {
+  HIMG_DBG_AVG = 0,        /* u8  [C][rows][cols] box averages                 */
+  HIMG_DBG_LOWRES = 1,     /* u8  [C][rows][cols] low-res plane (m_data)       */
+  HIMG_DBG_LRES_SYM = 2,   /* u8  [C][chan_size] LRES payload before entropy   */
+  HIMG_DBG_FRES_SYM = 3,   /* u8  [rows][C][64][cols] FRES payload             */
+  HIMG_DBG_LRES_HIST = 4,  /* u32 [261] token histogram                        */
+  HIMG_DBG_FRES_HIST = 5,  /* u32 [261]                                        */
+  HIMG_DBG_LRES_LEN = 6,   /* u32 [261] code lengths                           */
+  HIMG_DBG_FRES_LEN = 7,   /* u32 [261]                                        */
+  HIMG_DBG_LRES_CODE = 8,  /* u64 [261] LSB-first codes                        */
+  HIMG_DBG_FRES_CODE = 9,  /* u64 [261]                                        */
+  HIMG_DBG_FRES_ROW_BYTES = 10 /* u32 [rows] payload bytes per block row       */
+};
+int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void *host_dst,
+                        size_t dst_bytes, size_t *bytes_written);
+
+/* Per-stage device timing with hipEvents recorded on the caller's stream.
+ * enable != 0 brackets every kernel of the following calls; stage_ms returns
+ * the accumulated milliseconds and launch counts since the last reset. */
+#define HIMG_MAX_STAGES 32
+int himg_hip_profile_enable(himg_hip_ctx *ctx, int enable);
+int himg_hip_profile_reset(himg_hip_ctx *ctx);
+int himg_hip_profile_read(himg_hip_ctx *ctx, int *n_stages,
+                          const char *names[HIMG_MAX_STAGES],
+                          double ms[HIMG_MAX_STAGES], int launches[HIMG_MAX_STAGES]);
+
+/* ---- host utilities (no GPU needed) -------------------------------------- */
+
+/* Synthetic RGBA generators of SURVEY.md Appendix C.1. */
+enum { HIMG_SYNTH_GRAD = 0, HIMG_SYNTH_GRADN = 1, HIMG_SYNTH_RAND = 2, HIMG_SYNTH_RANDTILE = 3 };
+int himg_synth_fill(int kind, uint64_t seed, int width, int height, uint8_t *rgba);
+uint64_t himg_fnv1a64(const uint8_t *data, size_t n);
+
+/* Host-side format tables (quantize.cpp:72-125, mapper.cpp:75-223); exposed
+ * so the parity tests can compare them with the oracle without a GPU. */
+void himg_tables_shift(int quality, int chroma, uint8_t out[64]);
+void himg_tables_lowres_map(int quality, int16_t out[128]);
+void himg_tables_fullres_map(int16_t out[128]);
+uint8_t himg_tables_map_to_8bit(const int16_t table[128], int x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIMG_HIP_H_ */
