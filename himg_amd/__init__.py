@@ -1,0 +1,217 @@
+"""himg_amd -- MI355X-native HIMG encode/decode engine (Python plumbing).
+
+The product is the C-ABI shared library (include/himg_hip.h) built from the
+hand-written HIP kernels under himg_amd/csrc/.  This module is only the ctypes
+binding that tests, bench.py and the multi-GPU driver use; PyTorch supplies
+device memory, streams and torch.distributed, nothing else.
+
+There is no CPU fallback: if the native library cannot be loaded or no GPU is
+usable, the compute entry points raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB, build_lib
+
+HIMG_OK = 0
+HIMG_ERR_ARG = -1
+HIMG_ERR_HIP = -2
+HIMG_ERR_UNSUPPORTED = -3
+HIMG_ERR_FORMAT = -4
+HIMG_ERR_CAPACITY = -5
+
+SYNTH = {"grad": 0, "gradn": 1, "rand": 2, "randtile": 3}
+
+# himg_hip_debug_read selectors (include/himg_hip.h)
+DBG = {
+    "avg": 0, "lowres": 1, "lres_sym": 2, "fres_sym": 3, "lres_hist": 4, "fres_hist": 5,
+    "lres_len": 6, "fres_len": 7, "lres_code": 8, "fres_code": 9, "fres_row_bytes": 10,
+}
+DBG_DECODER = 0x100
+
+_lib = None
+
+
+class HimgError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("himg_hip error %d %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load (building if necessary) the native library; fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = LIB
+    if not os.path.exists(path):
+        path = build_lib()
+    L = C.CDLL(path)
+    vp, i32, u32, u64, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
+    P = C.POINTER
+    L.himg_hip_create.argtypes = [i32, P(vp)]
+    L.himg_hip_destroy.argtypes = [vp]
+    L.himg_hip_destroy.restype = None
+    L.himg_hip_last_error.argtypes = [vp]
+    L.himg_hip_last_error.restype = C.c_char_p
+    L.himg_hip_max_packed_size.argtypes = [i32, i32, i32]
+    L.himg_hip_max_packed_size.restype = sz
+    L.himg_hip_encode.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, P(vp), P(sz)]
+    L.himg_hip_decode.argtypes = [vp, vp, sz, P(vp), P(i32), P(i32), P(i32)]
+    L.himg_hip_free.argtypes = [vp]
+    L.himg_hip_free.restype = None
+    L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
+    L.himg_hip_decode_device.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_debug_read.argtypes = [vp, i32, i32, vp, sz, P(sz)]
+    L.himg_hip_profile_enable.argtypes = [vp, i32]
+    L.himg_hip_profile_reset.argtypes = [vp]
+    L.himg_hip_profile_read.argtypes = [vp, P(i32), P(C.c_char_p), P(C.c_double), P(i32)]
+    L.himg_synth_fill.argtypes = [i32, u64, i32, i32, vp]
+    L.himg_fnv1a64.argtypes = [vp, sz]
+    L.himg_fnv1a64.restype = u64
+    L.himg_tables_shift.argtypes = [i32, i32, vp]
+    L.himg_tables_shift.restype = None
+    L.himg_tables_lowres_map.argtypes = [i32, vp]
+    L.himg_tables_lowres_map.restype = None
+    L.himg_tables_fullres_map.argtypes = [vp]
+    L.himg_tables_fullres_map.restype = None
+    L.himg_tables_map_to_8bit.argtypes = [vp, i32]
+    L.himg_tables_map_to_8bit.restype = C.c_uint8
+    _lib = L
+    return L
+
+
+# ---- host utilities (no GPU) -------------------------------------------------
+
+def synth(kind, seed, width, height):
+    """Synthetic RGBA frame as a (H, W, 4) uint8 array."""
+    a = np.empty((height, width, 4), np.uint8)
+    rc = lib().himg_synth_fill(SYNTH[kind], seed, width, height, a.ctypes.data)
+    if rc:
+        raise HimgError(rc, "synth")
+    return a
+
+
+def fnv1a64(buf):
+    b = np.ascontiguousarray(np.frombuffer(buf, np.uint8) if isinstance(buf, (bytes, bytearray)) else buf)
+    return "%016x" % lib().himg_fnv1a64(b.ctypes.data, b.nbytes)
+
+
+def max_packed_size(width, height, channels):
+    return int(lib().himg_hip_max_packed_size(width, height, channels))
+
+
+def psnr(a, b):
+    """PSNR over all channels, 10*log10(255^2/MSE), double precision."""
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float(np.mean(d * d))
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 * 255.0 / mse)
+
+
+# ---- engine ------------------------------------------------------------------
+
+class Engine:
+    """One C-ABI context (one device).  Mirrors the reference's Encoder/Decoder
+    pair: encode()/decode() take and return host buffers like
+    himg::Encoder::Encode / himg::Decoder::Decode; the *_device methods work on
+    HBM-resident batches (torch CUDA tensors or raw device pointers)."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        rc = lib().himg_hip_create(device, C.byref(self._ctx))
+        if rc:
+            raise HimgError(rc, "himg_hip_create (no usable GPU? there is no CPU fallback)")
+        self.device = device
+
+    def close(self):
+        if self._ctx:
+            lib().himg_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise HimgError(rc, "%s: %s" % (what, lib().himg_hip_last_error(self._ctx).decode()))
+
+    # host-buffer API ---------------------------------------------------------
+    def encode(self, img, quality=50, use_ycbcr=True, channels=None, pixel_stride=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]
+        ch = channels if channels is not None else (img.shape[2] if img.ndim == 3 else 1)
+        stride = pixel_stride if pixel_stride is not None else (img.shape[2] if img.ndim == 3 else 1)
+        out, n = C.c_void_p(), C.c_size_t()
+        rc = lib().himg_hip_encode(self._ctx, img.ctypes.data, w, h, stride, ch, quality,
+                                   1 if use_ycbcr else 0, C.byref(out), C.byref(n))
+        self._check(rc, "encode")
+        buf = C.string_at(out, n.value)
+        lib().himg_hip_free(out)
+        return np.frombuffer(buf, np.uint8).copy()
+
+    def decode(self, packed):
+        packed = np.ascontiguousarray(np.frombuffer(packed, np.uint8) if isinstance(packed, (bytes, bytearray)) else packed)
+        out = C.c_void_p()
+        w, h, c = C.c_int(), C.c_int(), C.c_int()
+        rc = lib().himg_hip_decode(self._ctx, packed.ctypes.data, packed.nbytes, C.byref(out),
+                                   C.byref(w), C.byref(h), C.byref(c))
+        self._check(rc, "decode")
+        n = w.value * h.value * c.value
+        buf = C.string_at(out, n)
+        lib().himg_hip_free(out)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, w.value, c.value).copy()
+
+    # device-resident API -------------------------------------------------------
+    def encode_device(self, d_frames, batch, width, height, pixel_stride, channels, quality,
+                      use_ycbcr, d_out, out_stride, d_sizes, d_status, stream=0):
+        rc = lib().himg_hip_encode_device(self._ctx, _ptr(d_frames), batch, width, height,
+                                          pixel_stride, channels, quality, 1 if use_ycbcr else 0,
+                                          _ptr(d_out), out_stride, _ptr(d_sizes), _ptr(d_status),
+                                          C.c_void_p(stream))
+        self._check(rc, "encode_device")
+
+    def decode_device(self, d_packed, in_stride, h_sizes, batch, width, height, channels, d_out,
+                      d_status, stream=0):
+        hs = np.ascontiguousarray(h_sizes, np.uint32)
+        rc = lib().himg_hip_decode_device(self._ctx, _ptr(d_packed), in_stride, hs.ctypes.data,
+                                          batch, width, height, channels, _ptr(d_out),
+                                          _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "decode_device")
+
+    # introspection ---------------------------------------------------------------
+    def debug_read(self, what, frame, nbytes, dtype=np.uint8, decoder=False):
+        buf = np.empty(nbytes, np.uint8)
+        n = C.c_size_t()
+        sel = DBG[what] | (DBG_DECODER if decoder else 0)
+        rc = lib().himg_hip_debug_read(self._ctx, sel, frame, buf.ctypes.data, nbytes, C.byref(n))
+        self._check(rc, "debug_read(%s)" % what)
+        return buf[: n.value].view(dtype)
+
+    def profile(self, enable):
+        lib().himg_hip_profile_enable(self._ctx, 1 if enable else 0)
+
+    def profile_reset(self):
+        lib().himg_hip_profile_reset(self._ctx)
+
+    def profile_read(self):
+        n = C.c_int()
+        names = (C.c_char_p * 32)()
+        ms = (C.c_double * 32)()
+        cnt = (C.c_int * 32)()
+        rc = lib().himg_hip_profile_read(self._ctx, C.byref(n), names, ms, cnt)
+        self._check(rc, "profile_read")
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor, or a raw integer address."""
+    if x is None:
+        return C.c_void_p(0)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))

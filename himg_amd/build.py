@@ -1,0 +1,78 @@
+"""Build the in-tree native library: HIP kernels + C ABI -> himg_amd/lib/libhimg_hip.so.
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the
+build container as well as on the MI355X box.  The .so is git-ignored but
+travels with the repo snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "himg_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "himg_amd", "lib")
+LIB = os.path.join(LIBDIR, "libhimg_hip.so")
+
+HIP_SOURCES = ["kernels_enc.hip", "kernels_dec.hip", "himg_hip.hip"]
+CXX_SOURCES = ["encoder.cpp", "decoder.cpp"]
+C_SOURCES = ["himg_tables.c", "himg_synth.c"]
+HEADERS = ["himg_dev.h", "himg_tables.h", "../../include/himg_hip.h",
+           "../../include/encoder.h", "../../include/decoder.h"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the HIMG engine has no CPU fallback")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every HIP/C++/C source for gfx950 into one shared library."""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES + CXX_SOURCES + C_SOURCES
+            if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    for s in srcs:
+        o = os.path.join(LIBDIR, os.path.basename(s) + ".o")
+        if force or _stale(o, [s] + deps[len(srcs):]):
+            if s.endswith(".c"):
+                cmd = ["gcc", "-O2", "-fPIC", "-std=c99", "-c", s, "-o", o] + inc
+            elif s.endswith(".cpp"):
+                cmd = ["g++", "-O2", "-fPIC", "-std=c++11", "-c", s, "-o", o] + inc
+            else:
+                cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
+                       "-Wno-unused-value", "-c", s, "-o", o] + inc
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        objs.append(o)
+    tmp = LIB + ".tmp"
+    subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs
+                   + ["-lpthread"], check=True)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+def build_oracle(verbose=False):
+    """Build the CPU checker (tests / smoke / cpu_baseline only)."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")] + ([] if verbose else ["-s"]),
+                   check=True)
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))
+    build_oracle(verbose=True)

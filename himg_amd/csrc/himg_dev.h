@@ -1,0 +1,121 @@
+// himg_dev.h -- structures shared by the HIP kernels and the host orchestration.
+//
+// Vocabulary (follows the reference's domain):
+//   block row  : one strip of 8 pixel rows = cols tiles = row_block symbols
+//   LRES / FRES: the low-res and full-res payloads before entropy coding
+//   span       : a contiguous symbol range entropy-coded by one workgroup
+//                (FRES: one block row; LRES: kLresSpan symbols)
+#ifndef HIMG_DEV_H_
+#define HIMG_DEV_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace himg_dev {
+
+constexpr int kNumSym = 261;      // huffman_common.h:18-20
+constexpr int kHistStride = 264;  // padded row of a histogram / code table
+constexpr int kLresSpan = 16384;  // LRES symbols per entropy span
+constexpr int kIterSyms = 4096;   // symbols per workgroup iteration (256 thr x 16 B)
+constexpr int kTreeStride = 384;  // bytes reserved per serialised tree (max 359)
+constexpr int kMaxCodeLen = 32;   // reference keeps codes in uint32_t (huffman_enc.cpp:87)
+constexpr int kHeadLen = 175;     // RIFF(12)+FRMT(19)+LMAP(136)+'LRES',size(8)
+
+struct Geom {
+  int W, H, C, stride;
+  int rows, cols, mrows, mcols;
+  int chan_size, lres_size;  // LRES payload per channel / total
+  int row_block;             // cols*C*64: FRES symbols per block row
+  int ycbcr;                 // effective flag: use_ycbcr && C >= 3
+  int lres_spans;            // ceil(lres_size / kLresSpan)
+  int use_blocks;            // FRES: block_size < in_size (huffman_enc.cpp:256)
+  long long frame_bytes;     // W*H*stride
+  long long fres_size;       // rows*row_block
+};
+
+// Per-batch device workspace of the encoder. Every array is indexed
+// [frame][...] with the stated per-frame stride (in elements).
+struct EncWs {
+  uint8_t *avg, *low;        size_t plane_stride;  // C*rows*cols (padded)
+  uint8_t *lres_sym;         size_t lres_stride;
+  uint8_t *fres_sym;         size_t fres_stride;
+  uint32_t *hist;            // [f][2][kHistStride]      0 = LRES, 1 = FRES
+  uint32_t *span_hist_l;     // [f][lres_spans][kHistStride]
+  uint32_t *span_hist_f;     // [f][rows][kHistStride]
+  uint32_t *lres_trail;      // [f][lres_spans]  trailing zeros | allzero<<31
+  uint64_t *codes;           // [f][2][kHistStride]
+  uint32_t *lens;            // [f][2][kHistStride]
+  uint8_t *tree;             // [f][2][kTreeStride]
+  uint32_t *tree_nbytes;     // [f][2]
+  uint64_t *span_bit0;       // [f][lres_spans + rows] absolute start bit in the frame's output
+  uint32_t *span_bits;       // [f][lres_spans + rows] payload bits of the span
+  int32_t *status;           // [f]
+};
+
+// Container bytes that do not depend on the pixel data, built on the host.
+struct StaticChunks {
+  uint8_t head[176];  // RIFF..HIMG FRMT LMAP 'LRES' <size>   (kHeadLen bytes)
+  uint8_t mid[272];   // QCFG FMAP 'FRES' <size>
+  int mid_len;        // 268 with chroma table, 236 without
+};
+
+struct ShiftTables {
+  uint8_t s[2][64];  // [0] luma, [1] chroma; row-major coefficient position
+};
+
+struct LresTables {
+  int16_t tab[128];   // low-res companding table (positive half)
+  uint8_t code[512];  // code[delta + 255] for delta in [-255, 255]
+};
+
+// ---- decoder ---------------------------------------------------------------
+
+constexpr int kLutBits = 10;  // first-level Huffman decode LUT
+constexpr int kDecThreads = 1024;
+
+struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
+  uint32_t payload_off;      // byte offset (in the packed stream) after the aligned tree
+  uint32_t chunk_end;        // byte offset of the end of the chunk
+  int32_t root;              // node index of the root
+  int32_t num_nodes;
+};
+
+struct DecFrame {            // written by k_dec_parse, read by later kernels
+  int32_t status;
+  int32_t ycbcr;
+  DecStream s[2];
+  int16_t lmap[128];         // decoder-side companding tables (positive halves)
+  int16_t fmap[128];
+  uint8_t shift[2][64];
+};
+
+struct DecWs {
+  DecFrame *frames;          // [f]
+  int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
+  uint32_t *lut;             // [f][2][1<<kLutBits]
+  uint32_t *row_off;         // [f][rows] payload byte offset of each FRES row
+  uint32_t *row_len;         // [f][rows]
+  uint8_t *lres_sym;         size_t lres_stride;
+  uint8_t *fres_sym;         size_t fres_stride;
+  uint8_t *low;              size_t plane_stride;
+};
+
+// ---- launch wrappers (defined in kernels_enc.hip / kernels_dec.hip) --------
+
+struct Profiler;  // host-side, see himg_hip.hip
+
+void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
+                   uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,
+                   const StaticChunks &sc, const ShiftTables &st, const LresTables &lt,
+                   const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof);
+
+void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
+                   size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
+                   int32_t *d_status, hipStream_t stream, Profiler *prof);
+
+// Stage timing hook: called before/after every kernel launch when profiling.
+void prof_begin(Profiler *p, const char *stage, hipStream_t s);
+void prof_end(Profiler *p, hipStream_t s);
+
+}  // namespace himg_dev
+#endif  // HIMG_DEV_H_

@@ -1,0 +1,584 @@
+// himg_hip.hip -- host side of the C ABI declared in include/himg_hip.h.
+//
+// Owns the device workspace, builds the data-independent container bytes and
+// kernel tables on the host (they depend only on quality / geometry), and
+// sequences the kernels of kernels_enc.hip / kernels_dec.hip.  There is no CPU
+// fallback: every compute entry point needs a working HIP device.
+#include "himg_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "himg_dev.h"
+#include "himg_tables.h"
+
+using namespace himg_dev;
+
+namespace himg_dev {
+
+struct Profiler {
+  bool enabled = false;
+  struct Rec { const char *name; hipEvent_t a, b; };
+  std::vector<Rec> pending;
+  struct Acc { std::string name; double ms = 0; int n = 0; };
+  std::vector<Acc> acc;
+  const char *cur = nullptr;
+  hipEvent_t cur_a = nullptr;
+
+  void collect() {
+    for (auto &r : pending) {
+      hipEventSynchronize(r.b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, r.a, r.b);
+      hipEventDestroy(r.a);
+      hipEventDestroy(r.b);
+      size_t i = 0;
+      for (; i < acc.size(); ++i)
+        if (acc[i].name == r.name) break;
+      if (i == acc.size()) { acc.push_back(Acc()); acc.back().name = r.name; }
+      acc[i].ms += ms;
+      acc[i].n += 1;
+    }
+    pending.clear();
+  }
+};
+
+void prof_begin(Profiler *p, const char *stage, hipStream_t s) {
+  if (!p || !p->enabled) return;
+  p->cur = stage;
+  hipEventCreate(&p->cur_a);
+  hipEventRecord(p->cur_a, s);
+}
+void prof_end(Profiler *p, hipStream_t s) {
+  if (!p || !p->enabled) return;
+  hipEvent_t b;
+  hipEventCreate(&b);
+  hipEventRecord(b, s);
+  p->pending.push_back({p->cur, p->cur_a, b});
+}
+
+}  // namespace himg_dev
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  // Grow-only device allocation.
+  bool reserve(size_t n) {
+    if (n <= cap) return true;
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (hipMalloc(&p, n) != hipSuccess) return false;
+    cap = n;
+    return true;
+  }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct himg_hip_ctx {
+  int device = 0;
+  std::string err;
+  Profiler prof;
+  hipStream_t last_stream = nullptr;
+
+  // Fixed table: LUT of the full-res companding search (FullResMapper is the
+  // same for every quality, mapper.cpp:213-223), 32769 entries.
+  DevBuf fmap_lut;
+
+  // Encoder workspace.
+  DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist;
+  Geom enc_geom{};
+  EncWs enc_ws{};
+  int enc_batch = 0;
+  bool enc_valid = false;
+
+  // Decoder workspace.
+  DevBuf d_frames, d_nodes, d_lut, d_rows, d_lres, d_fres, d_planes, d_sizes;
+  Geom dec_geom{};
+  DecWs dec_ws{};
+  int dec_batch = 0;
+  bool dec_valid = false;
+
+  // Staging for the host-buffer API.
+  DevBuf h_in, h_out, h_sizes, h_status;
+};
+
+static int fail(himg_hip_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+  if (ctx) {
+    ctx->err = what;
+    if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                  \
+  do {                                                                      \
+    hipError_t e_ = (expr);                                                 \
+    if (e_ != hipSuccess) return fail(ctx, HIMG_ERR_HIP, #expr, e_);        \
+  } while (0)
+
+static bool make_geom(int width, int height, int pixel_stride, int num_channels, int use_ycbcr,
+                      Geom *g) {
+  if (width < 1 || height < 1 || num_channels < 1 || num_channels > 4 ||
+      pixel_stride < num_channels)
+    return false;
+  g->W = width; g->H = height; g->C = num_channels; g->stride = pixel_stride;
+  g->rows = (height + 7) >> 3; g->cols = (width + 7) >> 3;
+  g->mrows = (g->rows + 15) / 16; g->mcols = (g->cols + 15) / 16;
+  g->chan_size = g->mrows * g->mcols + g->rows * g->cols;   // downsampled.cpp:171-175
+  const long long lres = (long long)g->chan_size * num_channels;
+  const long long fres = (long long)g->rows * g->cols * 64 * num_channels;
+  // The reference keeps every size in `int` (encoder.cpp:81,270,339-341).
+  if (fres > 0x7fffffffLL || (long long)width * height * pixel_stride > 0x7fffffffLL) return false;
+  g->lres_size = (int)lres;
+  g->row_block = g->cols * num_channels * 64;
+  g->ycbcr = (use_ycbcr && num_channels >= 3) ? 1 : 0;   // encoder.cpp:69
+  g->lres_spans = (g->lres_size + kLresSpan - 1) / kLresSpan;
+  g->use_blocks = g->rows > 1 ? 1 : 0;                   // block_size < in_size
+  g->frame_bytes = (long long)width * height * pixel_stride;
+  g->fres_size = fres;
+  return true;
+}
+
+extern "C" size_t himg_hip_max_packed_size(int width, int height, int num_channels) {
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g)) return 0;
+  // Payloads never exceed their symbol counts by more than the tree
+  // (huffman_enc.cpp:242-244 assumes the same); plus row headers and chunks.
+  size_t n = 12 + 19 + 136 + 8 + 72 + 188 + 8;
+  n += (size_t)g.lres_size + kTreeStride;
+  n += (size_t)g.fres_size + kTreeStride + 4u * (size_t)g.rows;
+  return round_up(n + 64, 256);
+}
+
+extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
+  if (!out) return HIMG_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return HIMG_ERR_HIP;
+  if (device < 0 || device >= count) return HIMG_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return HIMG_ERR_HIP;
+  himg_hip_ctx *ctx = new himg_hip_ctx();
+  ctx->device = device;
+  // Companding LUT for every magnitude an int16 can take.
+  std::vector<uint8_t> lut(32769);
+  int16_t fmap[128];
+  himg_tables_fullres_map(fmap);
+  for (int a = 0; a <= 32767; ++a) lut[a] = himg_tables_map_to_8bit(fmap, a);
+  lut[32768] = (uint8_t)(0u - himg_tables_map_to_8bit(fmap, -32768));  // |x| of -32768 (unreachable)
+  if (!ctx->fmap_lut.reserve(round_up(lut.size(), 256)) ||
+      hipMemcpy(ctx->fmap_lut.p, lut.data(), lut.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    delete ctx;
+    return HIMG_ERR_HIP;
+  }
+  *out = ctx;
+  return HIMG_OK;
+}
+
+extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  ctx->prof.collect();
+  DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
+                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_lut, &ctx->d_rows,
+                   &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->h_in,
+                   &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
+  for (DevBuf *b : all) b->release();
+  delete ctx;
+}
+
+extern "C" const char *himg_hip_last_error(const himg_hip_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : "no context";
+}
+
+extern "C" void himg_hip_free(void *p) { std::free(p); }
+
+// ---------------------------------------------------------------------------
+// Host-built tables and container bytes.
+// ---------------------------------------------------------------------------
+static void put_u32(uint8_t *p, uint32_t x) {
+  p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); p[3] = (uint8_t)(x >> 24);
+}
+
+static int build_static(const Geom &g, int quality, StaticChunks *sc, ShiftTables *st,
+                        LresTables *lt) {
+  memset(sc, 0, sizeof(*sc));
+  uint8_t *h = sc->head;
+  // encoder.cpp:111-129,139-166
+  memcpy(h, "RIFF", 4); put_u32(h + 4, 0); memcpy(h + 8, "HIMG", 4);
+  memcpy(h + 12, "FRMT", 4); put_u32(h + 16, 11);
+  h[20] = 1; put_u32(h + 21, (uint32_t)g.W); put_u32(h + 25, (uint32_t)g.H);
+  h[29] = (uint8_t)g.C; h[30] = (uint8_t)g.ycbcr;
+  // encoder.cpp:88-89,168-184
+  int16_t lmap[128], fmap[128];
+  himg_tables_lowres_map(quality, lmap);
+  memcpy(h + 31, "LMAP", 4);
+  const int ln = himg_tables_mapping_function(lmap, h + 39);
+  if (ln != 128) return HIMG_ERR_UNSUPPORTED;  // low-res tables never exceed 255
+  put_u32(h + 35, (uint32_t)ln);
+  memcpy(h + 167, "LRES", 4);  // size patched on the device
+  // encoder.cpp:95-100,222-256
+  himg_tables_shift(quality, 0, st->s[0]);
+  himg_tables_shift(quality, 1, st->s[1]);
+  uint8_t *m = sc->mid;
+  int o = 0;
+  memcpy(m + o, "QCFG", 4); put_u32(m + o + 4, g.ycbcr ? 64u : 32u); o += 8;
+  for (int t = 0; t < (g.ycbcr ? 2 : 1); ++t)
+    for (int i = 0; i < 32; ++i) m[o++] = (uint8_t)((st->s[t][2 * i] << 4) | st->s[t][2 * i + 1]);
+  himg_tables_fullres_map(fmap);
+  memcpy(m + o, "FMAP", 4);
+  const int fn = himg_tables_mapping_function(fmap, m + o + 8);
+  put_u32(m + o + 4, (uint32_t)fn);
+  o += 8 + fn;
+  memcpy(m + o, "FRES", 4); o += 8;  // size patched on the device
+  sc->mid_len = o;
+  // Low-res companding LUT over every possible prediction error.
+  memcpy(lt->tab, lmap, sizeof(lmap));
+  for (int d = -255; d <= 255; ++d) lt->code[d + 255] = himg_tables_map_to_8bit(lmap, d);
+  lt->code[511] = 0;
+  return HIMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Workspaces.
+// ---------------------------------------------------------------------------
+static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
+  EncWs &w = ctx->enc_ws;
+  const size_t plane = round_up((size_t)g.C * g.rows * g.cols, 256);
+  const size_t lres = round_up((size_t)g.lres_size + 16, 256);
+  const size_t fres = round_up((size_t)g.fres_size + 16, 256);
+  const int nsp = g.lres_spans + g.rows;
+  if (!ctx->e_planes.reserve(2 * plane * batch) || !ctx->e_lres.reserve(lres * batch) ||
+      !ctx->e_fres.reserve(fres * batch))
+    return fail(ctx, HIMG_ERR_HIP, "encoder workspace allocation failed");
+  // Small per-frame arrays, carved from one allocation.
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += round_up(bytes, 256); return o; };
+  const size_t o_hist = carve((size_t)batch * 2 * kHistStride * 4);
+  const size_t o_codes = carve((size_t)batch * 2 * kHistStride * 8);
+  const size_t o_lens = carve((size_t)batch * 2 * kHistStride * 4);
+  const size_t o_tree = carve((size_t)batch * 2 * kTreeStride);
+  const size_t o_tnb = carve((size_t)batch * 2 * 4);
+  const size_t o_trail = carve((size_t)batch * g.lres_spans * 4);
+  const size_t o_bit0 = carve((size_t)batch * nsp * 8);
+  const size_t o_bits = carve((size_t)batch * nsp * 4);
+  const size_t o_status = carve((size_t)batch * 4);
+  if (!ctx->e_small.reserve(off) ||
+      !ctx->e_spanhist.reserve((size_t)batch * nsp * kHistStride * 4))
+    return fail(ctx, HIMG_ERR_HIP, "encoder workspace allocation failed");
+  uint8_t *sm = (uint8_t *)ctx->e_small.p;
+  w.avg = (uint8_t *)ctx->e_planes.p;
+  w.low = w.avg + plane * batch;
+  w.plane_stride = plane;
+  w.lres_sym = (uint8_t *)ctx->e_lres.p; w.lres_stride = lres;
+  w.fres_sym = (uint8_t *)ctx->e_fres.p; w.fres_stride = fres;
+  w.hist = (uint32_t *)(sm + o_hist);
+  w.codes = (uint64_t *)(sm + o_codes);
+  w.lens = (uint32_t *)(sm + o_lens);
+  w.tree = sm + o_tree;
+  w.tree_nbytes = (uint32_t *)(sm + o_tnb);
+  w.lres_trail = (uint32_t *)(sm + o_trail);
+  w.span_bit0 = (uint64_t *)(sm + o_bit0);
+  w.span_bits = (uint32_t *)(sm + o_bits);
+  w.status = (int32_t *)(sm + o_status);
+  w.span_hist_l = (uint32_t *)ctx->e_spanhist.p;
+  w.span_hist_f = w.span_hist_l + (size_t)batch * g.lres_spans * kHistStride;
+  ctx->enc_geom = g;
+  ctx->enc_batch = batch;
+  ctx->enc_valid = true;
+  return HIMG_OK;
+}
+
+static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
+  DecWs &w = ctx->dec_ws;
+  const size_t plane = round_up((size_t)g.C * g.rows * g.cols, 256);
+  const size_t lres = round_up((size_t)g.lres_size + 16, 256);
+  const size_t fres = round_up((size_t)g.fres_size + 16, 256);
+  if (!ctx->d_frames.reserve(sizeof(DecFrame) * batch) ||
+      !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 3 * 4) ||
+      !ctx->d_lut.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
+      !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
+      !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
+      !ctx->d_sizes.reserve((size_t)batch * 4))
+    return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
+  w.frames = (DecFrame *)ctx->d_frames.p;
+  w.nodes = (int32_t *)ctx->d_nodes.p;
+  w.lut = (uint32_t *)ctx->d_lut.p;
+  w.row_off = (uint32_t *)ctx->d_rows.p;
+  w.row_len = w.row_off + (size_t)batch * g.rows;
+  w.lres_sym = (uint8_t *)ctx->d_lres.p; w.lres_stride = lres;
+  w.fres_sym = (uint8_t *)ctx->d_fres.p; w.fres_stride = fres;
+  w.low = (uint8_t *)ctx->d_planes.p; w.plane_stride = plane;
+  ctx->dec_geom = g;
+  ctx->dec_batch = batch;
+  ctx->dec_valid = true;
+  return HIMG_OK;
+}
+
+static int status_to_code(int32_t st) {
+  switch (st) {
+    case 0: return HIMG_OK;
+    case 1: return HIMG_ERR_ARG;
+    case 3: return HIMG_ERR_UNSUPPORTED;
+    case 4: return HIMG_ERR_FORMAT;
+    case 5: return HIMG_ERR_CAPACITY;
+    default: return HIMG_ERR_HIP;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Device-resident API.
+// ---------------------------------------------------------------------------
+__global__ void k_copy_status(const int32_t *src, int32_t *dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+extern "C" int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, int batch, int width,
+                                      int height, int pixel_stride, int num_channels, int quality,
+                                      int use_ycbcr, void *d_out, size_t out_stride,
+                                      uint32_t *d_sizes, int32_t *d_status, void *stream) {
+  if (!ctx || !d_frames || !d_out || !d_sizes || batch < 1 || batch > 65535) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, pixel_stride, num_channels, use_ycbcr, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  if (g.rows > 65535 || batch * g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if ((out_stride & 255) || out_stride < 1024 || ((uintptr_t)d_out & 15) || ((uintptr_t)d_frames & 15))
+    return fail(ctx, HIMG_ERR_ARG, "out_stride must be a multiple of 256; buffers 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_enc_ws(ctx, g, batch);
+  if (rc) return rc;
+  StaticChunks sc;
+  ShiftTables st;
+  LresTables lt;
+  rc = build_static(g, quality, &sc, &st, &lt);
+  if (rc) return fail(ctx, rc, "unsupported table configuration");
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  launch_encode(g, ctx->enc_ws, batch, (const uint8_t *)d_frames, (uint8_t *)d_out, out_stride,
+                d_sizes, sc, st, lt, (const uint8_t *)ctx->fmap_lut.p, s, &ctx->prof);
+  if (d_status)
+    hipLaunchKernelGGL(k_copy_status, dim3((batch + 63) / 64), dim3(64), 0, s, ctx->enc_ws.status,
+                       d_status, batch);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, size_t in_stride,
+                                      const uint32_t *h_sizes, int batch, int width, int height,
+                                      int num_channels, void *d_out, int32_t *d_status,
+                                      void *stream) {
+  if (!ctx || !d_packed || !h_sizes || !d_out || !d_status || batch < 1 || batch > 65535)
+    return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  if (g.rows + 1 > 65535 || batch * g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if ((in_stride & 3) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
+    return fail(ctx, HIMG_ERR_ARG, "in_stride must be a multiple of 4; buffers 16-byte aligned");
+  for (int i = 0; i < batch; ++i)
+    if (h_sizes[i] > in_stride && batch > 1) return fail(ctx, HIMG_ERR_ARG, "stream larger than in_stride");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, batch);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, h_sizes, (size_t)batch * 4, hipMemcpyHostToDevice, s));
+  launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
+                (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Host-buffer API.
+// ---------------------------------------------------------------------------
+extern "C" int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
+                               int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                               uint8_t **out, size_t *out_size) {
+  if (!ctx || !data || !out || !out_size) return HIMG_ERR_ARG;
+  *out = nullptr;
+  *out_size = 0;
+  Geom g;
+  if (!make_geom(width, height, pixel_stride, num_channels, use_ycbcr, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t cap = himg_hip_max_packed_size(width, height, num_channels);
+  if (!ctx->h_in.reserve(round_up((size_t)g.frame_bytes, 256)) || !ctx->h_out.reserve(cap) ||
+      !ctx->h_sizes.reserve(256) || !ctx->h_status.reserve(256))
+    return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+  HIP_TRY(ctx, hipMemcpy(ctx->h_in.p, data, (size_t)g.frame_bytes, hipMemcpyHostToDevice));
+  int rc = himg_hip_encode_device(ctx, ctx->h_in.p, 1, width, height, pixel_stride, num_channels,
+                                  quality, use_ycbcr, ctx->h_out.p, cap, (uint32_t *)ctx->h_sizes.p,
+                                  (int32_t *)ctx->h_status.p, nullptr);
+  if (rc) return rc;
+  uint32_t n = 0;
+  int32_t st = 0;
+  HIP_TRY(ctx, hipMemcpy(&n, ctx->h_sizes.p, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(&st, ctx->h_status.p, 4, hipMemcpyDeviceToHost));
+  if (st) return fail(ctx, status_to_code(st), "device encode reported an error");
+  uint8_t *buf = (uint8_t *)std::malloc(n ? n : 1);
+  if (!buf) return fail(ctx, HIMG_ERR_ARG, "out of host memory");
+  HIP_TRY(ctx, hipMemcpy(buf, ctx->h_out.p, n, hipMemcpyDeviceToHost));
+  *out = buf;
+  *out_size = n;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size,
+                               uint8_t **out, int *width, int *height, int *num_channels) {
+  if (!ctx || !packed || !out || !width || !height || !num_channels) return HIMG_ERR_ARG;
+  *out = nullptr;
+  // Geometry comes from the FRMT chunk; the host only needs it to size the
+  // launch, every check is repeated on the device (k_dec_parse).
+  // decoder.cpp:144-200
+  if (packed_size < 12 || packed_size > 0x7fffffffu || memcmp(packed, "RIFF", 4) != 0 ||
+      memcmp(packed + 8, "HIMG", 4) != 0)
+    return fail(ctx, HIMG_ERR_FORMAT, "Not a RIFF HIMG file.");
+  size_t idx = 12;
+  int W = 0, H = 0, C = 0;
+  for (;;) {
+    if (idx + 8 > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.");
+    const uint32_t sz = packed[idx + 4] | (packed[idx + 5] << 8) | (packed[idx + 6] << 16) |
+                        ((uint32_t)packed[idx + 7] << 24);
+    const bool frmt = memcmp(packed + idx, "FRMT", 4) == 0;
+    idx += 8;
+    if (idx + sz > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.");
+    if (frmt) {
+      if (sz < 11 || packed[idx] != 1) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.");
+      W = (int)(packed[idx + 1] | (packed[idx + 2] << 8) | (packed[idx + 3] << 16) | ((uint32_t)packed[idx + 4] << 24));
+      H = (int)(packed[idx + 5] | (packed[idx + 6] << 8) | (packed[idx + 7] << 16) | ((uint32_t)packed[idx + 8] << 24));
+      C = packed[idx + 9];
+      break;
+    }
+    idx += sz;
+  }
+  Geom g;
+  if (!make_geom(W, H, C, C, 1, &g)) return fail(ctx, HIMG_ERR_UNSUPPORTED, "unsupported geometry");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t in_cap = round_up(packed_size + 16, 256);
+  const size_t out_bytes = (size_t)W * H * C;
+  if (!ctx->h_in.reserve(in_cap) || !ctx->h_out.reserve(round_up(out_bytes, 256)) ||
+      !ctx->h_status.reserve(256))
+    return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+  HIP_TRY(ctx, hipMemcpy(ctx->h_in.p, packed, packed_size, hipMemcpyHostToDevice));
+  const uint32_t sz32 = (uint32_t)packed_size;
+  int rc = himg_hip_decode_device(ctx, ctx->h_in.p, in_cap, &sz32, 1, W, H, C, ctx->h_out.p,
+                                  (int32_t *)ctx->h_status.p, nullptr);
+  if (rc) return rc;
+  int32_t st = 0;
+  HIP_TRY(ctx, hipMemcpy(&st, ctx->h_status.p, 4, hipMemcpyDeviceToHost));
+  if (st) return fail(ctx, status_to_code(st), "Error: Invalid Huffman data.");
+  uint8_t *buf = (uint8_t *)std::malloc(out_bytes ? out_bytes : 1);
+  if (!buf) return fail(ctx, HIMG_ERR_ARG, "out of host memory");
+  HIP_TRY(ctx, hipMemcpy(buf, ctx->h_out.p, out_bytes, hipMemcpyDeviceToHost));
+  *out = buf;
+  *width = W; *height = H; *num_channels = C;
+  return HIMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Introspection.
+// ---------------------------------------------------------------------------
+extern "C" int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void *dst,
+                                   size_t dst_bytes, size_t *written) {
+  if (!ctx || !dst) return HIMG_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  const void *src = nullptr;
+  size_t n = 0;
+  const bool dec = (what & 0x100) != 0;  // 0x100 | what: decoder-side buffers
+  what &= 0xff;
+  if (!dec) {
+    if (!ctx->enc_valid || frame < 0 || frame >= ctx->enc_batch) return HIMG_ERR_ARG;
+    const Geom &g = ctx->enc_geom;
+    const EncWs &w = ctx->enc_ws;
+    const int nsp = g.lres_spans + g.rows;
+    switch (what) {
+      case HIMG_DBG_AVG: src = w.avg + frame * w.plane_stride; n = (size_t)g.C * g.rows * g.cols; break;
+      case HIMG_DBG_LOWRES: src = w.low + frame * w.plane_stride; n = (size_t)g.C * g.rows * g.cols; break;
+      case HIMG_DBG_LRES_SYM: src = w.lres_sym + frame * w.lres_stride; n = (size_t)g.lres_size; break;
+      case HIMG_DBG_FRES_SYM: src = w.fres_sym + frame * w.fres_stride; n = (size_t)g.fres_size; break;
+      case HIMG_DBG_LRES_HIST: src = w.hist + ((size_t)frame * 2 + 0) * kHistStride; n = kNumSym * 4; break;
+      case HIMG_DBG_FRES_HIST: src = w.hist + ((size_t)frame * 2 + 1) * kHistStride; n = kNumSym * 4; break;
+      case HIMG_DBG_LRES_LEN: src = w.lens + ((size_t)frame * 2 + 0) * kHistStride; n = kNumSym * 4; break;
+      case HIMG_DBG_FRES_LEN: src = w.lens + ((size_t)frame * 2 + 1) * kHistStride; n = kNumSym * 4; break;
+      case HIMG_DBG_LRES_CODE: src = w.codes + ((size_t)frame * 2 + 0) * kHistStride; n = kNumSym * 8; break;
+      case HIMG_DBG_FRES_CODE: src = w.codes + ((size_t)frame * 2 + 1) * kHistStride; n = kNumSym * 8; break;
+      case HIMG_DBG_FRES_ROW_BYTES: {
+        // Convert payload bits to bytes on the host.
+        std::vector<uint32_t> bits(g.rows);
+        HIP_TRY(ctx, hipMemcpy(bits.data(), w.span_bits + (size_t)frame * nsp + g.lres_spans,
+                               (size_t)g.rows * 4, hipMemcpyDeviceToHost));
+        n = (size_t)g.rows * 4;
+        if (dst_bytes < n) return HIMG_ERR_CAPACITY;
+        for (int r = 0; r < g.rows; ++r) ((uint32_t *)dst)[r] = (bits[r] + 7) >> 3;
+        if (written) *written = n;
+        return HIMG_OK;
+      }
+      default: return HIMG_ERR_ARG;
+    }
+  } else {
+    if (!ctx->dec_valid || frame < 0 || frame >= ctx->dec_batch) return HIMG_ERR_ARG;
+    const Geom &g = ctx->dec_geom;
+    const DecWs &w = ctx->dec_ws;
+    switch (what) {
+      case HIMG_DBG_LOWRES: src = w.low + frame * w.plane_stride; n = (size_t)g.C * g.rows * g.cols; break;
+      case HIMG_DBG_LRES_SYM: src = w.lres_sym + frame * w.lres_stride; n = (size_t)g.lres_size; break;
+      case HIMG_DBG_FRES_SYM: src = w.fres_sym + frame * w.fres_stride; n = (size_t)g.fres_size; break;
+      default: return HIMG_ERR_ARG;
+    }
+  }
+  if (dst_bytes < n) return HIMG_ERR_CAPACITY;
+  HIP_TRY(ctx, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+  if (written) *written = n;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_profile_enable(himg_hip_ctx *ctx, int enable) {
+  if (!ctx) return HIMG_ERR_ARG;
+  ctx->prof.enabled = enable != 0;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_profile_reset(himg_hip_ctx *ctx) {
+  if (!ctx) return HIMG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  ctx->prof.collect();
+  ctx->prof.acc.clear();
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_profile_read(himg_hip_ctx *ctx, int *n_stages,
+                                     const char *names[HIMG_MAX_STAGES],
+                                     double ms[HIMG_MAX_STAGES], int launches[HIMG_MAX_STAGES]) {
+  if (!ctx || !n_stages) return HIMG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  ctx->prof.collect();
+  int n = 0;
+  for (auto &a : ctx->prof.acc) {
+    if (n >= HIMG_MAX_STAGES) break;
+    names[n] = a.name.c_str();
+    ms[n] = a.ms;
+    launches[n] = a.n;
+    ++n;
+  }
+  *n_stages = n;
+  return HIMG_OK;
+}

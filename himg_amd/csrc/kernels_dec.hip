@@ -1,0 +1,673 @@
+// kernels_dec.hip -- HIMG decode path as hand-written HIP for gfx950 (MI355X).
+//
+// Pipeline (all on device, batched over frames):
+//   k_dec_parse       RIFF/chunk walk, tables, Huffman trees, row index
+//                     (decoder.cpp:144-272,428-461, huffman_dec.cpp:152-251)
+//   k_dec_huff        RLE+Huffman decode of the LRES stream and of every FRES
+//                     block row (huffman_dec.cpp:274-418).  Each stream is decoded
+//                     by a whole workgroup: the payload is cut into 256-bit
+//                     sub-sequences, every lane decodes one speculatively and the
+//                     workgroup iterates to the self-synchronised fixpoint, then a
+//                     prefix scan of the symbol counts places the output.
+//   k_lres_unpredict  inverse low-res prediction              (downsampled.cpp:318-382)
+//   k_tile_inv        gather, dequantise, inverse WHT, low-res add, clamp,
+//                     colour inverse (decoder.cpp:331-426, quantize.cpp:153-165,
+//                     hadamard.cpp:90-103, ycbcr.cpp:54-82)
+#include "himg_dev.h"
+
+namespace himg_dev {
+
+__device__ static constexpr uint8_t kScanD[64] = {
+    0,  1,  9,  8,  16, 17, 18, 10, 2,  3,  11, 19, 27, 26, 25, 24,
+    32, 33, 34, 35, 36, 28, 20, 12, 4,  5,  13, 21, 29, 37, 45, 44,
+    43, 42, 41, 40, 48, 49, 50, 51, 52, 53, 54, 46, 38, 30, 22, 14,
+    6,  7,  15, 23, 31, 39, 47, 55, 63, 62, 61, 60, 59, 58, 57, 56};
+
+// Device status values (host maps them to HIMG_ERR_*): 0 ok, 1 geometry
+// mismatch, 3 outside the built scope, 4 the reference would return false.
+constexpr int kStGeom = 1, kStUnsupported = 3, kStFormat = 4;
+constexpr int kMaxDepth = 48;   // deepest code the decoder walks (+14 extra bits <= 64)
+constexpr int kMaxNodes = 2 * kNumSym - 1;
+
+__device__ __forceinline__ int clamp255d(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+__device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// Forward chunk search (decoder.cpp:428-461).  Returns false when not found.
+__device__ bool find_chunk(const uint8_t *p, uint32_t n, uint32_t *idx, uint32_t tag,
+                           uint32_t *size) {
+  for (;;) {
+    if (*idx + 8 > n) return false;
+    const uint32_t t = rd32(p + *idx), sz = rd32(p + *idx + 4);
+    *idx += 8;
+    if (sz > 0x7fffffffu || (unsigned long long)*idx + sz > n) return false;
+    if (t == tag) { *size = sz; return true; }
+    *idx += sz;
+  }
+}
+
+__device__ bool parse_map(const uint8_t *in, uint32_t size, int16_t *t) {
+  // mapper.cpp:127-157
+  if (size < 1) return false;
+  const int n1 = in[0];
+  if (n1 > 127 || (uint32_t)(1 + n1 + 2 * (127 - n1)) != size) return false;
+  const uint8_t *q = in + 1;
+  t[0] = 0;
+  for (int i = 1; i <= 127; ++i) {
+    if (i <= n1) { t[i] = (int16_t)*q++; }
+    else { t[i] = (int16_t)(uint16_t)(q[0] | (q[1] << 8)); q += 2; }
+  }
+  return true;
+}
+
+// Pre-order tree recovery (huffman_dec.cpp:152-213), iterative.  Node arrays:
+// nodes[3*i+0] child_a, +1 child_b, +2 symbol (-1 for branches); per node the
+// low bits of its code and its depth are kept in aux[] for the LUT fill.
+struct TreeAux { uint32_t code; int32_t depth; };
+
+__device__ int recover_tree(const uint8_t *p, uint32_t begin, uint32_t end, int32_t *nodes,
+                            TreeAux *aux, int32_t *num_nodes, uint32_t *payload_off) {
+  // Explicit stack of pending subtrees: (parent, which child, code, depth).
+  int32_t st_par[kMaxDepth + 4], st_depth[kMaxDepth + 4];
+  uint32_t st_code[kMaxDepth + 4];
+  uint8_t st_which[kMaxDepth + 4];
+  int sp = 0, count = 0;
+  unsigned long long bit = 8ull * begin;
+  const unsigned long long bit_end = 8ull * end;
+  st_par[0] = -1; st_which[0] = 0; st_code[0] = 0; st_depth[0] = 0; sp = 1;
+  while (sp > 0) {
+    --sp;
+    const int par = st_par[sp], which = st_which[sp], depth = st_depth[sp];
+    const uint32_t code = st_code[sp];
+    if (count >= kMaxNodes) return kStFormat;
+    const int me = count++;
+    if (par >= 0) nodes[3 * par + which] = me;
+    nodes[3 * me + 0] = -1; nodes[3 * me + 1] = -1; nodes[3 * me + 2] = -1;
+    aux[me].code = code; aux[me].depth = depth;
+    if (bit >= bit_end) return kStFormat;  // ReadBitChecked, huffman_dec.cpp:51-60
+    const int leaf = (p[bit >> 3] >> (bit & 7)) & 1;
+    ++bit;
+    if (leaf) {
+      if (bit + 9 > bit_end) return kStFormat;  // ReadBitsChecked, huffman_dec.cpp:94-106
+      int sym = 0;
+      for (int i = 0; i < 9; ++i, ++bit) sym |= ((p[bit >> 3] >> (bit & 7)) & 1) << i;
+      nodes[3 * me + 2] = sym;
+    } else {
+      if (depth + 1 > kMaxDepth) return kStUnsupported;
+      // child_b is pushed first so that child_a is parsed first (pre-order).
+      st_par[sp] = me; st_which[sp] = 1; st_depth[sp] = depth + 1;
+      st_code[sp] = depth < 32 ? (code | (1u << depth)) : code; ++sp;
+      st_par[sp] = me; st_which[sp] = 0; st_depth[sp] = depth + 1; st_code[sp] = code; ++sp;
+    }
+  }
+  *num_nodes = count;
+  *payload_off = (uint32_t)((bit + 7) >> 3);  // AlignToByte, huffman_dec.cpp:229
+  return 0;
+}
+
+// LUT entry: [8:0] symbol | [9] "continue at node" flag | [19:10] node | [25:20] bits.
+__device__ __forceinline__ uint32_t lut_leaf(int sym, int bits) { return (uint32_t)sym | ((uint32_t)bits << 20); }
+__device__ __forceinline__ uint32_t lut_node(int node, int bits) { return 512u | ((uint32_t)node << 10) | ((uint32_t)bits << 20); }
+
+// ---------------------------------------------------------------------------
+// k_dec_parse: one wavefront per frame; lane 0 walks the container, the whole
+// wave fills the two first-level decode LUTs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_t *packed,
+                                                  size_t in_stride, const uint32_t *sizes) {
+  __shared__ TreeAux aux[2][kMaxNodes + 1];
+  __shared__ int s_status;
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  const uint32_t n = sizes[f];
+  DecFrame *df = ws.frames + f;
+  int32_t *nodes0 = ws.nodes + ((size_t)f * 2 + 0) * (kMaxNodes + 1) * 3;
+  int32_t *nodes1 = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
+
+  if (lane == 0) {
+    int st = 0;
+    uint32_t idx = 12, sz = 0;
+    do {
+      // decoder.cpp:144-166
+      if (n < 12 || rd32(p) != 0x46464952u /*RIFF*/ || rd32(p + 4) + 8u != n ||
+          rd32(p + 8) != 0x474d4948u /*HIMG*/) { st = kStFormat; break; }
+      // decoder.cpp:168-200
+      if (!find_chunk(p, n, &idx, 0x544d5246u /*FRMT*/, &sz) || sz < 11 || p[idx] != 1) { st = kStFormat; break; }
+      {
+        const uint32_t w = rd32(p + idx + 1), h = rd32(p + idx + 5);
+        const int c = p[idx + 9];
+        df->ycbcr = (p[idx + 10] != 0 && c >= 3) ? 1 : 0;
+        if ((int)w != g.W || (int)h != g.H || c != g.C) { st = kStGeom; break; }
+        idx += sz;
+      }
+      // decoder.cpp:202-212
+      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz) || !parse_map(p + idx, sz, df->lmap)) { st = kStFormat; break; }
+      idx += sz;
+      // decoder.cpp:214-232: LRES is one unblocked stream.
+      if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { st = kStFormat; break; }
+      df->s[0].chunk_end = idx + sz;
+      st = recover_tree(p, idx, idx + sz, nodes0, aux[0], &df->s[0].num_nodes, &df->s[0].payload_off);
+      if (st) break;
+      df->s[0].root = 0;
+      // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
+      if (df->s[0].payload_off >= df->s[0].chunk_end) { st = kStFormat; break; }
+      idx += sz;
+      // decoder.cpp:250-260, quantize.cpp:190-213
+      if (!find_chunk(p, n, &idx, 0x47464351u /*QCFG*/, &sz) || sz != (df->ycbcr ? 64u : 32u)) { st = kStFormat; break; }
+      for (int i = 0; i < 32; ++i) {
+        df->shift[0][2 * i] = p[idx + i] >> 4; df->shift[0][2 * i + 1] = p[idx + i] & 15;
+        const uint8_t x = df->ycbcr ? p[idx + 32 + i] : 0;
+        df->shift[1][2 * i] = x >> 4; df->shift[1][2 * i + 1] = x & 15;
+      }
+      idx += sz;
+      // decoder.cpp:262-272
+      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz) || !parse_map(p + idx, sz, df->fmap)) { st = kStFormat; break; }
+      idx += sz;
+      // decoder.cpp:274-290
+      if (!find_chunk(p, n, &idx, 0x53455246u /*FRES*/, &sz)) { st = kStFormat; break; }
+      df->s[1].chunk_end = idx + sz;
+      // Trap T2: the decoder derives use_blocks from the COMPRESSED size
+      // (huffman_dec.cpp:215-219); UncompressBlock refuses when it is false (:265).
+      if (!((uint32_t)g.row_block < sz)) { st = kStFormat; break; }
+      st = recover_tree(p, idx, idx + sz, nodes1, aux[1], &df->s[1].num_nodes, &df->s[1].payload_off);
+      if (st) break;
+      df->s[1].root = 0;
+      if (df->s[1].payload_off >= df->s[1].chunk_end) { st = kStFormat; break; }
+      // Row index: serial walk over the size headers (huffman_dec.cpp:232-248).
+      uint32_t q = df->s[1].payload_off, end = df->s[1].chunk_end;
+      uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
+      int r = 0;
+      while (q != end) {
+        if (q + 2 > end) { st = kStFormat; break; }
+        uint32_t len = p[q] | (p[q + 1] << 8);
+        q += 2;
+        if (len & 0x8000u) {
+          if (q + 2 > end) { st = kStFormat; break; }
+          len = (len & 0x7fffu) | ((uint32_t)(p[q] | (p[q + 1] << 8)) << 15);
+          q += 2;
+        }
+        if (len > end - q) { st = kStFormat; break; }
+        if (r < g.rows) { ro[r] = q; rl[r] = len; }
+        ++r;
+        q += len;
+      }
+      if (!st && r < g.rows) st = kStFormat;  // fewer blocks than block rows
+    } while (0);
+    // A tree that is a single leaf decodes without consuming code bits in the
+    // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
+    // the encoder's 1-bit codes; such streams are rejected here.
+    if (!st && (nodes0[2] >= 0 || nodes1[2] >= 0)) st = kStFormat;
+    df->status = st;
+    s_status = st;
+  }
+  __syncthreads();
+  if (s_status) return;
+
+  // First-level LUTs (kLutBits wide, LSB-first codes index them directly).
+  for (int s = 0; s < 2; ++s) {
+    const int32_t *nodes = s ? nodes1 : nodes0;
+    uint32_t *lut = ws.lut + ((size_t)f * 2 + s) * (1u << kLutBits);
+    const int nn = df->s[s].num_nodes;
+    for (int k = lane; k < nn; k += 64) {
+      const int depth = aux[s][k].depth;
+      const uint32_t code = aux[s][k].code;
+      const int sym = nodes[3 * k + 2];
+      if (sym >= 0 && depth <= kLutBits) {
+        for (uint32_t i = 0; i < (1u << (kLutBits - depth)); ++i)
+          lut[(i << depth) | code] = lut_leaf(sym, depth);
+      } else if (sym < 0 && depth == kLutBits) {
+        lut[code] = lut_node(k, depth);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_dec_huff
+// ---------------------------------------------------------------------------
+constexpr int kSubBits = 256;                                    // bits per sub-sequence
+constexpr int kChunkBits = kDecThreads * kSubBits;               // per workgroup iteration
+constexpr int kPayWords = kChunkBits / 32 + 8;                   // staged payload (+ slack)
+constexpr int kWinBytes = 32768;                                 // output window in LDS
+
+struct Tok { int sym; int nbits; int count; };
+
+// Decode one token at bit `pos` of the staged payload.
+__device__ __forceinline__ Tok decode_token(const uint32_t *pay, uint32_t pos, const uint32_t *lut,
+                                            const short *ca, const short *cb, const short *sy) {
+  const uint32_t wi = pos >> 5, sh = pos & 31;
+  const uint32_t w0 = pay[wi], w1 = pay[wi + 1], w2 = pay[wi + 2];
+  unsigned long long v = (((unsigned long long)w1 << 32) | w0) >> sh;
+  if (sh) v |= (unsigned long long)w2 << (64 - sh);
+  const uint32_t e = lut[v & ((1u << kLutBits) - 1)];
+  int len = (int)(e >> 20) & 63;
+  int sym;
+  if (e & 512u) {
+    int node = (int)(e >> 10) & 1023;
+    while (sy[node] < 0 && len < kMaxDepth + 1) {
+      node = ((v >> len) & 1ull) ? cb[node] : ca[node];
+      ++len;
+    }
+    sym = sy[node];
+  } else {
+    sym = (int)(e & 511u);
+  }
+  Tok t;
+  t.sym = sym;
+  if (sym < 256) { t.nbits = len; t.count = 1; return t; }
+  // RLE symbols (huffman_common.h:24-28, huffman_dec.cpp:330-354).
+  const int eb = sym == 256 ? 0 : sym == 257 ? 2 : sym == 258 ? 4 : sym == 259 ? 8 : 14;
+  const int base = sym == 256 ? 2 : sym == 257 ? 3 : sym == 258 ? 7 : sym == 259 ? 23 : 279;
+  const int extra = (int)((v >> len) & ((1ull << eb) - 1ull));
+  t.nbits = len + eb;
+  t.count = (sym <= 260) ? base + extra : -1;  // symbols above 260: reference aborts (:349-352)
+  return t;
+}
+
+// Exclusive scan of a 64-bit value over the 1024-thread workgroup.
+__device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v,
+                                                             unsigned long long *sm,
+                                                             unsigned long long *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) sm[wave] = incl;
+  __syncthreads();
+  unsigned long long pre = 0, tot = 0;
+  for (int w = 0; w < kDecThreads / 64; ++w) {
+    if (w < wave) pre += sm[w];
+    tot += sm[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + incl - v;
+}
+
+__global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, const uint8_t *packed,
+                                                          size_t in_stride, const uint32_t *sizes) {
+  __shared__ uint32_t pay[kPayWords];
+  __shared__ uint32_t win[kWinBytes / 4];
+  __shared__ uint32_t lut[1 << kLutBits];
+  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ uint32_t nxt[kDecThreads + 1];
+  __shared__ unsigned long long sm64[kDecThreads / 64];
+  __shared__ int s_flag;
+  __shared__ unsigned long long s_endbit;  // bit position right after the token that completes the output
+  __shared__ int s_err;
+
+  const int blk = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  const int strm = blk == 0 ? 0 : 1;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  const uint32_t stream_size = sizes[f];
+
+  uint32_t pay_off, pay_len, out_size;
+  uint8_t *out;
+  if (strm == 0) {
+    pay_off = df->s[0].payload_off;
+    pay_len = df->s[0].chunk_end - pay_off;
+    out_size = (uint32_t)g.lres_size;
+    out = ws.lres_sym + (size_t)f * ws.lres_stride;
+  } else {
+    const int r = blk - 1;
+    pay_off = ws.row_off[(size_t)f * g.rows + r];
+    pay_len = ws.row_len[(size_t)f * g.rows + r];
+    out_size = (uint32_t)g.row_block;
+    out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
+  }
+
+  {
+    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
+    const int nn = df->s[strm].num_nodes;
+    for (int k = tid; k < nn; k += kDecThreads) {
+      ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
+    }
+    const uint32_t *gl = ws.lut + ((size_t)f * 2 + strm) * (1u << kLutBits);
+    for (int k = tid; k < (1 << kLutBits); k += kDecThreads) lut[k] = gl[k];
+    if (tid == 0) { s_err = 0; s_endbit = ~0ull; }
+  }
+  __syncthreads();
+
+  const unsigned long long P1 = 8ull * pay_len;  // payload end, in bits from pay_off
+  unsigned long long cur = 0;                    // exact bit position of the next token
+  unsigned long long O0 = 0;                     // symbols produced so far
+
+  while (cur < P1 && O0 < out_size) {
+    // ---- stage this chunk's payload bytes in LDS (zero beyond the stream) ----
+    // Word j of pay[] holds stream bytes [gb + 4j, gb + 4j + 4).
+    const unsigned long long abs_bit = 8ull * pay_off + cur;
+    const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;         // dword aligned byte offset
+    const uint32_t rel0 = (uint32_t)(abs_bit - 8ull * gb);     // bit of `cur` inside pay[]
+    for (int j = tid; j < kPayWords; j += kDecThreads) {
+      const uint32_t b = gb + 4u * j;
+      uint32_t w = 0;
+      if (b + 4 <= stream_size) {
+        w = *reinterpret_cast<const uint32_t *>(p + b);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (b + k < stream_size) w |= (uint32_t)p[b + k] << (8 * k);
+      }
+      pay[j] = w;
+    }
+    __syncthreads();
+
+    // Limits in staged-bit coordinates.
+    const unsigned long long rem = P1 - cur;  // payload bits left from cur
+    const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kChunkBits ? rem : kChunkBits);
+    const uint32_t my_b0 = rel0 + tid * kSubBits;
+    uint32_t lim = rel0 + (tid + 1) * kSubBits;
+    if (lim > rel_end) lim = rel_end;
+
+    // ---- speculative decode to the self-synchronised fixpoint ----
+    uint32_t start = my_b0 < rel_end ? my_b0 : rel_end;
+    uint32_t endpos = start;
+    unsigned long long cnt = 0;
+    bool dirty = true;
+    for (;;) {
+      if (dirty) {
+        uint32_t pos = start;
+        unsigned long long c = 0;
+        while (pos < lim) {
+          const Tok t = decode_token(pay, pos, lut, ca, cb, sy);
+          pos += t.nbits ? t.nbits : 1;
+          c += (unsigned long long)(t.count > 0 ? t.count : 0);
+        }
+        endpos = pos;
+        cnt = c;
+      }
+      nxt[tid + 1] = endpos;
+      if (tid == 0) s_flag = 0;
+      __syncthreads();
+      const uint32_t ns = tid == 0 ? rel0 : nxt[tid];
+      dirty = (ns != start);
+      start = ns;
+      if (dirty) s_flag = 1;
+      __syncthreads();
+      const int any = s_flag;
+      __syncthreads();
+      if (!any) break;
+    }
+    // Here: thread t decodes exactly the tokens that START in [start, lim) and
+    // the chain is exact from the chunk's first token on.
+    unsigned long long tot;
+    const unsigned long long off = block_scan_u64(cnt, sm64, &tot);
+    const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
+
+    // ---- produce symbols window by window (zero runs are the window's fill) ----
+    uint32_t bp = start;
+    unsigned long long op = O0 + off;
+    bool done = !(bp < lim) || op >= out_size;
+    for (unsigned long long wb = (O0 / kWinBytes) * kWinBytes; wb < O1; wb += kWinBytes) {
+      for (int k = tid; k < kWinBytes / 4; k += kDecThreads) win[k] = 0;
+      __syncthreads();
+      const unsigned long long we = wb + kWinBytes;
+      while (!done && op < we) {
+        const Tok t = decode_token(pay, bp, lut, ca, cb, sy);
+        if (t.count < 0 || t.nbits == 0) { s_err = 1; done = true; break; }
+        if (t.sym < 256) {
+          if (t.sym) {
+            const uint32_t o = (uint32_t)(op - wb);
+            atomicOr(&win[o >> 2], (uint32_t)t.sym << ((o & 3) * 8));
+          }
+        } else if (op + (unsigned long long)t.count > out_size) {
+          s_err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
+          done = true;
+          break;
+        }
+        op += (unsigned long long)t.count;
+        bp += t.nbits;
+        if (op >= out_size) { s_endbit = cur + (bp - rel0); done = true; }
+        else if (!(bp < lim)) done = true;
+      }
+      __syncthreads();
+      // Flush [max(wb, O0), min(we, O1)) to the symbol buffer.
+      const unsigned long long lo = wb > O0 ? wb : O0, hi = we < O1 ? we : O1;
+      const uint32_t l = (uint32_t)(lo - wb), h = (uint32_t)(hi - wb);
+      const uint32_t la = (l + 15u) & ~15u, ha = h & ~15u;
+      if (la <= ha && (((uintptr_t)(out + wb)) & 15) == 0) {
+        for (uint32_t k = l + tid; k < la; k += kDecThreads) out[wb + k] = (uint8_t)(win[k >> 2] >> ((k & 3) * 8));
+        for (uint32_t k = la / 16 + tid; k < ha / 16; k += kDecThreads) {
+          uint4 q;
+          q.x = win[4 * k]; q.y = win[4 * k + 1]; q.z = win[4 * k + 2]; q.w = win[4 * k + 3];
+          *reinterpret_cast<uint4 *>(out + wb + 16ull * k) = q;
+        }
+        for (uint32_t k = ha + tid; k < h; k += kDecThreads) out[wb + k] = (uint8_t)(win[k >> 2] >> ((k & 3) * 8));
+      } else {
+        for (uint32_t k = l + tid; k < h; k += kDecThreads) out[wb + k] = (uint8_t)(win[k >> 2] >> ((k & 3) * 8));
+      }
+      __syncthreads();
+    }
+
+    // ---- advance to the next chunk ----
+    if (tid == kDecThreads - 1) nxt[0] = endpos;
+    __syncthreads();
+    const uint32_t last_end = nxt[0];
+    cur += (unsigned long long)(last_end - rel0);
+    O0 += tot;
+    if (last_end == rel0) break;  // no progress (cannot happen on a valid stream)
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
+  if (tid == 0) {
+    int bad = s_err;
+    if (O0 < out_size) bad = 1;                 // ran out of payload before the block was full
+    const unsigned long long E = s_endbit;      // bits consumed when the block became full
+    // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
+    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+    if (bad) atomicMax(&df->status, kStFormat);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_lres_unpredict: one wavefront per 16x16 macro block, anti-diagonal
+// wavefronts like k_lres_predict (downsampled.cpp:318-382).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int predict_d(int s1, int s2, int s3, int p) {
+  switch (p) {
+    default:
+    case 0: return clamp255d((3 * (s2 + s3) - 2 * s1 + 2) >> 2);
+    case 1: return s2;
+    case 2: return s3;
+    case 3: return (s2 + s3 + 1) >> 1;
+    case 4: return clamp255d(s2 + s3 - s1);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
+  __shared__ uint8_t rec[16][17];
+  const int mu = blockIdx.x, mv = blockIdx.y;
+  const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
+  const int lane = threadIdx.x;
+  const DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  const uint8_t *in = ws.lres_sym + (size_t)f * ws.lres_stride + (size_t)c * g.chan_size;
+  uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * g.cols;
+  const int u0 = mu * 16, v0 = mv * 16;
+  const int bw = min(16, g.cols - u0), bh = min(16, g.rows - v0);
+  // DecodePredictor (downsampled.cpp:37-39): uint8 + 2 in int arithmetic, so
+  // stored 254/255 come back as 256/257 and fall into PredictSample's default.
+  const int pc = (int)in[mv * g.mcols + mu] + 2;
+  const uint8_t *src = in + g.mrows * g.mcols + (size_t)v0 * g.cols + (size_t)bh * u0;
+  for (int d = 0; d < 31; ++d) {
+    const int dv = lane, du = d - lane;
+    if (lane < 16 && dv < bh && du >= 0 && du < bw) {
+      int s1, s2, s3;
+      if (du > 0 && dv > 0) { s1 = rec[dv - 1][du - 1]; s2 = rec[dv - 1][du]; s3 = rec[dv][du - 1]; }
+      else if (du > 0) { s1 = s2 = s3 = rec[dv][du - 1]; }
+      else if (dv > 0) { s1 = s2 = s3 = rec[dv - 1][du]; }
+      else { s1 = s2 = s3 = 128; }
+      const int predicted = predict_d(s1, s2, s3, pc);
+      const int sc = (int8_t)src[dv * bw + du];
+      // mapper.h:33-35 with the mirrored table (mapper.cpp:148-154).
+      const int un = sc >= 0 ? df->lmap[sc] : (sc == -128 ? -df->lmap[127] : -df->lmap[-sc]);
+      const int val = clamp255d((int)(int16_t)(predicted + un));
+      rec[dv][du] = (uint8_t)val;
+      m[(size_t)(v0 + dv) * g.cols + u0 + du] = (uint8_t)val;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_tile_inv: one lane per 8x8 tile.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void interp9d(int a[9]) {
+  a[4] = (a[0] + a[8] + 1) >> 1;
+  a[2] = (a[0] + a[4] + 1) >> 1;
+  a[6] = (a[4] + a[8] + 1) >> 1;
+  a[1] = (a[0] + a[2] + 1) >> 1;
+  a[3] = (a[2] + a[4] + 1) >> 1;
+  a[5] = (a[4] + a[6] + 1) >> 1;
+  a[7] = (a[6] + a[8] + 1) >> 1;
+}
+
+// Inverse 8-point butterfly: int32, floor >>3, narrowed to int16 (hadamard.cpp:47-74).
+__device__ __forceinline__ void iwht8(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5,
+                                      int &x6, int &x7) {
+  const int a0 = x0 + x4, a1 = x1 + x5, a2 = x2 + x6, a3 = x3 + x7;
+  const int a4 = x0 - x4, a5 = x1 - x5, a6 = x2 - x6, a7 = x3 - x7;
+  const int b0 = a0 + a2, b1 = a1 + a3, b2 = a0 - a2, b3 = a1 - a3;
+  const int b4 = a4 + a6, b5 = a5 + a7, b6 = a4 - a6, b7 = a5 - a7;
+  x0 = (int16_t)((b0 + b1) >> 3); x1 = (int16_t)((b4 + b5) >> 3);
+  x2 = (int16_t)((b6 + b7) >> 3); x3 = (int16_t)((b2 + b3) >> 3);
+  x4 = (int16_t)((b2 - b3) >> 3); x5 = (int16_t)((b6 - b7) >> 3);
+  x6 = (int16_t)((b4 - b5) >> 3); x7 = (int16_t)((b0 - b1) >> 3);
+}
+
+__global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames) {
+  __shared__ int16_t s_unmap[256];   // indexed by the code byte
+  __shared__ uint8_t s_shift[2][64];
+  const int v = blockIdx.y, f = blockIdx.z;
+  const DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  for (int k = threadIdx.x; k < 256; k += 256) {
+    const int sc = (int8_t)k;
+    s_unmap[k] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
+  }
+  for (int k = threadIdx.x; k < 128; k += 256) s_shift[k >> 6][k & 63] = df->shift[k >> 6][k & 63];
+  __syncthreads();
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= g.cols) return;
+  const int ycbcr = df->ycbcr;
+  const int bw = min(8, g.W - 8 * u), bh = min(8, g.H - 8 * v);
+  const int u2 = min(u + 1, g.cols - 1), v2 = min(v + 1, g.rows - 1);
+  const uint8_t *src_row = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)v * g.row_block + u;
+  uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
+
+  uint32_t px[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) px[i] = 0;
+
+  for (int c = 0; c < g.C; ++c) {
+    const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * g.cols;
+    const bool chroma = ycbcr && (c == 1 || c == 2);  // decoder.cpp:376
+    const uint8_t *shift = s_shift[chroma ? 1 : 0];
+    const uint8_t *src = src_row + (size_t)c * 64 * g.cols;
+    int b[64];
+    // Gather (decoder.cpp:384-392) + Quantize::Unpack (quantize.cpp:153-165; int16 wrap).
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int pos = kScanD[i];
+      const int code = src[(size_t)i * g.cols];
+      b[pos] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
+    }
+    // Inverse WHT: rows first, then columns, >>3 after each pass (trap T8).
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+      iwht8(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
+            b[y * 8 + 6], b[y * 8 + 7]);
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      iwht8(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
+
+    int left[9], right[9];
+    left[0] = m[(size_t)v * g.cols + u];   left[8] = m[(size_t)v2 * g.cols + u];
+    right[0] = m[(size_t)v * g.cols + u2]; right[8] = m[(size_t)v2 * g.cols + u2];
+    interp9d(left);
+    interp9d(right);
+    const int sh = 8 * c;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      int a[9];
+      a[0] = left[y]; a[8] = right[y];
+      interp9d(a);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        // buf0[i] += lowres[i] in int16, then ClampTo8Bit (decoder.cpp:401-413, common.h:37-39).
+        const int val = clamp255d((int)(int16_t)(b[y * 8 + x] + a[x]));
+        px[y * 8 + x] |= (uint32_t)val << sh;
+      }
+    }
+  }
+
+  // Colour inverse on the clamped planes (ycbcr.cpp:54-82) and store.
+  const bool fast = (g.C == 4 && bw == 8 && bh == 8);
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      uint32_t w = px[y * 8 + x];
+      if (ycbcr) {
+        const int yy = w & 255;
+        const int cbv = (int)((w >> 8) & 255) * 2 - 255;
+        const int crv = (int)((w >> 16) & 255) * 2 - 255;
+        const int gg = yy - ((cbv + crv + 2) >> 2);
+        const int bb = gg + cbv, rr = gg + crv;
+        w = (w & 0xff000000u) | (uint32_t)clamp255d(rr) | ((uint32_t)clamp255d(gg) << 8) |
+            ((uint32_t)clamp255d(bb) << 16);
+      }
+      px[y * 8 + x] = w;
+    }
+    if (fast) {
+      uint4 *rp = reinterpret_cast<uint4 *>(img + ((size_t)(8 * v + y) * g.W + 8 * u) * 4);
+      uint4 q0, q1;
+      q0.x = px[y * 8 + 0]; q0.y = px[y * 8 + 1]; q0.z = px[y * 8 + 2]; q0.w = px[y * 8 + 3];
+      q1.x = px[y * 8 + 4]; q1.y = px[y * 8 + 5]; q1.z = px[y * 8 + 6]; q1.w = px[y * 8 + 7];
+      rp[0] = q0; rp[1] = q1;
+    } else if (y < bh) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        if (x < bw) {
+          uint8_t *q = img + ((size_t)(8 * v + y) * g.W + 8 * u + x) * g.C;
+          for (int c = 0; c < g.C; ++c) q[c] = (uint8_t)(px[y * 8 + x] >> (8 * c));
+        }
+      }
+    }
+  }
+}
+
+// k_dec_status: copy the per-frame verdict out of the workspace.
+__global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < batch) status[f] = ws.frames[f].status;
+}
+
+#define HIMG_LAUNCH(name, grid, block, ...)                    \
+  do {                                                         \
+    prof_begin(prof, #name, stream);                           \
+    hipLaunchKernelGGL(name, grid, block, 0, stream, __VA_ARGS__); \
+    prof_end(prof, stream);                                    \
+  } while (0)
+
+void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
+                   size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
+                   int32_t *d_status, hipStream_t stream, Profiler *prof) {
+  const unsigned gx = (unsigned)((g.cols + 255) / 256);
+  HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
+  HIMG_LAUNCH(k_dec_huff, dim3(g.rows + 1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
+              d_sizes);
+  HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
+  HIMG_LAUNCH(k_tile_inv, dim3(gx, g.rows, batch), dim3(256), g, ws, d_out);
+  HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
+}
+
+}  // namespace himg_dev

@@ -1,0 +1,950 @@
+// kernels_enc.hip -- HIMG encode path as hand-written HIP for gfx950 (MI355X).
+//
+// Pipeline (all on device, batched over frames):
+//   k_lowres_avg      colour lift + 8x8 box average          (ycbcr.cpp:24-52, downsampled.cpp:76-96)
+//   k_lowres_blend    1/16-phase blend -> low-res plane      (downsampled.cpp:98-113)
+//   k_lres_predict    predictor select + delta coding        (downsampled.cpp:177-316)
+//   k_tile_fwd        lift, low-res removal, WHT, quantize,  (encoder.cpp:258-327, hadamard.cpp:78-88,
+//                     compand, coefficient-major scatter      quantize.cpp:127-151, mapper.cpp:159-182)
+//   k_lres_summary    zero-run summaries of LRES spans
+//   k_tok_hist        RLE tokenise + histogram per span      (huffman_enc.cpp:98-144)
+//   k_tree            Huffman tree, codes, serialised tree   (huffman_enc.cpp:148-238)
+//   k_sizes           span sizes -> offsets, container bytes (huffman_enc.cpp:342-352, encoder.cpp:111-256,337-353)
+//   k_emit            RLE tokenise + bit pack                (huffman_enc.cpp:290-358)
+//   k_padfix          stale pad bits of the reference's reused scratch buffer (huffman_enc.cpp:288,355; trap T1)
+//
+// Wavefront = 64 lanes everywhere; no MFMA (there is no dense contraction).
+#include "himg_dev.h"
+
+namespace himg_dev {
+
+// L-shell coefficient scan order (reference common.cpp:13-22; part of the format).
+__device__ static constexpr uint8_t kScan[64] = {
+    0,  1,  9,  8,  16, 17, 18, 10, 2,  3,  11, 19, 27, 26, 25, 24,
+    32, 33, 34, 35, 36, 28, 20, 12, 4,  5,  13, 21, 29, 37, 45, 44,
+    43, 42, 41, 40, 48, 49, 50, 51, 52, 53, 54, 46, 38, 30, 22, 14,
+    6,  7,  15, 23, 31, 39, 47, 55, 63, 62, 61, 60, 59, 58, 57, 56};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+// Colour lift of one pixel (ycbcr.cpp:32-37).
+__device__ __forceinline__ void lift_fwd(int &c0, int &c1, int &c2) {
+  const int y = (c0 + 2 * c1 + c2 + 2) >> 2;
+  const int cb = (c2 - c1 + 256) >> 1;
+  const int cr = (c0 - c1 + 256) >> 1;
+  c0 = y; c1 = cb; c2 = cr;
+}
+
+// Load one pixel as up to four channel values, lifted when the frame is YCbCr coded.
+__device__ __forceinline__ void load_pixel(const uint8_t *img, const Geom &g, int x, int y,
+                                           int ch[4]) {
+  const uint8_t *p = img + ((long long)y * g.W + x) * g.stride;
+  if (g.stride == 4 && g.C == 4) {
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+    ch[0] = w & 255; ch[1] = (w >> 8) & 255; ch[2] = (w >> 16) & 255; ch[3] = w >> 24;
+  } else {
+    ch[0] = p[0];
+    ch[1] = g.C > 1 ? p[1] : 0;
+    ch[2] = g.C > 2 ? p[2] : 0;
+    ch[3] = g.C > 3 ? p[3] : 0;
+  }
+  if (g.ycbcr) lift_fwd(ch[0], ch[1], ch[2]);
+}
+
+// ---------------------------------------------------------------------------
+// k_lowres_avg: one thread per tile window.  Window x in [8u-3, 8u+4], y in
+// [8v-3, 8v+4], clipped to the image (downsampled.cpp:76-96).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lowres_avg(Geom g, const uint8_t *frames,
+                                                    uint8_t *avg, size_t plane_stride) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y, f = blockIdx.z;
+  if (u >= g.cols) return;
+  const uint8_t *img = frames + (long long)f * g.frame_bytes;
+  const int x0 = max(0, 8 * u - 3), x1 = min(g.W - 1, 8 * u + 4);
+  const int y0 = max(0, 8 * v - 3), y1 = min(g.H - 1, 8 * v + 4);
+  int sum[4] = {0, 0, 0, 0};
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x) {
+      int ch[4];
+      load_pixel(img, g, x, y, ch);
+      sum[0] += ch[0]; sum[1] += ch[1]; sum[2] += ch[2]; sum[3] += ch[3];
+    }
+  const int cnt = (x1 - x0 + 1) * (y1 - y0 + 1);
+  uint8_t *a = avg + (size_t)f * plane_stride;
+  for (int c = 0; c < g.C; ++c)
+    a[((size_t)c * g.rows + v) * g.cols + u] = (uint8_t)((sum[c] + (cnt >> 1)) / cnt);
+}
+
+// k_lowres_blend: m = blend of the averages at (v-1,v) x (u-1,u) (downsampled.cpp:98-113).
+__global__ __launch_bounds__(256) void k_lowres_blend(Geom g, const uint8_t *avg, uint8_t *low,
+                                                      size_t plane_stride) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
+  if (u >= g.cols) return;
+  const uint8_t *a = avg + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
+  const int r1 = max(0, v - 1), c1 = max(0, u - 1);
+  const int x11 = a[r1 * g.cols + c1], x12 = a[r1 * g.cols + u];
+  const int x21 = a[v * g.cols + c1], x22 = a[v * g.cols + u];
+  const int a1 = (x11 + 15 * x12 + 8) >> 4;
+  const int a2 = (x21 + 15 * x22 + 8) >> 4;
+  low[(size_t)f * plane_stride + ((size_t)c * g.rows + v) * g.cols + u] =
+      (uint8_t)((a1 + 15 * a2 + 8) >> 4);
+}
+
+// Predictors of downsampled.cpp:41-60.
+__device__ __forceinline__ int predict(int s1, int s2, int s3, int p) {
+  switch (p) {
+    default:
+    case 0: return clamp255((3 * (s2 + s3) - 2 * s1 + 2) >> 2);
+    case 1: return s2;
+    case 2: return s3;
+    case 3: return (s2 + s3 + 1) >> 1;
+    case 4: return clamp255(s2 + s3 - s1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_lres_predict: one wavefront per 16x16 macro block.
+//  1. predictor selection over ORIGINAL neighbours: 4 samples per lane, wave
+//     reduction of the five squared-error sums (downsampled.cpp:182-253);
+//  2. delta coding over RECONSTRUCTED neighbours (downsampled.cpp:255-315):
+//     the 256-step serial chain is run as 31 anti-diagonal wavefronts, lane =
+//     row of the macro block, reconstructed samples exchanged through LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
+                                                     size_t plane_stride, uint8_t *lres_sym,
+                                                     size_t lres_stride, LresTables lt) {
+  __shared__ uint8_t mb[16][17];
+  __shared__ uint8_t rec[16][17];
+  const int mu = blockIdx.x, mv = blockIdx.y;
+  const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
+  const int lane = threadIdx.x;
+  const uint8_t *m = low + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
+  const int u0 = mu * 16, v0 = mv * 16;
+  const int bw = min(16, g.cols - u0), bh = min(16, g.rows - v0);
+
+  for (int k = lane; k < 256; k += 64) {
+    const int dv = k >> 4, du = k & 15;
+    mb[dv][du] = (dv < bh && du < bw) ? m[(size_t)(v0 + dv) * g.cols + u0 + du] : 0;
+  }
+  __syncthreads();
+
+  int err[5] = {0, 0, 0, 0, 0};
+  for (int k = lane; k < 256; k += 64) {
+    const int dv = k >> 4, du = k & 15;
+    if (dv < bh && du < bw) {
+      int s1, s2, s3;
+      if (du > 0 && dv > 0) { s1 = mb[dv - 1][du - 1]; s2 = mb[dv - 1][du]; s3 = mb[dv][du - 1]; }
+      else if (du > 0) { s1 = s2 = s3 = mb[dv][du - 1]; }
+      else if (dv > 0) { s1 = s2 = s3 = mb[dv - 1][du]; }
+      else { s1 = s2 = s3 = 128; }
+      const int actual = mb[dv][du];
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        const int d = actual - predict(s1, s2, s3, p);
+        err[p] += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 5; ++p)
+    for (int d = 32; d >= 1; d >>= 1) err[p] += __shfl_xor(err[p], d);
+  int best = 0, best_err = err[0];
+#pragma unroll
+  for (int p = 1; p < 5; ++p)
+    if (err[p] < best_err) { best = p; best_err = err[p]; }
+
+  uint8_t *out = lres_sym + (size_t)f * lres_stride + (size_t)c * g.chan_size;
+  if (lane == 0) out[mv * g.mcols + mu] = (uint8_t)(best - 2);  // downsampled.cpp:33-35
+  // The stored byte is read back as (uint8 + 2) in int arithmetic
+  // (downsampled.cpp:37-39), so selections 0 and 1 both CODE with predictor 0.
+  const int pc = best <= 1 ? 0 : best;
+
+  uint8_t *dst = out + g.mrows * g.mcols + (size_t)v0 * g.cols + (size_t)bh * u0;
+  for (int d = 0; d < 31; ++d) {
+    const int dv = lane, du = d - lane;
+    if (lane < 16 && dv < bh && du >= 0 && du < bw) {
+      int s1, s2, s3;
+      if (du > 0 && dv > 0) { s1 = rec[dv - 1][du - 1]; s2 = rec[dv - 1][du]; s3 = rec[dv][du - 1]; }
+      else if (du > 0) { s1 = s2 = s3 = rec[dv][du - 1]; }
+      else if (dv > 0) { s1 = s2 = s3 = rec[dv - 1][du]; }
+      else { s1 = s2 = s3 = 128; }
+      const int predicted = predict(s1, s2, s3, pc);
+      const int delta = (int)mb[dv][du] - predicted;
+      const uint8_t code = lt.code[delta + 255];
+      const int sc = (int8_t)code;
+      const int un = sc >= 0 ? lt.tab[sc] : -lt.tab[-sc];
+      rec[dv][du] = (uint8_t)clamp255(predicted + un);
+      dst[dv * bw + du] = code;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tile helpers.
+// ---------------------------------------------------------------------------
+
+// Recursive rounded midpoints at positions 4,2,6,1,3,5,7 (downsampled.cpp:131-147).
+__device__ __forceinline__ void interp9(int a[9]) {
+  a[4] = (a[0] + a[8] + 1) >> 1;
+  a[2] = (a[0] + a[4] + 1) >> 1;
+  a[6] = (a[4] + a[8] + 1) >> 1;
+  a[1] = (a[0] + a[2] + 1) >> 1;
+  a[3] = (a[2] + a[4] + 1) >> 1;
+  a[5] = (a[4] + a[6] + 1) >> 1;
+  a[7] = (a[6] + a[8] + 1) >> 1;
+}
+
+// 8-point sequency-ordered WHT butterfly (hadamard.cpp:18-44); in-place on
+// eight ints.  Forward results are taken mod 2^16 by the caller (the reference
+// computes in wrapping int16; add/sub commute with the wrap).
+__device__ __forceinline__ void wht8(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5,
+                                     int &x6, int &x7) {
+  const int a0 = x0 + x4, a1 = x1 + x5, a2 = x2 + x6, a3 = x3 + x7;
+  const int a4 = x0 - x4, a5 = x1 - x5, a6 = x2 - x6, a7 = x3 - x7;
+  const int b0 = a0 + a2, b1 = a1 + a3, b2 = a0 - a2, b3 = a1 - a3;
+  const int b4 = a4 + a6, b5 = a5 + a7, b6 = a4 - a6, b7 = a5 - a7;
+  x0 = b0 + b1; x1 = b4 + b5; x2 = b6 + b7; x3 = b2 + b3;
+  x4 = b2 - b3; x5 = b6 - b7; x6 = b4 - b5; x7 = b0 - b1;
+}
+
+// ---------------------------------------------------------------------------
+// k_tile_fwd: one lane per 8x8 tile, a wavefront covers 64 horizontally
+// adjacent tiles of one block row, so for every coefficient the 64 lanes write
+// 64 consecutive symbol bytes (encoder.cpp:320-323 layout).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_fwd(Geom g, const uint8_t *frames,
+                                                  const uint8_t *low, size_t plane_stride,
+                                                  uint8_t *fres_sym, size_t fres_stride,
+                                                  const uint8_t *__restrict__ fmap_lut,
+                                                  ShiftTables st) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y, f = blockIdx.z;
+  if (u >= g.cols) return;
+  const uint8_t *img = frames + (long long)f * g.frame_bytes;
+  const int bw = min(8, g.W - 8 * u), bh = min(8, g.H - 8 * v);
+
+  // Pixels of the tile, channels packed 8 bits each, already lifted.
+  uint32_t px[64];
+  if (bw == 8 && bh == 8 && g.stride == 4 && g.C == 4) {
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(
+          img + ((long long)(8 * v + y) * g.W + 8 * u) * 4);
+      const uint4 q0 = rp[0], q1 = rp[1];
+      px[y * 8 + 0] = q0.x; px[y * 8 + 1] = q0.y; px[y * 8 + 2] = q0.z; px[y * 8 + 3] = q0.w;
+      px[y * 8 + 4] = q1.x; px[y * 8 + 5] = q1.y; px[y * 8 + 6] = q1.z; px[y * 8 + 7] = q1.w;
+    }
+    if (g.ycbcr) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        int c0 = px[i] & 255, c1 = (px[i] >> 8) & 255, c2 = (px[i] >> 16) & 255;
+        lift_fwd(c0, c1, c2);
+        px[i] = (px[i] & 0xff000000u) | (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
+      }
+    }
+  } else {
+    // Partial tiles replicate the last valid pixel of the row, rows below the
+    // image repeat the bottom-right valid pixel (encoder.cpp:26-52).
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int yy = y < bh ? y : bh - 1;
+        const int xx = y < bh ? min(x, bw - 1) : bw - 1;
+        int ch[4];
+        load_pixel(img, g, 8 * u + xx, 8 * v + yy, ch);
+        px[y * 8 + x] = (uint32_t)ch[0] | ((uint32_t)ch[1] << 8) | ((uint32_t)ch[2] << 16) |
+                        ((uint32_t)ch[3] << 24);
+      }
+  }
+
+  const int u2 = min(u + 1, g.cols - 1), v2 = min(v + 1, g.rows - 1);
+  uint8_t *dst_row = fres_sym + (size_t)f * fres_stride + (size_t)v * g.row_block + u;
+
+  for (int c = 0; c < g.C; ++c) {
+    const uint8_t *m = low + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
+    // Bilinear low-res block from the four corners (downsampled.cpp:116-169).
+    int left[9], right[9];
+    left[0] = m[(size_t)v * g.cols + u];   left[8] = m[(size_t)v2 * g.cols + u];
+    right[0] = m[(size_t)v * g.cols + u2]; right[8] = m[(size_t)v2 * g.cols + u2];
+    interp9(left);
+    interp9(right);
+
+    int b[64];
+    const int sh = 8 * c;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      int a[9];
+      a[0] = left[y]; a[8] = right[y];
+      interp9(a);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) b[y * 8 + x] = (int)((px[y * 8 + x] >> sh) & 255) - a[x];
+    }
+    // Forward 2-D WHT: rows, then columns (hadamard.cpp:78-88).
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+      wht8(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
+           b[y * 8 + 6], b[y * 8 + 7]);
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      wht8(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
+
+    const bool chroma = g.ycbcr && (c == 1 || c == 2);  // encoder.cpp:284
+    const uint8_t *shift = st.s[chroma ? 1 : 0];
+    uint8_t *dst = dst_row + (size_t)c * 64 * g.cols;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int pos = kScan[i];
+      const int s = shift[pos];
+      int x = (int)(int16_t)b[pos];  // the reference's int16 wrap
+      // Sign-magnitude rounding shift (quantize.cpp:135-148).
+      const int r = s ? (1 << (s - 1)) : 0;
+      const int mag = x < 0 ? ((-x + r) >> s) : ((x + r) >> s);
+      // Companding through the LUT of Mapper::MapTo8Bit (mapper.cpp:159-182).
+      const uint32_t code = fmap_lut[mag];
+      const uint8_t out = (x < 0) ? (uint8_t)(0u - code) : (uint8_t)code;
+      dst[(size_t)i * g.cols] = out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Entropy coder helpers.
+// ---------------------------------------------------------------------------
+
+struct ZR {   // zero-run summary of a symbol range
+  int tz;     // trailing zeros
+  int az;     // 1 when the range is all zeros
+};
+__device__ __forceinline__ ZR zr_combine(ZR l, ZR r) {
+  ZR o;
+  o.tz = r.az ? l.tz + r.tz : r.tz;
+  o.az = l.az & r.az;
+  return o;
+}
+
+// Exclusive block scan (256 threads) of zero-run summaries; `carry` is the state
+// before this block of symbols.  Returns the exclusive prefix; *total receives
+// the state after the block.  `sm` needs 4 entries.
+__device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total) {
+  const int lane = lane_id(), wave = wave_id();
+  ZR incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    ZR t;
+    t.tz = __shfl_up(incl.tz, d);
+    t.az = __shfl_up(incl.az, d);
+    if (lane >= d) incl = zr_combine(t, incl);
+  }
+  if (lane == 63) sm[wave] = incl;
+  ZR ex;
+  ex.tz = __shfl_up(incl.tz, 1);
+  ex.az = __shfl_up(incl.az, 1);
+  if (lane == 0) { ex.tz = 0; ex.az = 1; }
+  __syncthreads();
+  ZR pre = carry, tot = carry;
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) pre = zr_combine(pre, sm[w]);
+    tot = zr_combine(tot, sm[w]);
+  }
+  __syncthreads();
+  *total = tot;
+  return zr_combine(pre, ex);
+}
+
+// Exclusive block scan (256 threads) of a bit count; *total = block sum.
+__device__ __forceinline__ uint32_t block_scan_u32(uint32_t v, uint32_t *sm, uint32_t *total) {
+  const int lane = lane_id(), wave = wave_id();
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) sm[wave] = incl;
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) pre += sm[w];
+    tot += sm[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return pre + incl - v;
+}
+
+// Greedy zero-run tokens: from the run start in steps of 16662, remainder last
+// (huffman_enc.cpp:111-141; trap T6).  f(symbol, extra_bits, extra_value).
+template <class F>
+__device__ __forceinline__ void emit_run(int len, F &&f) {
+  while (len >= 16662) { f(260, 14, 16662 - 279); len -= 16662; }
+  if (len == 0) return;
+  if (len == 1) f(0, 0, 0);
+  else if (len == 2) f(256, 0, 0);
+  else if (len <= 6) f(257, 2, len - 3);
+  else if (len <= 22) f(258, 4, len - 7);
+  else if (len <= 278) f(259, 8, len - 23);
+  else f(260, 14, len - 279);
+}
+
+// Walk one thread's 16 symbols.  A zero run is tokenised by the thread that
+// holds the run's LAST zero (the run start comes in through run_in), which
+// keeps token order == thread order with a forward scan only.
+template <class F>
+__device__ __forceinline__ void walk16(const uint32_t w[4], int nvalid, int run_in, bool flush,
+                                       F &&f) {
+  int run = run_in;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < nvalid) {
+      const int s = (w[k >> 2] >> ((k & 3) * 8)) & 255;
+      if (s == 0) {
+        ++run;
+      } else {
+        if (run) emit_run(run, f);
+        run = 0;
+        f(s, 0, 0);
+      }
+    }
+  }
+  if (flush && run) emit_run(run, f);
+}
+
+// Zero-run summary of one thread's chunk.  Chunks with fewer than 16 valid
+// symbols only occur at the very end of a span; an empty chunk is the identity.
+__device__ __forceinline__ ZR summarize16(const uint32_t w[4], int nvalid) {
+  ZR z;
+  int tz = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < nvalid) {
+      const int s = (w[k >> 2] >> ((k & 3) * 8)) & 255;
+      tz = s ? 0 : tz + 1;
+    }
+  }
+  z.tz = tz;
+  z.az = (tz == nvalid) ? 1 : 0;
+  return z;
+}
+
+// Load 16 symbols of a span (zero padded beyond `remaining`).
+__device__ __forceinline__ void load16(const uint8_t *p, long long remaining, uint32_t w[4]) {
+  if (remaining >= 16 && ((uintptr_t)p & 15) == 0) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+  } else {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for (int k = 0; k < 16; ++k)
+      if (k < remaining) w[k >> 2] |= (uint32_t)p[k] << ((k & 3) * 8);
+  }
+}
+
+// Span descriptor shared by k_tok_hist / k_emit.
+struct Span {
+  const uint8_t *sym;   // first symbol of the span
+  int len;              // symbols in the span
+  bool last_of_block;   // the span holds the block's last symbol
+  bool is_lres;
+  int index;            // index into the per-frame span arrays
+};
+
+__device__ __forceinline__ Span get_span(const Geom &g, const EncWs &ws, int sp, int f) {
+  Span s;
+  s.index = sp;
+  if (sp < g.lres_spans) {
+    const int start = sp * kLresSpan;
+    s.sym = ws.lres_sym + (size_t)f * ws.lres_stride + start;
+    s.len = min(kLresSpan, g.lres_size - start);
+    s.last_of_block = (sp == g.lres_spans - 1);
+    s.is_lres = true;
+  } else {
+    const int r = sp - g.lres_spans;
+    s.sym = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
+    s.len = g.row_block;
+    s.last_of_block = true;
+    s.is_lres = false;
+  }
+  return s;
+}
+
+// Zeros immediately before LRES span `sp` (0 for FRES rows: runs never cross
+// a block row, huffman_enc.cpp:105-106).
+__device__ __forceinline__ int span_carry_in(const Geom &g, const EncWs &ws, int sp, int f) {
+  if (sp >= g.lres_spans) return 0;
+  const uint32_t *tr = ws.lres_trail + (size_t)f * g.lres_spans;
+  int t = 0;
+  for (int k = sp - 1; k >= 0; --k) {
+    const uint32_t x = tr[k];
+    t += (int)(x & 0x7fffffffu);
+    if (!(x >> 31)) break;
+  }
+  return t;
+}
+
+// k_lres_summary: trailing-zero summary of every LRES span.
+__global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
+  __shared__ ZR sm[4];
+  const int sp = blockIdx.x, f = blockIdx.y;
+  const Span s = get_span(g, ws, sp, f);
+  ZR carry = {0, 1}, total = carry;
+  for (int base = 0; base < s.len; base += kIterSyms) {
+    const int off = base + threadIdx.x * 16;
+    const int nvalid = max(0, min(16, s.len - off));
+    uint32_t w[4];
+    load16(s.sym + off, s.len - off, w);
+    const ZR mine = summarize16(w, nvalid);
+    block_scan_zr(mine, carry, sm, &total);
+    carry = total;
+  }
+  if (threadIdx.x == 0)
+    ws.lres_trail[(size_t)f * g.lres_spans + sp] =
+        (uint32_t)total.tz | (total.az ? 0x80000000u : 0u);
+}
+
+// k_tok_hist: token histogram of one span (huffman_enc.cpp:98-144).
+__global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws) {
+  __shared__ uint32_t hist[kHistStride];
+  __shared__ ZR sm[4];
+  const int sp = blockIdx.x, f = blockIdx.y;
+  const Span s = get_span(g, ws, sp, f);
+  for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
+  ZR carry;
+  carry.tz = span_carry_in(g, ws, sp, f);
+  carry.az = 0;
+  __syncthreads();
+  for (int base = 0; base < s.len; base += kIterSyms) {
+    const int off = base + threadIdx.x * 16;
+    const int nvalid = max(0, min(16, s.len - off));
+    uint32_t w[4];
+    load16(s.sym + off, s.len - off, w);
+    const ZR mine = summarize16(w, nvalid);
+    ZR total;
+    const ZR ex = block_scan_zr(mine, carry, sm, &total);
+    carry = total;
+    carry.az = 0;
+    const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
+    walk16(w, nvalid, ex.tz, flush, [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); });
+  }
+  __syncthreads();
+  uint32_t *sh = (s.is_lres ? ws.span_hist_l + ((size_t)f * g.lres_spans + sp) * kHistStride
+                            : ws.span_hist_f + ((size_t)f * g.rows + (sp - g.lres_spans)) * kHistStride);
+  uint32_t *gh = ws.hist + ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
+  for (int k = threadIdx.x; k < kHistStride; k += 256) {
+    const uint32_t c = hist[k];
+    sh[k] = c;
+    if (c && k < kNumSym) atomicAdd(&gh[k], c);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_tree: one wavefront per (stream, frame).  Builds the Huffman tree with the
+// reference's tie-breaking (trap T5): repeatedly join the two lightest nodes
+// under the total order (count ascending, node index DESCENDING); the lighter
+// becomes child_a (bit 0).  Then a pre-order walk serialises the tree and
+// assigns LSB-first codes (huffman_enc.cpp:148-180).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_tree(EncWs ws) {
+  __shared__ int cnt[2 * kNumSym];
+  __shared__ short ca[2 * kNumSym], cb[2 * kNumSym], nsym[2 * kNumSym];
+  __shared__ uint32_t bits[kTreeStride / 4];
+  __shared__ short stk_node[kNumSym + 8];
+  __shared__ uint8_t stk_bits[kNumSym + 8];
+  __shared__ uint64_t stk_code[kNumSym + 8];
+  __shared__ int s_num;
+
+  const int strm = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  const size_t tab = ((size_t)f * 2 + strm) * kHistStride;
+  const uint32_t *hist = ws.hist + tab;
+  uint64_t *codes = ws.codes + tab;
+  uint32_t *lens = ws.lens + tab;
+
+  for (int k = lane; k < kTreeStride / 4; k += 64) bits[k] = 0;
+  for (int k = lane; k < kHistStride; k += 64) { codes[k] = 0; lens[k] = 0; }
+  // Leaves in ascending symbol order (huffman_enc.cpp:186-196).
+  int num = 0;
+  for (int base = 0; base < kNumSym; base += 64) {
+    const int k = base + lane;
+    const uint32_t c = k < kNumSym ? hist[k] : 0;
+    const unsigned long long mask = __ballot(c > 0);
+    if (c > 0) {
+      const int idx = num + __popcll(mask & ((1ull << lane) - 1ull));
+      cnt[idx] = (int)c; ca[idx] = -1; cb[idx] = -1; nsym[idx] = (short)k;
+    }
+    num += __popcll(mask);
+  }
+  __syncthreads();
+
+  int next = num;
+  for (int left = num; left > 1; --left) {
+    unsigned long long b1 = ~0ull, b2 = ~0ull;
+    for (int k = lane; k < next; k += 64) {
+      const int c = cnt[k];
+      if (c > 0) {
+        const unsigned long long key = ((unsigned long long)(uint32_t)c << 10) | (uint32_t)(1023 - k);
+        if (key < b1) { b2 = b1; b1 = key; }
+        else if (key < b2) { b2 = key; }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long o1 = __shfl_xor(b1, d), o2 = __shfl_xor(b2, d);
+      if (o1 < b1) { b2 = (b1 < o2) ? b1 : o2; b1 = o1; }
+      else { b2 = (b2 < o1) ? b2 : o1; }
+    }
+    const int n1 = 1023 - (int)(b1 & 1023), n2 = 1023 - (int)(b2 & 1023);
+    __syncthreads();
+    if (lane == 0) {
+      ca[next] = (short)n1; cb[next] = (short)n2; nsym[next] = -1;
+      cnt[next] = cnt[n1] + cnt[n2];
+      cnt[n1] = 0; cnt[n2] = 0;
+    }
+    ++next;
+    __syncthreads();
+  }
+
+  if (lane == 0) {
+    int err = 0;
+    uint32_t nb = 0;  // bits written
+    auto put = [&](uint32_t v, int n) {
+      for (int i = 0; i < n; ++i, ++nb)
+        if ((v >> i) & 1u) bits[nb >> 5] |= 1u << (nb & 31);
+    };
+    int sp = 0;
+    if (num == 1) {  // single symbol: one leaf, code 0, length 1 (huffman_enc.cpp:231-237)
+      stk_node[0] = 0; stk_code[0] = 0; stk_bits[0] = 1; sp = 1;
+    } else if (num > 1) {
+      stk_node[0] = (short)(next - 1); stk_code[0] = 0; stk_bits[0] = 0; sp = 1;
+    }
+    while (sp > 0) {
+      --sp;
+      const int n = stk_node[sp];
+      const uint64_t code = stk_code[sp];
+      const int nbits = stk_bits[sp];
+      if (nsym[n] >= 0) {
+        put(1, 1);
+        put((uint32_t)nsym[n], 9);
+        codes[nsym[n]] = code;
+        lens[nsym[n]] = (uint32_t)nbits;
+        if (nbits > kMaxCodeLen) err = 1;
+      } else {
+        put(0, 1);
+        const uint64_t bcode = code + (nbits < 63 ? (1ull << nbits) : 0ull);
+        stk_node[sp] = cb[n]; stk_code[sp] = bcode; stk_bits[sp] = (uint8_t)min(nbits + 1, 255); ++sp;
+        stk_node[sp] = ca[n]; stk_code[sp] = code;  stk_bits[sp] = (uint8_t)min(nbits + 1, 255); ++sp;
+      }
+    }
+    s_num = (int)((nb + 7) >> 3);
+    ws.tree_nbytes[(size_t)f * 2 + strm] = (nb + 7) >> 3;
+    if (err) atomicMax(&ws.status[f], 3);  // code longer than 32 bits: outside the built scope
+  }
+  __syncthreads();
+  uint8_t *tree = ws.tree + ((size_t)f * 2 + strm) * kTreeStride;
+  for (int k = lane; k < s_num; k += 64) tree[k] = (uint8_t)(bits[k >> 2] >> ((k & 3) * 8));
+}
+
+__device__ __forceinline__ int extra_bits_of(int sym) {
+  return sym < 257 ? 0 : (sym == 257 ? 2 : (sym == 258 ? 4 : (sym == 259 ? 8 : 14)));
+}
+
+// ---------------------------------------------------------------------------
+// k_sizes: one workgroup per frame.  Span bit counts follow from the span
+// histograms and the code lengths, so the symbols are not re-read.  Writes every
+// container byte that is not entropy payload: RIFF/FRMT/LMAP/'LRES' head, both
+// serialised trees, QCFG/FMAP/'FRES', the per-row size headers
+// (huffman_enc.cpp:342-352) and all size fields (encoder.cpp:131-137,347-350).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc, uint8_t *out,
+                                               size_t out_stride, uint32_t *sizes) {
+  __shared__ uint32_t sm[4];
+  __shared__ uint32_t cost[2][kHistStride];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  uint8_t *o = out + (size_t)f * out_stride;
+  const int nsp = g.lres_spans + g.rows;
+  uint64_t *bit0 = ws.span_bit0 + (size_t)f * nsp;
+  uint32_t *nbits = ws.span_bits + (size_t)f * nsp;
+
+  for (int k = tid; k < 2 * kHistStride; k += 256) {
+    const int s = k / kHistStride, sym = k % kHistStride;
+    cost[s][sym] = sym < kNumSym ? ws.lens[((size_t)f * 2 + s) * kHistStride + sym] + extra_bits_of(sym) : 0;
+  }
+  __syncthreads();
+  const uint32_t tree_l = ws.tree_nbytes[(size_t)f * 2 + 0];
+  const uint32_t tree_f = ws.tree_nbytes[(size_t)f * 2 + 1];
+
+  // LRES spans: one continuous bit stream after the byte-aligned tree.
+  unsigned long long run = 8ull * (kHeadLen + tree_l);
+  for (int base = 0; base < g.lres_spans; base += 256) {
+    const int s = base + tid;
+    uint32_t b = 0;
+    if (s < g.lres_spans) {
+      const uint32_t *h = ws.span_hist_l + ((size_t)f * g.lres_spans + s) * kHistStride;
+      for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[0][k];
+    }
+    uint32_t tot;
+    const uint32_t ex = block_scan_u32(b, sm, &tot);
+    if (s < g.lres_spans) { bit0[s] = run + ex; nbits[s] = b; }
+    run += tot;
+  }
+  const unsigned long long lres_end_bit = run;
+  const uint32_t lres_bytes = (uint32_t)(((lres_end_bit + 7) >> 3) - kHeadLen);
+
+  // FRES rows: byte aligned payloads, each behind a 2- or 4-byte size header.
+  const unsigned long long fres_base = (unsigned long long)kHeadLen + lres_bytes + sc.mid_len;
+  unsigned long long pos = fres_base + tree_f;  // running byte position
+  for (int base = 0; base < g.rows; base += 256) {
+    const int r = base + tid;
+    uint32_t b = 0, nbytes = 0, hdr = 0;
+    if (r < g.rows) {
+      const uint32_t *h = ws.span_hist_f + ((size_t)f * g.rows + r) * kHistStride;
+      for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[1][k];
+      nbytes = (b + 7) >> 3;
+      hdr = g.use_blocks ? (nbytes <= 0x7fffu ? 2u : 4u) : 0u;
+    }
+    uint32_t tot;
+    const uint32_t ex = block_scan_u32(nbytes + hdr, sm, &tot);
+    if (r < g.rows) {
+      const unsigned long long p = pos + ex + hdr;  // first payload byte
+      bit0[g.lres_spans + r] = 8ull * p;
+      nbits[g.lres_spans + r] = b;
+      if (p + nbytes <= out_stride) {
+        if (hdr == 2) {
+          o[p - 2] = (uint8_t)(nbytes & 255); o[p - 1] = (uint8_t)(nbytes >> 8);
+        } else if (hdr == 4) {
+          const uint32_t lo = (nbytes & 0x7fffu) | 0x8000u, hi = nbytes >> 15;
+          o[p - 4] = (uint8_t)(lo & 255); o[p - 3] = (uint8_t)(lo >> 8);
+          o[p - 2] = (uint8_t)(hi & 255); o[p - 1] = (uint8_t)(hi >> 8);
+        }
+      }
+    }
+    pos += tot;
+  }
+  const unsigned long long total = pos;
+  const uint32_t fres_bytes = (uint32_t)(total - fres_base);
+  const bool fits = total <= out_stride && total < 0x7fffffffull;
+  if (tid == 0) {
+    if (!fits) atomicMax(&ws.status[f], 5);
+    sizes[f] = (fits && ws.status[f] == 0) ? (uint32_t)total : 0u;
+  }
+  if (!fits) return;
+
+  // Static container bytes with the data-dependent size fields patched in.
+  for (int k = tid; k < kHeadLen; k += 256) {
+    uint8_t b = sc.head[k];
+    if (k >= 4 && k < 8) b = (uint8_t)(((uint32_t)total - 8u) >> (8 * (k - 4)));
+    if (k >= kHeadLen - 4) b = (uint8_t)(lres_bytes >> (8 * (k - (kHeadLen - 4))));
+    o[k] = b;
+  }
+  for (int k = tid; k < sc.mid_len; k += 256) {
+    uint8_t b = sc.mid[k];
+    if (k >= sc.mid_len - 4) b = (uint8_t)(fres_bytes >> (8 * (k - (sc.mid_len - 4))));
+    o[kHeadLen + lres_bytes + k] = b;
+  }
+  const uint8_t *tl = ws.tree + ((size_t)f * 2 + 0) * kTreeStride;
+  const uint8_t *tf = ws.tree + ((size_t)f * 2 + 1) * kTreeStride;
+  for (int k = tid; k < (int)tree_l; k += 256) o[kHeadLen + k] = tl[k];
+  for (int k = tid; k < (int)tree_f; k += 256) o[fres_base + k] = tf[k];
+}
+
+// ---------------------------------------------------------------------------
+// k_emit: RLE tokenise + Huffman bit pack of one span straight into its final
+// position.  Bits are assembled in an LDS staging buffer with ds atomics and
+// flushed as whole dwords; the dwords at the two ends of a span are shared
+// with neighbours: FRES rows are byte aligned, so edge dwords are written with
+// byte stores (single owner per byte); LRES spans meet at arbitrary bit
+// positions, so their edge dwords are OR-ed into the pre-zeroed LRES region.
+// ---------------------------------------------------------------------------
+constexpr int kStageWords = 6144;  // >= (31 + (4096+32)*46) / 32
+
+__global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
+                                              const uint32_t *sizes) {
+  __shared__ uint32_t stage[kStageWords];
+  __shared__ uint32_t s_code[kHistStride];
+  __shared__ uint8_t s_len[kHistStride];
+  __shared__ ZR sm_zr[4];
+  __shared__ uint32_t sm_u[4];
+
+  const int sp = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  if (sizes[f] == 0) return;  // frame failed (status says why)
+  const Span s = get_span(g, ws, sp, f);
+  const int nsp = g.lres_spans + g.rows;
+  const unsigned long long B0 = ws.span_bit0[(size_t)f * nsp + sp];
+  const unsigned long long B1 = B0 + ws.span_bits[(size_t)f * nsp + sp];
+  uint8_t *o8 = out + (size_t)f * out_stride;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
+
+  const size_t tab = ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
+  for (int k = tid; k < kHistStride; k += 256) {
+    s_code[k] = (uint32_t)ws.codes[tab + k];
+    s_len[k] = (uint8_t)ws.lens[tab + k];
+  }
+  for (int k = tid; k < kStageWords; k += 256) stage[k] = 0;
+  ZR carry;
+  carry.tz = span_carry_in(g, ws, sp, f);
+  carry.az = 0;
+  unsigned long long gword = B0 >> 5;           // global dword of stage[0]
+  uint32_t carry_bits = (uint32_t)(B0 & 31);    // bits of stage[0] that precede this span
+  __syncthreads();
+
+  auto store_word = [&](unsigned long long gw, uint32_t val) {
+    const unsigned long long wb0 = gw * 32ull;
+    if (wb0 >= B0 && wb0 + 32ull <= B1) {
+      o32[gw] = val;
+    } else if (s.is_lres) {
+      if (val) atomicOr(&o32[gw], val);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned long long bb = (gw * 4ull + b) * 8ull;
+        if (bb >= B0 && bb < B1) o8[gw * 4ull + b] = (uint8_t)(val >> (8 * b));
+      }
+    }
+  };
+
+  for (int base = 0; base < s.len; base += kIterSyms) {
+    const int off = base + tid * 16;
+    const int nvalid = max(0, min(16, s.len - off));
+    uint32_t w[4];
+    load16(s.sym + off, s.len - off, w);
+    const ZR mine = summarize16(w, nvalid);
+    ZR total;
+    const ZR ex = block_scan_zr(mine, carry, sm_zr, &total);
+    carry = total;
+    carry.az = 0;
+    const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
+
+    uint32_t mybits = 0;
+    walk16(w, nvalid, ex.tz, flush, [&](int sym, int eb, int) { mybits += s_len[sym] + eb; });
+    uint32_t iter_bits;
+    const uint32_t myoff = block_scan_u32(mybits, sm_u, &iter_bits);
+
+    // Append this thread's tokens at its bit offset inside the staging buffer.
+    uint32_t pos = carry_bits + myoff;
+    uint32_t widx = pos >> 5;
+    uint32_t accb = pos & 31;
+    unsigned long long acc = 0;
+    auto put = [&](uint32_t v, int n) {  // n <= 32
+      acc |= (unsigned long long)v << accb;
+      accb += n;
+      if (accb >= 32) {
+        atomicOr(&stage[widx], (uint32_t)acc);
+        ++widx;
+        acc >>= 32;
+        accb -= 32;
+      }
+    };
+    walk16(w, nvalid, ex.tz, flush, [&](int sym, int eb, int ev) {
+      put(s_code[sym], s_len[sym]);
+      if (eb) put((uint32_t)ev, eb);
+    });
+    if (accb && acc) atomicOr(&stage[widx], (uint32_t)acc);
+    __syncthreads();
+
+    const uint32_t end_bits = carry_bits + iter_bits;
+    const uint32_t nfull = end_bits >> 5;
+    for (uint32_t k = tid; k < nfull; k += 256) store_word(gword + k, stage[k]);
+    const uint32_t partial = stage[nfull];
+    __syncthreads();
+    for (uint32_t k = tid; k <= nfull; k += 256) stage[k] = 0;
+    __syncthreads();
+    if (tid == 0) stage[0] = partial;
+    gword += nfull;
+    carry_bits = end_bits & 31;
+    __syncthreads();
+  }
+  if (tid == 0 && carry_bits) store_word(gword, stage[0]);
+}
+
+// ---------------------------------------------------------------------------
+// k_padfix (trap T1): the reference packs every block row into ONE scratch
+// buffer that is never cleared, and WriteBits only touches the bits it writes
+// (huffman_enc.cpp:31-50,288,355-358).  The unused high bits of a row's last
+// byte therefore keep what the most recent earlier row left at that byte index.
+// One thread per row resolves its pad bits by walking back over earlier rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_padfix(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
+                                                const uint32_t *sizes) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+  if (r >= g.rows || sizes[f] == 0) return;
+  const int nsp = g.lres_spans + g.rows;
+  const uint64_t *bit0 = ws.span_bit0 + (size_t)f * nsp + g.lres_spans;
+  const uint32_t *nbits = ws.span_bits + (size_t)f * nsp + g.lres_spans;
+  uint8_t *o = out + (size_t)f * out_stride;
+  const uint32_t bits = nbits[r];
+  const uint32_t valid = bits & 7;
+  if (valid == 0) return;  // last byte full: nothing stale shows through
+  const uint32_t idx = ((bits + 7) >> 3) - 1;  // index of the last byte inside the row
+  uint32_t need = 0xffu & ~((1u << valid) - 1u);
+  uint32_t acc = 0;
+  for (int q = r - 1; q >= 0 && need; --q) {
+    const uint32_t qb = nbits[q];
+    const uint32_t qn = (qb + 7) >> 3;
+    if (qn <= idx) continue;  // row q never wrote scratch[idx]
+    const uint32_t byte = o[(bit0[q] >> 3) + idx];
+    if (qn - 1 == idx) {
+      // scratch[idx] is row q's own last byte: its valid bits are q's, its pad
+      // bits are older still.
+      const uint32_t qv = qb & 7;
+      const uint32_t vmask = qv ? ((1u << qv) - 1u) : 0xffu;
+      acc |= byte & vmask & need;
+      need &= ~vmask;
+    } else {
+      acc |= byte & need;
+      need = 0;
+    }
+  }
+  if (acc) o[(bit0[r] >> 3) + idx] |= (uint8_t)acc;
+}
+
+// ---------------------------------------------------------------------------
+// Host-side launch sequence.
+// ---------------------------------------------------------------------------
+#define HIMG_LAUNCH(name, grid, block, ...)                    \
+  do {                                                         \
+    prof_begin(prof, #name, stream);                           \
+    hipLaunchKernelGGL(name, grid, block, 0, stream, __VA_ARGS__); \
+    prof_end(prof, stream);                                    \
+  } while (0)
+
+void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
+                   uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,
+                   const StaticChunks &sc, const ShiftTables &st, const LresTables &lt,
+                   const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof) {
+  const int nsp = g.lres_spans + g.rows;
+  const dim3 b256(256);
+  const unsigned gx = (unsigned)((g.cols + 255) / 256);
+
+  prof_begin(prof, "memset", stream);
+  (void)hipMemsetAsync(ws.hist, 0, (size_t)batch * 2 * kHistStride * sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(ws.status, 0, (size_t)batch * sizeof(int32_t), stream);
+  // LRES payload region: pre-zeroed because span edges are OR-ed in (k_emit).
+  {
+    const size_t start = (size_t)(kHeadLen & ~3);
+    size_t width = (size_t)g.lres_size + kTreeStride + 64;
+    if (start + width > out_stride) width = out_stride - start;
+    (void)hipMemset2DAsync(d_out + start, out_stride, 0, width, (size_t)batch, stream);
+  }
+  prof_end(prof, stream);
+
+  HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride);
+  HIMG_LAUNCH(k_lowres_blend, dim3(gx, g.rows, batch * g.C), b256, g, ws.avg, ws.low,
+              ws.plane_stride);
+  HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws.low,
+              ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
+  HIMG_LAUNCH(k_tile_fwd, dim3(gx, g.rows, batch), b256, g, d_frames, ws.low, ws.plane_stride,
+              ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+  HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
+  HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws);
+  HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws);
+  HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes);
+  HIMG_LAUNCH(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes);
+  HIMG_LAUNCH(k_padfix, dim3((g.rows + 255) / 256, batch), b256, g, ws, d_out, out_stride,
+              d_sizes);
+}
+
+}  // namespace himg_dev
