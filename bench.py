@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- HIMG encode+decode throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: `--batch` 4096x4096 RGBA
+frames (randtile, q=50; BASELINE.json configs[1]) that are ALREADY RESIDENT IN
+HBM are encoded to .himg streams and decoded back, all through the C ABI
+(hand-written HIP kernels).  value = pixels through encode+decode per second,
+i.e. N*batch*W*H*K / wall time, whole job.  Frame 0 of rank 0 is the golden
+input: its stream and decoded pixels are checked against the hashes recorded
+from the real reference, so a fast-but-wrong run cannot report a number.
+
+For N > 1 the driver launches one rank per GPU (torch.distributed, backend
+"nccl" = RCCL).  Frames are independent objects, so they are sharded over the
+ranks with no data-path collective (weak scaling: fixed per-GPU batch); only
+the barrier and the max-over-ranks timing use the process group.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel, algorithmic bytes per launch / its mean duration
+               measured with HIP events on the launch stream, vs 8 TB/s HBM.
+  cpu_baseline the REAL reference (oracle/_ref, compiled from /root/reference)
+               or, if that library is absent, our C port (oracle/), timed on this
+               node's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+GOLDEN_4096 = {"packed_size": 17227700, "stream_fnv": "65c2fb5345506268",
+               "decoded_fnv": "dd3685000a721519"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--quality", type=int, default=50)
+    ap.add_argument("--kind", default="randtile")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(frame, quality, budget_s):
+    """Time the reference CPU path on this node's host cores (rank 0, N=1 only).
+    Test-infrastructure use of oracle/: it is the thing timed here, never the
+    product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    h, w = frame.shape[:2]
+    mpx = w * h / 1e6
+    cores = os.cpu_count() or 1
+    if ol.have_ref():
+        kind, enc, dec = "reference", ol.ref_encode, ol.ref_decode
+    else:
+        kind, enc, dec = "port", ol.oracle_encode, ol.oracle_decode
+    # Encode: single thread by design (reference encoder.cpp:258-335).
+    t_enc, n_enc, packed = 0.0, 0, None
+    while n_enc < 1 or (t_enc < budget_s * 0.6 and n_enc < 8):
+        t0 = time.perf_counter()
+        packed = enc(frame, quality, True)
+        t_enc += time.perf_counter() - t0
+        n_enc += 1
+    # Decode: Decoder(0) = all hardware threads (decoder.cpp:79-85); first call warms up.
+    dec(packed, 0)
+    t_dec, n_dec = 0.0, 0
+    while n_dec < 2 or (t_dec < budget_s * 0.25 and n_dec < 30):
+        t0 = time.perf_counter()
+        rc, _ = dec(packed, 0)
+        t_dec += time.perf_counter() - t0
+        n_dec += 1
+        assert rc == 0
+    t0 = time.perf_counter()
+    dec(packed, 1)
+    t_dec1 = time.perf_counter() - t0
+    e, d = t_enc / n_enc, t_dec / n_dec
+    return {
+        "value": round(mpx / (e + d), 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+        "sample": "%dx%d RGBA %s q=%d: %d encodes on 1 thread (%.3f s each) + %d decodes on %d threads "
+                  "(%.4f s each); same frame as the GPU run" % (w, h, "randtile", quality, n_enc, e,
+                                                                n_dec, cores, d),
+        "encode_mpx_s_1thread": round(mpx / e, 3),
+        "decode_mpx_s_allthreads": round(mpx / d, 3),
+        "decode_mpx_s_1thread": round(mpx / t_dec1, 3),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import himg_amd
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, B, Q = args.width, args.height, args.batch, args.quality
+    eng = himg_amd.Engine(local_rank)
+    # Synthetic frames: rank r gets seeds r*B .. r*B+B-1 (seed 0 is the golden input).
+    frames = np.stack([himg_amd.synth(args.kind, rank * B + i, W, H) for i in range(B)])
+    d_frames = torch.from_numpy(frames).to(dev)
+    cap = himg_amd.max_packed_size(W, H, 4)
+    d_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st_e = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st_d = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_pix = torch.empty((B, H, W, 4), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def encode():
+        eng.encode_device(d_frames, B, W, H, 4, 4, Q, True, d_out, cap, d_sizes, d_st_e, stream)
+
+    # Packed sizes are needed on the host once (the decode ABI takes them as a host array).
+    encode()
+    torch.cuda.synchronize()
+    h_sizes = d_sizes.cpu().numpy().astype(np.uint32)
+    assert not d_st_e.cpu().numpy().any(), "encode failed: %s" % d_st_e.cpu().numpy()
+
+    def decode():
+        eng.decode_device(d_out, cap, h_sizes, B, W, H, 4, d_pix, d_st_d, stream)
+
+    decode()
+    torch.cuda.synchronize()
+    assert not d_st_d.cpu().numpy().any(), "decode failed: %s" % d_st_d.cpu().numpy()
+
+    # Parity gate before any timing counts.
+    verified = "n/a"
+    if rank == 0:
+        s0 = d_out[0, : int(h_sizes[0])].cpu().numpy()
+        p0 = d_pix[0].cpu().numpy()
+        if (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
+            assert int(h_sizes[0]) == GOLDEN_4096["packed_size"], h_sizes[0]
+            assert himg_amd.fnv1a64(s0) == GOLDEN_4096["stream_fnv"], "stream differs from the reference"
+            assert himg_amd.fnv1a64(p0) == GOLDEN_4096["decoded_fnv"], "pixels differ from the reference"
+            verified = "golden"
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as ol
+            assert np.array_equal(s0, ol.oracle_encode(frames[0], Q, True))
+            verified = "oracle"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        encode()
+        decode()
+    barrier()
+    eng.profile_reset()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        encode()
+        decode()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.profile(False)
+    prof = eng.profile_read()  # stage -> (total ms, launches), HIP events on `stream`
+
+    # Encode-only and decode-only rates (same protocol, not part of `value`).
+    def timed(fn, n):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+    n_side = max(3, args.steps // 2)
+    t_enc = timed(encode, n_side)
+    t_dec = timed(decode, n_side)
+
+    if world > 1:
+        t = torch.tensor([dt, t_enc, t_dec], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_enc, t_dec = (float(x) for x in t.cpu())
+
+    if rank == 0:
+        px_step = float(world) * B * W * H
+        ms_step = dt / args.steps * 1e3
+        value = px_step * args.steps / dt / 1e6
+        packed_total = float(h_sizes.astype(np.float64).sum())
+        # algorithmic bytes per pixel-frame = W*H*4 read + packed written
+        # (encode), packed read + W*H*4 written (decode); one launch processes B frames.
+        alg_bytes_side = B * W * H * 4.0 + packed_total
+        enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_lres_summary",
+                      "k_tok_hist", "k_tree", "k_sizes", "k_emit", "k_padfix", "memset"}
+        stages = {k: {"ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
+        dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None
+        roofline = None
+        if dom:
+            ach = alg_bytes_side / (stages[dom]["ms"] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                key = "%s@%dx%dx%d" % (dom, W, H, B)
+                traffic = tj.get(key)
+            roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom in enc_stages else "decode",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": alg_bytes_side,
+                        "kernel_ms": round(stages[dom]["ms"], 4)}
+        out = {
+            "metric": "Mpixels/s encode+decode, 4K RGBA q=50", "value": round(value, 2),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i16/i32 integer", "data": "synthetic",
+            "config": {"workload": "%dx%d RGBA %s q=%d, encode+decode, batch %d frames/GPU resident in HBM"
+                                   % (W, H, args.kind, Q, B),
+                       "parallelism": "independent frames sharded over %d rank(s), no data-path collective" % world,
+                       "bit_exact": verified},
+            "encode_mpx_s": round(world * B * W * H / t_enc / 1e6, 2),
+            "decode_mpx_s": round(world * B * W * H / t_dec / 1e6, 2),
+            "encode_read_roofline_frac": round(B * W * H * 4.0 / t_enc / 1e9 / HBM_PEAK_GBS, 4),
+            "pipeline_roofline": {
+                "encode_GBs": round(alg_bytes_side / t_enc / 1e9, 1),
+                "decode_GBs": round(alg_bytes_side / t_dec / 1e9, 1),
+                "encode_frac": round(alg_bytes_side / t_enc / 1e9 / HBM_PEAK_GBS, 4),
+                "decode_frac": round(alg_bytes_side / t_dec / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": roofline,
+            "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[0], Q, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""GPU (-m gpu): the HIP path through the C ABI vs the CPU oracle and the
+golden vectors recorded from the real reference.  Bar: bit-exact."""
+import numpy as np
+import pytest
+
+import himg_amd
+import oracle_lib as ol
+from golden_util import GOLDEN, cases, fixture, make_input
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(a, b, what):
+    a = np.asarray(a).ravel()
+    b = np.asarray(b).ravel()
+    assert a.size == b.size, "%s: size %d vs %d" % (what, a.size, b.size)
+    d = np.nonzero(a != b)[0]
+    assert d.size == 0, "%s: %d mismatches, first at %d (gpu=%s oracle=%s)" % (
+        what, d.size, d[0], a[d[0]], b[d[0]])
+
+
+STAGE_CASES = [("gradn", 0, 64, 64, 50), ("rand", 1, 64, 64, 50), ("randtile", 2, 64, 64, 50),
+               ("randtile", 3, 200, 120, 50), ("gradn", 4, 512, 512, 50),
+               ("randtile", 5, 512, 256, 90), ("randtile", 6, 256, 512, 10),
+               ("rand", 7, 136, 72, 100), ("grad", 0, 256, 256, 0)]
+
+
+@pytest.mark.parametrize("kind,seed,w,h,q", STAGE_CASES)
+def test_encode_stages_match_oracle(engine, kind, seed, w, h, q):
+    """Every intermediate product of the encoder, not just the final bytes."""
+    img = himg_amd.synth(kind, seed, w, h)
+    packed_o, tr = ol.oracle_encode(img, q, True, trace=True)
+    packed_g = engine.encode(img, q, True)
+    n_plane = 4 * tr["rows"] * tr["cols"]
+    _eq(engine.debug_read("avg", 0, n_plane), tr["avg"], "box averages")
+    _eq(engine.debug_read("lowres", 0, n_plane), tr["lowres"], "low-res plane")
+    _eq(engine.debug_read("lres_sym", 0, tr["lres_sym"].size), tr["lres_sym"], "LRES symbols")
+    _eq(engine.debug_read("fres_sym", 0, tr["fres_sym"].size), tr["fres_sym"], "FRES symbols")
+    for k in ("lres_hist", "fres_hist", "lres_len", "fres_len"):
+        _eq(engine.debug_read(k, 0, 261 * 4, np.uint32), tr[k], k)
+    for k in ("lres_code", "fres_code"):
+        _eq(engine.debug_read(k, 0, 261 * 8, np.uint64), tr[k], k)
+    _eq(engine.debug_read("fres_row_bytes", 0, tr["rows"] * 4, np.uint32), tr["fres_row_bytes"],
+        "row payload bytes")
+    _eq(packed_g, packed_o, "stream")
+
+
+@pytest.mark.parametrize("kind,seed,w,h,q", STAGE_CASES[:6])
+def test_decode_stages_match_oracle(engine, kind, seed, w, h, q):
+    img = himg_amd.synth(kind, seed, w, h)
+    packed = ol.oracle_encode(img, q, True)
+    rc, dt = ol.oracle_decode_trace(packed)
+    assert rc == 0
+    pix = engine.decode(packed)
+    _eq(engine.debug_read("lres_sym", 0, dt["lres_sym"].size, decoder=True), dt["lres_sym"], "LRES symbols")
+    _eq(engine.debug_read("lowres", 0, dt["lowres"].size, decoder=True), dt["lowres"], "low-res plane")
+    _eq(engine.debug_read("fres_sym", 0, dt["fres_sym"].size, decoder=True), dt["fres_sym"], "FRES symbols")
+    _eq(pix, dt["pixels"], "pixels")
+
+
+@pytest.mark.parametrize("name", cases(max_pixels=4096 * 4096))
+def test_encode_matches_golden(engine, name):
+    """Golden streams from the real reference, up to BASELINE's 4096x4096 configs
+    (quality sweep included): size, chunk sizes and FNV-1a-64 of the bytes."""
+    rec = GOLDEN[name]
+    img = make_input(rec)
+    packed = engine.encode(img, rec["quality"], bool(rec["ycbcr"]))
+    assert packed.size == rec["packed_size"]
+    assert himg_amd.fnv1a64(packed) == rec["stream_fnv"]
+    if "fixture" in rec:
+        _eq(packed, fixture(rec), "fixture bytes")
+
+
+@pytest.mark.parametrize("name", cases(max_pixels=4096 * 4096))
+def test_decode_matches_golden(engine, name):
+    rec = GOLDEN[name]
+    img = make_input(rec)
+    packed = fixture(rec) if "fixture" in rec else engine.encode(img, rec["quality"], bool(rec["ycbcr"]))
+    if not rec["decodes"]:
+        with pytest.raises(himg_amd.HimgError) as e:   # trap T2: same accept/reject as the reference
+            engine.decode(packed)
+        assert e.value.code == himg_amd.HIMG_ERR_FORMAT
+        return
+    if rec["width"] % 8:
+        pytest.skip("W%8 != 0 decode is undefined in the reference (trap T9)")
+    dec = engine.decode(packed)
+    assert dec.shape == (rec["height"], rec["width"], rec["channels"])
+    assert himg_amd.fnv1a64(dec) == rec["decoded_fnv"]
+    assert round(himg_amd.psnr(img, dec), 4) == pytest.approx(rec["psnr"], abs=1e-4)
+
+
+@pytest.mark.parametrize("w,h,ch,stride,ycbcr,q", [
+    (64, 64, 3, 3, True, 50), (64, 64, 3, 4, True, 50), (72, 40, 1, 1, True, 50),
+    (72, 40, 2, 2, True, 70), (64, 64, 4, 4, False, 50), (128, 52, 4, 4, True, 50),
+    (100, 60, 4, 4, True, 50), (8, 8, 4, 4, True, 50), (8, 200, 4, 4, True, 50),
+    (520, 24, 4, 4, True, 30), (4104, 16, 4, 4, True, 50)])
+def test_general_shapes_match_oracle(engine, w, h, ch, stride, ycbcr, q):
+    """Channel counts, pixel_stride > channels, -rgb mode, ragged heights and
+    widths, single-block-row images (no size headers)."""
+    img = himg_amd.synth("randtile", w * 7 + h, w, h)
+    if stride != 4:
+        img = np.ascontiguousarray(img[:, :, :stride])
+    a = engine.encode(img, q, ycbcr, channels=ch, pixel_stride=stride)
+    b = ol.oracle_encode(img, q, ycbcr, channels=ch, stride=stride)
+    _eq(a, b, "stream")
+    rc, pix = ol.oracle_decode(b)
+    if rc != 0:
+        with pytest.raises(himg_amd.HimgError):
+            engine.decode(b)
+    elif w % 8 == 0:
+        _eq(engine.decode(b), pix, "pixels")
+
+
+def test_long_zero_runs_and_run_splitting(engine):
+    """Flat and nearly flat frames: runs longer than 16662 are split greedily from
+    the run start and never cross a block row (trap T6); LRES spans are all zero."""
+    for w, h, fill in [(2048, 64, 7), (1024, 1024, 200)]:
+        img = np.full((h, w, 4), fill, np.uint8)
+        img[h // 2, w // 3] = 255 - fill
+        a = engine.encode(img, 50, True)
+        b = ol.oracle_encode(img, 50, True)
+        _eq(a, b, "stream %dx%d" % (w, h))
+
+
+def test_device_batch_api(engine):
+    """Batched, HBM-resident entry points: independent frames in one launch each
+    equal their single-frame golden streams; batched decode returns the pixels."""
+    import torch
+    names = ["randtile_s0_1920x1080_q50", "randtile_s1_1920x1080_q50", "randtile_s255_1920x1080_q50"]
+    recs = [GOLDEN[n] for n in names]
+    w, h = 1920, 1080
+    frames = np.stack([make_input(r) for r in recs] + [himg_amd.synth("rand", 9, w, h)])
+    B = frames.shape[0]
+    dev = torch.device("cuda:0")
+    d_frames = torch.from_numpy(frames).to(dev)
+    cap = himg_amd.max_packed_size(w, h, 4)
+    d_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_status = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    engine.encode_device(d_frames, B, w, h, 4, 4, 50, True, d_out, cap, d_sizes, d_status, stream)
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().numpy().astype(np.int64)
+    assert not d_status.cpu().numpy().any()
+    out = d_out.cpu().numpy()
+    for i, r in enumerate(recs):
+        assert sizes[i] == r["packed_size"]
+        assert himg_amd.fnv1a64(out[i, :sizes[i]]) == r["stream_fnv"]
+    _eq(out[3, :sizes[3]], ol.oracle_encode(frames[3], 50, True), "frame 3")
+
+    d_pix = torch.empty((B, h, w, 4), dtype=torch.uint8, device=dev)
+    d_st2 = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    engine.decode_device(d_out, cap, sizes.astype(np.uint32), B, w, h, 4, d_pix, d_st2, stream)
+    torch.cuda.synchronize()
+    assert not d_st2.cpu().numpy().any()
+    pix = d_pix.cpu().numpy()
+    for i, r in enumerate(recs):
+        assert himg_amd.fnv1a64(pix[i]) == r["decoded_fnv"]
+
+
+def test_decoder_rejects_like_reference(engine):
+    rec = GOLDEN["gradn_s0_64x64_q50"]
+    good = fixture(rec)
+    # Not RIFF / wrong total size / truncated / damaged row header.
+    bad = [good.copy() for _ in range(4)]
+    bad[0][0] = ord("X")
+    bad[1] = np.concatenate([good, np.zeros(3, np.uint8)])
+    bad[2] = good[:-40].copy()
+    bad[2][4:8] = np.frombuffer(np.uint32(bad[2].size - 8).tobytes(), np.uint8)
+    for b in bad[:3]:
+        rc, _ = ol.oracle_decode(b)
+        assert rc != 0
+        with pytest.raises(himg_amd.HimgError):
+            engine.decode(b)
+    # Stale pad bits (trap T1) are ignored by the decoder.
+    _eq(engine.decode(good), ol.oracle_decode(good)[1], "pixels")
+
+
+def test_engine_is_reusable_and_fresh_per_call(engine):
+    """Every encode has fresh-Encoder semantics (trap T4) and contexts are reusable."""
+    a = himg_amd.synth("randtile", 1, 128, 128)
+    b = himg_amd.synth("gradn", 2, 256, 64)
+    e1 = engine.encode(a, 50)
+    engine.encode(b, 30)
+    e2 = engine.encode(a, 50)
+    _eq(e1, e2, "repeat encode")
+    _eq(e1, ol.oracle_encode(a, 50), "oracle")
