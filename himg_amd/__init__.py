@@ -48,6 +48,13 @@ def lib():
     path = LIB
     if not os.path.exists(path):
         path = build_lib()
+    # PyTorch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Whichever
+    # copy is loaded first serves the whole process, and torch cannot enumerate
+    # GPUs through a foreign copy -- so when torch is installed let it load first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, i32, u32, u64, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
     P = C.POINTER
