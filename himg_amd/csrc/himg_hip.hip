@@ -331,7 +331,23 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   return HIMG_OK;
 }
 
+// Text the reference prints for a failed stage (decoder.cpp:96-135,232,287,345).
+static std::string format_message(int32_t st) {
+  static const char *kStage[] = {"", "Not a RIFF HIMG file.\n", "Error decoding header.\n",
+                                 "Error decoding low-res mapping function.\n",
+                                 "Error decoding low-res data.\n",
+                                 "Error decoding quantization configuration.\n",
+                                 "Error decoding full-res mapping function.\n",
+                                 "Error decoding full-res data.\n"};
+  std::string m;
+  if (st & 0x100) m += "Error: Invalid Huffman data.\n";
+  const int stage = (st >> 4) & 7;
+  m += kStage[stage];
+  return m;
+}
+
 static int status_to_code(int32_t st) {
+  st &= 15;
   switch (st) {
     case 0: return HIMG_OK;
     case 1: return HIMG_ERR_ARG;
@@ -450,18 +466,18 @@ extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t 
   // decoder.cpp:144-200
   if (packed_size < 12 || packed_size > 0x7fffffffu || memcmp(packed, "RIFF", 4) != 0 ||
       memcmp(packed + 8, "HIMG", 4) != 0)
-    return fail(ctx, HIMG_ERR_FORMAT, "Not a RIFF HIMG file.");
+    return fail(ctx, HIMG_ERR_FORMAT, "Not a RIFF HIMG file.\n");
   size_t idx = 12;
   int W = 0, H = 0, C = 0;
   for (;;) {
-    if (idx + 8 > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.");
+    if (idx + 8 > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.\n");
     const uint32_t sz = packed[idx + 4] | (packed[idx + 5] << 8) | (packed[idx + 6] << 16) |
                         ((uint32_t)packed[idx + 7] << 24);
     const bool frmt = memcmp(packed + idx, "FRMT", 4) == 0;
     idx += 8;
-    if (idx + sz > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.");
+    if (idx + sz > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.\n");
     if (frmt) {
-      if (sz < 11 || packed[idx] != 1) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.");
+      if (sz < 11 || packed[idx] != 1) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.\n");
       W = (int)(packed[idx + 1] | (packed[idx + 2] << 8) | (packed[idx + 3] << 16) | ((uint32_t)packed[idx + 4] << 24));
       H = (int)(packed[idx + 5] | (packed[idx + 6] << 8) | (packed[idx + 7] << 16) | ((uint32_t)packed[idx + 8] << 24));
       C = packed[idx + 9];
@@ -484,7 +500,14 @@ extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t 
   if (rc) return rc;
   int32_t st = 0;
   HIP_TRY(ctx, hipMemcpy(&st, ctx->h_status.p, 4, hipMemcpyDeviceToHost));
-  if (st) return fail(ctx, status_to_code(st), "Error: Invalid Huffman data.");
+  if (st) {
+    const int code = status_to_code(st);
+    if (code == HIMG_ERR_FORMAT) {
+      ctx->err = format_message(st);
+      return code;
+    }
+    return fail(ctx, code, "device decode reported an error");
+  }
   uint8_t *buf = (uint8_t *)std::malloc(out_bytes ? out_bytes : 1);
   if (!buf) return fail(ctx, HIMG_ERR_ARG, "out of host memory");
   HIP_TRY(ctx, hipMemcpy(buf, ctx->h_out.p, out_bytes, hipMemcpyDeviceToHost));

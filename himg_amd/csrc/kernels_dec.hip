@@ -25,7 +25,11 @@ __device__ static constexpr uint8_t kScanD[64] = {
 
 // Device status values (host maps them to HIMG_ERR_*): 0 ok, 1 geometry
 // mismatch, 3 outside the built scope, 4 the reference would return false.
+// A format error also carries the decoder stage that failed in bits 4..7 and
+// "the Huffman layer complained first" in bit 8, so that the C++ wrapper can
+// print the same lines as the reference (decoder.cpp:96-135,232,287,345).
 constexpr int kStGeom = 1, kStUnsupported = 3, kStFormat = 4;
+__device__ __host__ constexpr int fmt_err(int stage, int huff) { return kStFormat | (stage << 4) | (huff << 8); }
 constexpr int kMaxDepth = 48;   // deepest code the decoder walks (+14 extra bits <= 64)
 constexpr int kMaxNodes = 2 * kNumSym - 1;
 
@@ -132,9 +136,9 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
     do {
       // decoder.cpp:144-166
       if (n < 12 || rd32(p) != 0x46464952u /*RIFF*/ || rd32(p + 4) + 8u != n ||
-          rd32(p + 8) != 0x474d4948u /*HIMG*/) { st = kStFormat; break; }
+          rd32(p + 8) != 0x474d4948u /*HIMG*/) { st = fmt_err(1, 0); break; }
       // decoder.cpp:168-200
-      if (!find_chunk(p, n, &idx, 0x544d5246u /*FRMT*/, &sz) || sz < 11 || p[idx] != 1) { st = kStFormat; break; }
+      if (!find_chunk(p, n, &idx, 0x544d5246u /*FRMT*/, &sz) || sz < 11 || p[idx] != 1) { st = fmt_err(2, 0); break; }
       {
         const uint32_t w = rd32(p + idx + 1), h = rd32(p + idx + 5);
         const int c = p[idx + 9];
@@ -143,19 +147,19 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
         idx += sz;
       }
       // decoder.cpp:202-212
-      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz) || !parse_map(p + idx, sz, df->lmap)) { st = kStFormat; break; }
+      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz) || !parse_map(p + idx, sz, df->lmap)) { st = fmt_err(3, 0); break; }
       idx += sz;
       // decoder.cpp:214-232: LRES is one unblocked stream.
-      if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { st = kStFormat; break; }
+      if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { st = fmt_err(4, 0); break; }
       df->s[0].chunk_end = idx + sz;
       st = recover_tree(p, idx, idx + sz, nodes0, aux[0], &df->s[0].num_nodes, &df->s[0].payload_off);
-      if (st) break;
+      if (st) { if (st == kStFormat) st = fmt_err(4, 1); break; }
       df->s[0].root = 0;
       // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
-      if (df->s[0].payload_off >= df->s[0].chunk_end) { st = kStFormat; break; }
+      if (df->s[0].payload_off >= df->s[0].chunk_end) { st = fmt_err(4, 1); break; }
       idx += sz;
       // decoder.cpp:250-260, quantize.cpp:190-213
-      if (!find_chunk(p, n, &idx, 0x47464351u /*QCFG*/, &sz) || sz != (df->ycbcr ? 64u : 32u)) { st = kStFormat; break; }
+      if (!find_chunk(p, n, &idx, 0x47464351u /*QCFG*/, &sz) || sz != (df->ycbcr ? 64u : 32u)) { st = fmt_err(5, 0); break; }
       for (int i = 0; i < 32; ++i) {
         df->shift[0][2 * i] = p[idx + i] >> 4; df->shift[0][2 * i + 1] = p[idx + i] & 15;
         const uint8_t x = df->ycbcr ? p[idx + 32 + i] : 0;
@@ -163,42 +167,43 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       }
       idx += sz;
       // decoder.cpp:262-272
-      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz) || !parse_map(p + idx, sz, df->fmap)) { st = kStFormat; break; }
+      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz) || !parse_map(p + idx, sz, df->fmap)) { st = fmt_err(6, 0); break; }
       idx += sz;
       // decoder.cpp:274-290
-      if (!find_chunk(p, n, &idx, 0x53455246u /*FRES*/, &sz)) { st = kStFormat; break; }
+      if (!find_chunk(p, n, &idx, 0x53455246u /*FRES*/, &sz)) { st = fmt_err(7, 0); break; }
       df->s[1].chunk_end = idx + sz;
       // Trap T2: the decoder derives use_blocks from the COMPRESSED size
       // (huffman_dec.cpp:215-219); UncompressBlock refuses when it is false (:265).
-      if (!((uint32_t)g.row_block < sz)) { st = kStFormat; break; }
+      if (!((uint32_t)g.row_block < sz)) { st = fmt_err(7, 1); break; }
       st = recover_tree(p, idx, idx + sz, nodes1, aux[1], &df->s[1].num_nodes, &df->s[1].payload_off);
-      if (st) break;
+      if (st) { if (st == kStFormat) st = fmt_err(7, 1); break; }
       df->s[1].root = 0;
-      if (df->s[1].payload_off >= df->s[1].chunk_end) { st = kStFormat; break; }
+      if (df->s[1].payload_off >= df->s[1].chunk_end) { st = fmt_err(7, 1); break; }
       // Row index: serial walk over the size headers (huffman_dec.cpp:232-248).
       uint32_t q = df->s[1].payload_off, end = df->s[1].chunk_end;
       uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
       int r = 0;
       while (q != end) {
-        if (q + 2 > end) { st = kStFormat; break; }
+        if (q + 2 > end) { st = fmt_err(7, 1); break; }
         uint32_t len = p[q] | (p[q + 1] << 8);
         q += 2;
         if (len & 0x8000u) {
-          if (q + 2 > end) { st = kStFormat; break; }
+          if (q + 2 > end) { st = fmt_err(7, 1); break; }
           len = (len & 0x7fffu) | ((uint32_t)(p[q] | (p[q + 1] << 8)) << 15);
           q += 2;
         }
-        if (len > end - q) { st = kStFormat; break; }
+        if (len > end - q) { st = fmt_err(7, 1); break; }
         if (r < g.rows) { ro[r] = q; rl[r] = len; }
         ++r;
         q += len;
       }
-      if (!st && r < g.rows) st = kStFormat;  // fewer blocks than block rows
+      if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
     } while (0);
     // A tree that is a single leaf decodes without consuming code bits in the
     // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
     // the encoder's 1-bit codes; such streams are rejected here.
-    if (!st && (nodes0[2] >= 0 || nodes1[2] >= 0)) st = kStFormat;
+    if (!st && nodes0[2] >= 0) st = fmt_err(4, 1);
+    if (!st && nodes1[2] >= 0) st = fmt_err(7, 1);
     df->status = st;
     s_status = st;
   }
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     const unsigned long long E = s_endbit;      // bits consumed when the block became full
     // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
     if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
-    if (bad) atomicMax(&df->status, kStFormat);
+    if (bad) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
   }
 }
 

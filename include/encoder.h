@@ -1,0 +1,50 @@
+// encoder.h -- himg::Encoder, source compatible with the reference's public
+// surface (reference src/lib/encoder.h:20-64), backed by the MI355X engine.
+//
+// Callers written against the reference (src/chimg.cpp:140-163) compile
+// unchanged: same header name, namespace, constructor and public methods.  The
+// private part is different by design -- everything below the API is the C ABI
+// of include/himg_hip.h (hand-written HIP kernels), not a port of src/lib.
+#ifndef ENCODER_H_
+#define ENCODER_H_
+
+#include <cstdint>
+#include <vector>
+
+struct himg_hip_ctx;
+
+namespace himg {
+
+class Encoder {
+ public:
+  Encoder();
+  ~Encoder();
+  Encoder(const Encoder &) = delete;
+  Encoder &operator=(const Encoder &) = delete;
+
+  // Same contract as the reference (encoder.cpp:59-109): `data` is read during
+  // the call only; rows are tightly packed width*pixel_stride bytes.  Prints the
+  // reference's two progress lines to std::cout (encoder.cpp:219,334).  Unlike
+  // the reference, which always returns true, this returns false when the GPU
+  // engine reports an error (there is no CPU fallback).  Every call has
+  // fresh-object semantics (the reference's objects are single-use).
+  bool Encode(const uint8_t *data,
+              int width,
+              int height,
+              int pixel_stride,
+              int num_channels,
+              int quality,
+              bool use_ycbcr);
+
+  const uint8_t *packed_data() const { return m_packed_data.data(); }
+
+  int packed_size() const { return static_cast<int>(m_packed_data.size()); }
+
+ private:
+  himg_hip_ctx *m_ctx;
+  std::vector<uint8_t> m_packed_data;
+};
+
+}  // namespace himg
+
+#endif  // ENCODER_H_
