@@ -98,6 +98,18 @@ struct DecWs {
   uint8_t *lres_sym;         size_t lres_stride;
   uint8_t *fres_sym;         size_t fres_stride;
   uint8_t *low;              size_t plane_stride;
+  uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
+  // Parallel LRES decode (k_lres_spec / verify / write).
+  int lres_chunks;           // chunk slots per frame (upper bound from lres_size)
+  uint32_t *spec_start;      // [f][lres_chunks][1024] lane start, bits from the chunk's nominal start
+  uint32_t *spec_endpos;     // [f][lres_chunks][1024] lane end, same origin
+  uint32_t *spec_cnt;        // [f][lres_chunks][1024] symbols per lane
+  uint64_t *spec_end;        // [f][lres_chunks] payload bit where the chunk's speculative chain ends
+  uint64_t *fix_end;         // [f][lres_chunks] the same after the correction pass
+  uint64_t *spec_tot;        // [f][lres_chunks] symbols of the chunk
+  uint64_t *ver_base;        // [f][lres_chunks] output offset of the chunk
+  int32_t *ver_ok;           // [f] 1 when every chunk verified
+  uint64_t *lres_endbit;     // [f] bits consumed when the LRES output became complete
 };
 
 // ---- launch wrappers (defined in kernels_enc.hip / kernels_dec.hip) --------
@@ -111,7 +123,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
-                   int32_t *d_status, hipStream_t stream, Profiler *prof);
+                   int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused);
 
 // Stage timing hook: called before/after every kernel launch when profiling.
 void prof_begin(Profiler *p, const char *stage, hipStream_t s);

@@ -95,6 +95,9 @@ struct himg_hip_ctx {
   std::string err;
   Profiler prof;
   hipStream_t last_stream = nullptr;
+  // HIMG_FORCE_UNFUSED=1 routes every block row through the generic decode path
+  // (symbols via HBM), the one rows wider than the LDS budget always take.
+  bool allow_fused = true;
 
   // Fixed table: LUT of the full-res companding search (FullResMapper is the
   // same for every quality, mapper.cpp:213-223), 32769 entries.
@@ -108,7 +111,7 @@ struct himg_hip_ctx {
   bool enc_valid = false;
 
   // Decoder workspace.
-  DevBuf d_frames, d_nodes, d_lut, d_rows, d_lres, d_fres, d_planes, d_sizes;
+  DevBuf d_frames, d_nodes, d_lut, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
   Geom dec_geom{};
   DecWs dec_ws{};
   int dec_batch = 0;
@@ -175,6 +178,7 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   if (hipSetDevice(device) != hipSuccess) return HIMG_ERR_HIP;
   himg_hip_ctx *ctx = new himg_hip_ctx();
   ctx->device = device;
+  if (const char *e = std::getenv("HIMG_FORCE_UNFUSED")) ctx->allow_fused = !(e[0] == '1');
   // Companding LUT for every magnitude an int16 can take.
   std::vector<uint8_t> lut(32769);
   int16_t fmap[128];
@@ -197,7 +201,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   ctx->prof.collect();
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
                    &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_lut, &ctx->d_rows,
-                   &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->h_in,
+                   &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
   for (DevBuf *b : all) b->release();
   delete ctx;
@@ -315,7 +319,8 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
       !ctx->d_lut.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
-      !ctx->d_sizes.reserve((size_t)batch * 4))
+      !ctx->d_sizes.reserve((size_t)batch * 4) ||
+      !ctx->d_stats.reserve((size_t)batch * (g.rows + 1) * 8 * 4))
     return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
   w.frames = (DecFrame *)ctx->d_frames.p;
   w.nodes = (int32_t *)ctx->d_nodes.p;
@@ -325,6 +330,33 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.lres_sym = (uint8_t *)ctx->d_lres.p; w.lres_stride = lres;
   w.fres_sym = (uint8_t *)ctx->d_fres.p; w.fres_stride = fres;
   w.low = (uint8_t *)ctx->d_planes.p; w.plane_stride = plane;
+  w.stats = (uint32_t *)ctx->d_stats.p;
+  {
+    // LRES payload <= lres_size + tree bytes (huffman_enc.cpp:242-244).
+    const size_t max_bits = 8ull * ((size_t)g.lres_size + kTreeStride);
+    const size_t cb = (size_t)kDecThreads * 8 * 32;
+    int nch = (int)((max_bits + cb - 1) / cb);
+    if (nch > 1024) nch = 1024;  // beyond this the serial path takes over (k_lres_verify)
+    w.lres_chunks = nch;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += round_up(bytes, 256); return o; };
+    const size_t o_ss = carve((size_t)batch * nch * kDecThreads * 4);
+    const size_t o_sc = carve((size_t)batch * nch * kDecThreads * 4);
+    const size_t o_se = carve((size_t)batch * nch * 8);
+    const size_t o_st = carve((size_t)batch * nch * 8);
+    const size_t o_sp = carve((size_t)batch * nch * kDecThreads * 4);
+    const size_t o_fe = carve((size_t)batch * nch * 8);
+    const size_t o_vb = carve((size_t)batch * nch * 8);
+    const size_t o_ok = carve((size_t)batch * 4);
+    const size_t o_eb = carve((size_t)batch * 8);
+    if (!ctx->d_spec.reserve(off)) return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
+    uint8_t *b = (uint8_t *)ctx->d_spec.p;
+    w.spec_start = (uint32_t *)(b + o_ss); w.spec_cnt = (uint32_t *)(b + o_sc);
+    w.spec_end = (uint64_t *)(b + o_se); w.spec_tot = (uint64_t *)(b + o_st);
+    w.spec_endpos = (uint32_t *)(b + o_sp); w.fix_end = (uint64_t *)(b + o_fe);
+    w.ver_base = (uint64_t *)(b + o_vb); w.ver_ok = (int32_t *)(b + o_ok);
+    w.lres_endbit = (uint64_t *)(b + o_eb);
+  }
   ctx->dec_geom = g;
   ctx->dec_batch = batch;
   ctx->dec_valid = true;
@@ -417,7 +449,8 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   ctx->last_stream = s;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, h_sizes, (size_t)batch * 4, hipMemcpyHostToDevice, s));
   launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
-                (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof);
+                (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof,
+                ctx->allow_fused);
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }
@@ -565,6 +598,7 @@ extern "C" int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void 
       case HIMG_DBG_LOWRES: src = w.low + frame * w.plane_stride; n = (size_t)g.C * g.rows * g.cols; break;
       case HIMG_DBG_LRES_SYM: src = w.lres_sym + frame * w.lres_stride; n = (size_t)g.lres_size; break;
       case HIMG_DBG_FRES_SYM: src = w.fres_sym + frame * w.fres_stride; n = (size_t)g.fres_size; break;
+      case HIMG_DBG_DEC_STATS: src = w.stats + (size_t)frame * (g.rows + 1) * 8; n = (size_t)(g.rows + 1) * 32; break;
       default: return HIMG_ERR_ARG;
     }
   }

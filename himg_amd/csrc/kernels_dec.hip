@@ -30,7 +30,7 @@ __device__ static constexpr uint8_t kScanD[64] = {
 // print the same lines as the reference (decoder.cpp:96-135,232,287,345).
 constexpr int kStGeom = 1, kStUnsupported = 3, kStFormat = 4;
 __device__ __host__ constexpr int fmt_err(int stage, int huff) { return kStFormat | (stage << 4) | (huff << 8); }
-constexpr int kMaxDepth = 48;   // deepest code the decoder walks (+14 extra bits <= 64)
+constexpr int kMaxDepth = 32;   // deepest code the decoder walks (the reference encoder keeps codes in uint32_t)
 constexpr int kMaxNodes = 2 * kNumSym - 1;
 
 __device__ __forceinline__ int clamp255d(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
@@ -111,9 +111,17 @@ __device__ int recover_tree(const uint8_t *p, uint32_t begin, uint32_t end, int3
   return 0;
 }
 
-// LUT entry: [8:0] symbol | [9] "continue at node" flag | [19:10] node | [25:20] bits.
-__device__ __forceinline__ uint32_t lut_leaf(int sym, int bits) { return (uint32_t)sym | ((uint32_t)bits << 20); }
-__device__ __forceinline__ uint32_t lut_node(int node, int bits) { return 512u | ((uint32_t)node << 10) | ((uint32_t)bits << 20); }
+// LUT entry: [8:0] symbol | [9] "continue at node" flag | [15:10] code bits |
+// [19:16] RLE extra bits of the symbol | [31:20] node index (flagged entries).
+__device__ __forceinline__ int rle_extra_bits(int sym) {
+  return sym < 257 ? 0 : sym == 257 ? 2 : sym == 258 ? 4 : sym == 259 ? 8 : 14;
+}
+__device__ __forceinline__ uint32_t lut_leaf(int sym, int bits) {
+  return (uint32_t)sym | ((uint32_t)bits << 10) | ((uint32_t)rle_extra_bits(sym) << 16);
+}
+__device__ __forceinline__ uint32_t lut_node(int node, int bits) {
+  return 512u | ((uint32_t)bits << 10) | ((uint32_t)node << 20);
+}
 
 // ---------------------------------------------------------------------------
 // k_dec_parse: one wavefront per frame; lane 0 walks the container, the whole
@@ -230,45 +238,102 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
 }
 
 // ---------------------------------------------------------------------------
-// k_dec_huff
+// Entropy decoding (huffman_dec.cpp:274-418), parallel inside one stream.
+//
+// A whole workgroup (1024 lanes) decodes one Huffman stream (the LRES stream or
+// one FRES block row).  The payload is processed in chunks of 1024 sub-sequences
+// of WPS*32 bits.  Every lane decodes one sub-sequence speculatively from its
+// nominal start; then the workgroup iterates start[t+1] = end[t] until nothing
+// changes.  Lane 0's start is exact, so by induction the fixpoint is the exact
+// token chain (Huffman streams self-synchronise, typically a few rounds).  A
+// prefix scan of the per-lane symbol counts places the output.
+//
+// The chunk's payload words are staged in LDS TRANSPOSED ([word-in-subsequence]
+// [lane]) so that the 64 lanes of a wave, which walk 64 different sub-sequences,
+// hit 64 different banks; each lane keeps a 64-bit bit window in registers and
+// refills it one dword at a time.
 // ---------------------------------------------------------------------------
-constexpr int kSubBits = 256;                                    // bits per sub-sequence
-constexpr int kChunkBits = kDecThreads * kSubBits;               // per workgroup iteration
-constexpr int kPayWords = kChunkBits / 32 + 8;                   // staged payload (+ slack)
-constexpr int kWinBytes = 32768;                                 // output window in LDS
+constexpr int kWinBytes = 32768;  // output window in LDS (generic kernel)
+
+template <int WPS>
+struct PayView {
+  const uint32_t *pay;  // LDS, transposed
+  static constexpr int kRow = kDecThreads + 2;
+  __device__ __forceinline__ uint32_t ld(uint32_t j) const {
+    return pay[(j & (WPS - 1)) * kRow + (j / WPS)];
+  }
+};
+
+// Plain (untransposed) view: word j at w[j].
+struct LinearView {
+  const uint32_t *w;
+  __device__ __forceinline__ uint32_t ld(uint32_t j) const { return w[j]; }
+};
+
+// 64-bit bit window over a payload view.
+struct BitReader {
+  unsigned long long win;
+  int nb;         // valid bits in win
+  uint32_t next;  // next staged word to load
+  template <class PV>
+  __device__ __forceinline__ void init(const PV &pv, uint32_t pos) {
+    const uint32_t j = pos >> 5, sh = pos & 31;
+    win = (((unsigned long long)pv.ld(j + 1) << 32) | pv.ld(j)) >> sh;
+    nb = 64 - (int)sh;
+    next = j + 2;
+  }
+  __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
+};
+
+struct DecTables {
+  const uint32_t *lut;             // LDS, 1 << kLutBits entries
+  const short *ca, *cb, *sy;       // LDS tree nodes
+};
 
 struct Tok { int sym; int nbits; int count; };
 
-// Decode one token at bit `pos` of the staged payload.
-__device__ __forceinline__ Tok decode_token(const uint32_t *pay, uint32_t pos, const uint32_t *lut,
-                                            const short *ca, const short *cb, const short *sy) {
-  const uint32_t wi = pos >> 5, sh = pos & 31;
-  const uint32_t w0 = pay[wi], w1 = pay[wi + 1], w2 = pay[wi + 2];
-  unsigned long long v = (((unsigned long long)w1 << 32) | w0) >> sh;
-  if (sh) v |= (unsigned long long)w2 << (64 - sh);
-  const uint32_t e = lut[v & ((1u << kLutBits) - 1)];
-  int len = (int)(e >> 20) & 63;
-  int sym;
+// Token step of the hot loops, fully inline: one branch-free refill (>= 33
+// valid bits, enough for any code), one LUT read that yields symbol, code length
+// and extra-bit count; lanes whose code is longer than kLutBits walk the tree
+// (divergent, rare per lane); a second refill for the extra bits happens only
+// when some lane of the wave needs it.
+template <class PV>
+__device__ __forceinline__ void refill_bf(BitReader &br, const PV &pv) {
+  const uint32_t w = pv.ld(br.next);
+  const bool need = br.nb <= 32;
+  const unsigned long long add = (unsigned long long)w << (br.nb & 63);
+  br.win |= need ? add : 0ull;
+  br.nb += need ? 32 : 0;
+  br.next += need ? 1u : 0u;
+}
+
+template <class PV>
+__device__ __forceinline__ Tok next_token(BitReader &br, const PV &pv, const DecTables &t) {
+  refill_bf(br, pv);
+  const uint32_t e = t.lut[(uint32_t)br.win & ((1u << kLutBits) - 1)];
+  int len = (int)(e >> 10) & 63, eb = (int)(e >> 16) & 15;
+  int sym = (int)(e & 511u);
   if (e & 512u) {
-    int node = (int)(e >> 10) & 1023;
-    while (sy[node] < 0 && len < kMaxDepth + 1) {
-      node = ((v >> len) & 1ull) ? cb[node] : ca[node];
+    int node = (int)(e >> 20);
+    while (t.sy[node] < 0 && len < kMaxDepth) {
+      node = ((br.win >> len) & 1ull) ? t.cb[node] : t.ca[node];
       ++len;
     }
-    sym = sy[node];
-  } else {
-    sym = (int)(e & 511u);
+    sym = t.sy[node];
+    eb = rle_extra_bits(sym);
   }
-  Tok t;
-  t.sym = sym;
-  if (sym < 256) { t.nbits = len; t.count = 1; return t; }
+  br.consume(len);
+  if (__any(eb > br.nb)) refill_bf(br, pv);
   // RLE symbols (huffman_common.h:24-28, huffman_dec.cpp:330-354).
-  const int eb = sym == 256 ? 0 : sym == 257 ? 2 : sym == 258 ? 4 : sym == 259 ? 8 : 14;
-  const int base = sym == 256 ? 2 : sym == 257 ? 3 : sym == 258 ? 7 : sym == 259 ? 23 : 279;
-  const int extra = (int)((v >> len) & ((1ull << eb) - 1ull));
-  t.nbits = len + eb;
-  t.count = (sym <= 260) ? base + extra : -1;  // symbols above 260: reference aborts (:349-352)
-  return t;
+  const int extra = (int)((uint32_t)br.win & ((1u << eb) - 1u));
+  br.consume(eb);
+  const int base = eb == 0 ? 2 : eb == 2 ? 3 : eb == 4 ? 7 : eb == 8 ? 23 : 279;
+  Tok r;
+  r.sym = sym;
+  r.nbits = len + eb;
+  // Symbols above 260 make the reference abort (huffman_dec.cpp:349-352).
+  r.count = sym < 256 ? 1 : (sym <= 260 ? base + extra : -1);
+  return r;
 }
 
 // Exclusive scan of a 64-bit value over the 1024-thread workgroup.
@@ -294,25 +359,277 @@ __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long 
   return pre + incl - v;
 }
 
+struct StreamShared {            // small LDS state of the stream decoder
+  uint32_t nxt[kDecThreads + 1];
+  unsigned long long sm64[kDecThreads / 64];
+  unsigned long long endbit;     // bits consumed when the output became complete
+  int flag;
+  int err;
+};
+
+// ---- building blocks of the stream decoder -----------------------------------
+
+// Stage the payload words that cover one chunk starting at absolute stream bit
+// `abs_bit` (transposed, zero beyond the stream).  Returns the bit offset of
+// `abs_bit` inside the staged words.  Ends with a barrier.
+template <int WPS>
+__device__ __forceinline__ uint32_t stage_chunk(const uint8_t *p, uint32_t stream_size,
+                                                unsigned long long abs_bit, uint32_t *pay) {
+  constexpr int kStageWords = kDecThreads * WPS + 4;
+  const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;  // dword-aligned byte offset
+  for (int j = threadIdx.x; j < kStageWords; j += kDecThreads) {
+    const uint32_t b = gb + 4u * j;
+    uint32_t w = 0;
+    if (b + 4 <= stream_size) {
+      w = *reinterpret_cast<const uint32_t *>(p + b);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (b + k < stream_size) w |= (uint32_t)p[b + k] << (8 * k);
+    }
+    pay[(j & (WPS - 1)) * PayView<WPS>::kRow + (j / WPS)] = w;
+  }
+  __syncthreads();
+  return (uint32_t)(abs_bit - 8ull * gb);
+}
+
+// Speculative decode of one chunk to the self-synchronised fixpoint.  On return
+// lane t owns exactly the tokens that START in [start, lim) -- relative to lane
+// 0's start `first`, which the caller asserts (exact) or assumes (speculative).
+template <int WPS>
+__device__ __forceinline__ void fixpoint_chunk(const PayView<WPS> &pv, const DecTables &tb,
+                                               StreamShared *sh, uint32_t first, uint32_t my_b0,
+                                               uint32_t lim, uint32_t rel_end, uint32_t *start_io,
+                                               uint32_t *endpos_io, unsigned long long *cnt_io,
+                                               uint32_t *rounds, bool warm = false) {
+  // warm: (*start_io, *endpos_io, *cnt_io) hold a fixpoint reached for another
+  // first-token position; only lanes whose start changes decode again.
+  const int tid = threadIdx.x;
+  uint32_t start = my_b0 < rel_end ? my_b0 : rel_end;
+  if (tid == 0) start = first;
+  uint32_t endpos = start;
+  unsigned long long cnt = 0;
+  bool dirty = true;
+  if (warm) {
+    dirty = (tid == 0) && (first != *start_io);
+    if (!dirty) start = *start_io;
+    endpos = *endpos_io;
+    cnt = *cnt_io;
+  }
+  for (;;) {
+    if (dirty) {
+      uint32_t pos = start;
+      unsigned long long c = 0;
+      if (pos < lim) {
+        BitReader br;
+        br.init(pv, pos);
+        do {
+          const Tok t = next_token(br, pv, tb);
+          pos += t.nbits ? t.nbits : 1;
+          c += (unsigned long long)(t.count > 0 ? t.count : 0);
+        } while (pos < lim);
+      }
+      endpos = pos;
+      cnt = c;
+    }
+    sh->nxt[tid + 1] = endpos;
+    if (tid == 0) sh->flag = 0;
+    __syncthreads();
+    const uint32_t ns = tid == 0 ? first : sh->nxt[tid];
+    dirty = (ns != start);
+    start = ns;
+    if (dirty) sh->flag = 1;
+    __syncthreads();
+    const int any = sh->flag;
+    __syncthreads();
+    ++*rounds;
+    if (!any) break;
+  }
+  *start_io = start;
+  *endpos_io = endpos;
+  *cnt_io = cnt;
+}
+
+// Write the symbols of one chunk through 32 KiB LDS windows (zero runs are the
+// window's zero fill; windows are flushed with 16-byte stores).  Lane t decodes
+// the tokens starting in [bp, lim) and places them from output offset `op`.
+template <int WPS>
+__device__ __forceinline__ void write_chunk_windows(const PayView<WPS> &pv, const DecTables &tb,
+                                                    StreamShared *sh, uint32_t bp, uint32_t lim,
+                                                    unsigned long long op, unsigned long long O0,
+                                                    unsigned long long O1, uint32_t out_size,
+                                                    unsigned long long endbit_base, uint32_t rel0,
+                                                    uint32_t *win, uint8_t *gout) {
+  const int tid = threadIdx.x;
+  bool done = !(bp < lim) || op >= out_size;
+  BitReader br;
+  if (!done) br.init(pv, bp);
+  for (unsigned long long wb = (O0 / kWinBytes) * kWinBytes; wb < O1; wb += kWinBytes) {
+    for (int k = tid; k < kWinBytes / 4; k += kDecThreads) win[k] = 0;
+    __syncthreads();
+    const unsigned long long we = wb + kWinBytes;
+    while (!done && op < we) {
+      const Tok t = next_token(br, pv, tb);
+      if (t.count < 0 || t.nbits == 0) { sh->err = 1; done = true; break; }
+      if (t.sym < 256) {
+        if (t.sym) reinterpret_cast<uint8_t *>(win)[(uint32_t)(op - wb)] = (uint8_t)t.sym;
+      } else if (op + (unsigned long long)t.count > out_size) {
+        sh->err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
+        done = true;
+        break;
+      }
+      op += (unsigned long long)t.count;
+      bp += t.nbits;
+      if (op >= out_size) { sh->endbit = endbit_base + (bp - rel0); done = true; }
+      else if (!(bp < lim)) done = true;
+    }
+    __syncthreads();
+    // Flush [max(wb, O0), min(we, O1)): 16-byte stores inside, bytes at the edges
+    // (another workgroup may own the rest of an edge group).
+    const unsigned long long lo = wb > O0 ? wb : O0, hi = we < O1 ? we : O1;
+    const uint32_t l = (uint32_t)(lo - wb), h = (uint32_t)(hi - wb);
+    const uint32_t la = (l + 15u) & ~15u, ha = h & ~15u;
+    const uint8_t *w8 = reinterpret_cast<const uint8_t *>(win);
+    if (la <= ha && (((uintptr_t)(gout + wb)) & 15) == 0) {
+      for (uint32_t k = l + tid; k < la; k += kDecThreads) gout[wb + k] = w8[k];
+      for (uint32_t k = la / 16 + tid; k < ha / 16; k += kDecThreads) {
+        uint4 q;
+        q.x = win[4 * k]; q.y = win[4 * k + 1]; q.z = win[4 * k + 2]; q.w = win[4 * k + 3];
+        *reinterpret_cast<uint4 *>(gout + wb + 16ull * k) = q;
+      }
+      for (uint32_t k = ha + tid; k < h; k += kDecThreads) gout[wb + k] = w8[k];
+    } else {
+      for (uint32_t k = l + tid; k < h; k += kDecThreads) gout[wb + k] = w8[k];
+    }
+    __syncthreads();
+  }
+}
+
+// Decode one whole stream with one workgroup, chunk after chunk (each chunk's
+// first token position is exact because the previous chunk has finished).
+// FUSED: the whole output (out_size bytes) lives in LDS at `lds_out` (pre-zeroed
+// by the caller) and literals are written there directly; otherwise they go
+// through the LDS window to `gout`.  Returns (to every lane) 0 when the stream is
+// accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
+template <int WPS, bool FUSED>
+__device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
+                             uint32_t pay_len, uint32_t out_size, uint32_t *pay,
+                             const DecTables &tb, StreamShared *sh, uint8_t *lds_out,
+                             uint32_t *win, uint8_t *gout, uint32_t *stats) {
+  constexpr int kSubBits = WPS * 32;
+  constexpr int kChunkBits = kDecThreads * kSubBits;
+  const int tid = threadIdx.x;
+  const PayView<WPS> pv = {pay};
+  if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
+  __syncthreads();
+
+  const unsigned long long P1 = 8ull * pay_len;  // payload end, in bits from pay_off
+  unsigned long long cur = 0;                    // exact bit position of the next token
+  unsigned long long O0 = 0;                     // symbols produced so far
+  uint32_t st_chunks = 0, st_rounds = 0;
+  long long c_stage = 0, c_sync = 0, c_write = 0, c_t0 = clock64();
+
+  while (cur < P1 && O0 < out_size) {
+    const uint32_t rel0 = stage_chunk<WPS>(p, stream_size, 8ull * pay_off + cur, pay);
+    { const long long t = clock64(); c_stage += t - c_t0; c_t0 = t; ++st_chunks; }
+
+    const unsigned long long rem = P1 - cur;
+    const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kChunkBits ? rem : kChunkBits);
+    const uint32_t my_b0 = rel0 + tid * kSubBits;
+    uint32_t lim = rel0 + (tid + 1) * kSubBits;
+    if (lim > rel_end) lim = rel_end;
+
+    uint32_t start, endpos;
+    unsigned long long cnt;
+    fixpoint_chunk<WPS>(pv, tb, sh, rel0, my_b0, lim, rel_end, &start, &endpos, &cnt, &st_rounds);
+    { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
+
+    unsigned long long tot;
+    const unsigned long long off = block_scan_u64(cnt, sh->sm64, &tot);
+    const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
+
+    if (FUSED) {
+      uint32_t bp = start;
+      unsigned long long op = O0 + off;
+      bool done = !(bp < lim) || op >= out_size;
+      BitReader br;
+      if (!done) br.init(pv, bp);
+      while (!done) {
+        const Tok t = next_token(br, pv, tb);
+        if (t.count < 0 || t.nbits == 0) { sh->err = 1; break; }
+        if (t.sym < 256) {
+          if (t.sym) lds_out[op] = (uint8_t)t.sym;
+        } else if (op + (unsigned long long)t.count > out_size) {
+          sh->err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
+          break;
+        }
+        op += (unsigned long long)t.count;
+        bp += t.nbits;
+        if (op >= out_size) { sh->endbit = cur + (bp - rel0); done = true; }
+        else if (!(bp < lim)) done = true;
+      }
+      __syncthreads();
+    } else {
+      write_chunk_windows<WPS>(pv, tb, sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win,
+                               gout);
+    }
+    { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
+
+    // ---- advance to the next chunk ----
+    if (tid == kDecThreads - 1) sh->nxt[0] = endpos;
+    __syncthreads();
+    const uint32_t last_end = sh->nxt[0];
+    cur += (unsigned long long)(last_end - rel0);
+    O0 += tot;
+    if (last_end == rel0) break;  // no progress (cannot happen on a valid stream)
+    __syncthreads();
+  }
+  __syncthreads();
+
+  // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
+  int bad = sh->err;
+  if (O0 < out_size) bad = 1;  // ran out of payload before the block was full
+  const unsigned long long E = sh->endbit;
+  // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
+  if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+  if (tid == 0 && stats) {
+    stats[0] = st_chunks; stats[1] = st_rounds; stats[2] = 0;
+    stats[3] = (uint32_t)(c_stage >> 4); stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
+    stats[6] = pay_len; stats[7] = out_size;
+  }
+  return bad;
+}
+
+__device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
+                                                uint32_t *lut, short *ca, short *cb, short *sy) {
+  const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
+  const int nn = df->s[strm].num_nodes;
+  for (int k = threadIdx.x; k < nn; k += kDecThreads) {
+    ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
+  }
+  const uint32_t *gl = ws.lut + ((size_t)f * 2 + strm) * (1u << kLutBits);
+  for (int k = threadIdx.x; k < (1 << kLutBits); k += kDecThreads) lut[k] = gl[k];
+}
+
+// ---------------------------------------------------------------------------
+// k_dec_huff: generic stream decode to the symbol buffers in HBM.  Block 0 of a
+// frame is its LRES stream; blocks 1.. are FRES block rows (only launched for
+// rows that do not fit the fused kernel's LDS budget).
+// ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, const uint8_t *packed,
-                                                          size_t in_stride, const uint32_t *sizes) {
-  __shared__ uint32_t pay[kPayWords];
+                                                          size_t in_stride, const uint32_t *sizes,
+                                                          int first_block, int lres_fallback_only) {
+  __shared__ uint32_t pay[8 * (kDecThreads + 2)];
   __shared__ uint32_t win[kWinBytes / 4];
   __shared__ uint32_t lut[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
-  __shared__ uint32_t nxt[kDecThreads + 1];
-  __shared__ unsigned long long sm64[kDecThreads / 64];
-  __shared__ int s_flag;
-  __shared__ unsigned long long s_endbit;  // bit position right after the token that completes the output
-  __shared__ int s_err;
+  __shared__ StreamShared sh;
 
-  const int blk = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int blk = blockIdx.x + first_block, f = blockIdx.y;
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const int strm = blk == 0 ? 0 : 1;
+  if (strm == 0 && lres_fallback_only && ws.ver_ok[f]) return;  // parallel LRES path succeeded
   const uint8_t *p = packed + (size_t)f * in_stride;
-  const uint32_t stream_size = sizes[f];
-
   uint32_t pay_off, pay_len, out_size;
   uint8_t *out;
   if (strm == 0) {
@@ -327,149 +644,179 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
   }
-
-  {
-    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
-    const int nn = df->s[strm].num_nodes;
-    for (int k = tid; k < nn; k += kDecThreads) {
-      ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
-    }
-    const uint32_t *gl = ws.lut + ((size_t)f * 2 + strm) * (1u << kLutBits);
-    for (int k = tid; k < (1 << kLutBits); k += kDecThreads) lut[k] = gl[k];
-    if (tid == 0) { s_err = 0; s_endbit = ~0ull; }
-  }
+  load_dec_tables(ws, df, f, strm, lut, ca, cb, sy);
   __syncthreads();
+  DecTables tb;
+  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const int bad = decode_stream<8, false>(p, sizes[f], pay_off, pay_len, out_size, pay, tb, &sh,
+                                          nullptr, win, out,
+                                          ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
+  if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
+}
 
-  const unsigned long long P1 = 8ull * pay_len;  // payload end, in bits from pay_off
-  unsigned long long cur = 0;                    // exact bit position of the next token
-  unsigned long long O0 = 0;                     // symbols produced so far
+// ---------------------------------------------------------------------------
+// Parallel LRES decode.  The LRES payload is ONE Huffman stream (~1 M symbols at
+// 4096x4096), a long pole for a single workgroup.  All of its chunks are decoded
+// speculatively in parallel and the chain between chunks is then made exact:
+//   k_lres_spec    chunk k assumes its first token starts at its nominal first
+//                  bit and runs the in-chunk fixpoint; stores every lane's start,
+//                  end and symbol count, the chunk's end position and total.
+//   k_lres_fix     chunk k (k >= 1) restarts its fixpoint WARM with lane 0 at
+//                  T_k = spec end of chunk k-1; only lanes whose start changes
+//                  decode again (a handful unless the data does not
+//                  self-synchronise).  Stores the corrected chain, end and total.
+//   k_lres_verify  chunk 0 is exact, so T_1 and hence chunk 1's corrected chain are
+//                  exact; T_2 was taken from chunk 1's SPECULATIVE end, which is
+//                  right iff the correction left that end unchanged -- and so on.
+//                  All ends unchanged => every chunk exact (induction).  Output
+//                  offsets = scan of the corrected totals.
+//   k_lres_write   chunk k writes its symbols from the corrected lane starts.
+// If an end did change (a mis-speculation ran through a whole 32 KiB chunk) the
+// frame falls back to the serial workgroup-per-stream path (k_dec_huff).
+// ---------------------------------------------------------------------------
+constexpr int kLresWps = 8;
+constexpr int kLresChunkBits = kDecThreads * kLresWps * 32;
 
-  while (cur < P1 && O0 < out_size) {
-    // ---- stage this chunk's payload bytes in LDS (zero beyond the stream) ----
-    // Word j of pay[] holds stream bytes [gb + 4j, gb + 4j + 4).
-    const unsigned long long abs_bit = 8ull * pay_off + cur;
-    const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;         // dword aligned byte offset
-    const uint32_t rel0 = (uint32_t)(abs_bit - 8ull * gb);     // bit of `cur` inside pay[]
-    for (int j = tid; j < kPayWords; j += kDecThreads) {
-      const uint32_t b = gb + 4u * j;
-      uint32_t w = 0;
-      if (b + 4 <= stream_size) {
-        w = *reinterpret_cast<const uint32_t *>(p + b);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (b + k < stream_size) w |= (uint32_t)p[b + k] << (8 * k);
-      }
-      pay[j] = w;
-    }
-    __syncthreads();
-
-    // Limits in staged-bit coordinates.
-    const unsigned long long rem = P1 - cur;  // payload bits left from cur
-    const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kChunkBits ? rem : kChunkBits);
-    const uint32_t my_b0 = rel0 + tid * kSubBits;
-    uint32_t lim = rel0 + (tid + 1) * kSubBits;
-    if (lim > rel_end) lim = rel_end;
-
-    // ---- speculative decode to the self-synchronised fixpoint ----
-    uint32_t start = my_b0 < rel_end ? my_b0 : rel_end;
-    uint32_t endpos = start;
-    unsigned long long cnt = 0;
-    bool dirty = true;
-    for (;;) {
-      if (dirty) {
-        uint32_t pos = start;
-        unsigned long long c = 0;
-        while (pos < lim) {
-          const Tok t = decode_token(pay, pos, lut, ca, cb, sy);
-          pos += t.nbits ? t.nbits : 1;
-          c += (unsigned long long)(t.count > 0 ? t.count : 0);
-        }
-        endpos = pos;
-        cnt = c;
-      }
-      nxt[tid + 1] = endpos;
-      if (tid == 0) s_flag = 0;
-      __syncthreads();
-      const uint32_t ns = tid == 0 ? rel0 : nxt[tid];
-      dirty = (ns != start);
-      start = ns;
-      if (dirty) s_flag = 1;
-      __syncthreads();
-      const int any = s_flag;
-      __syncthreads();
-      if (!any) break;
-    }
-    // Here: thread t decodes exactly the tokens that START in [start, lim) and
-    // the chain is exact from the chunk's first token on.
-    unsigned long long tot;
-    const unsigned long long off = block_scan_u64(cnt, sm64, &tot);
-    const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
-
-    // ---- produce symbols window by window (zero runs are the window's fill) ----
-    uint32_t bp = start;
-    unsigned long long op = O0 + off;
-    bool done = !(bp < lim) || op >= out_size;
-    for (unsigned long long wb = (O0 / kWinBytes) * kWinBytes; wb < O1; wb += kWinBytes) {
-      for (int k = tid; k < kWinBytes / 4; k += kDecThreads) win[k] = 0;
-      __syncthreads();
-      const unsigned long long we = wb + kWinBytes;
-      while (!done && op < we) {
-        const Tok t = decode_token(pay, bp, lut, ca, cb, sy);
-        if (t.count < 0 || t.nbits == 0) { s_err = 1; done = true; break; }
-        if (t.sym < 256) {
-          if (t.sym) {
-            const uint32_t o = (uint32_t)(op - wb);
-            atomicOr(&win[o >> 2], (uint32_t)t.sym << ((o & 3) * 8));
-          }
-        } else if (op + (unsigned long long)t.count > out_size) {
-          s_err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
-          done = true;
-          break;
-        }
-        op += (unsigned long long)t.count;
-        bp += t.nbits;
-        if (op >= out_size) { s_endbit = cur + (bp - rel0); done = true; }
-        else if (!(bp < lim)) done = true;
-      }
-      __syncthreads();
-      // Flush [max(wb, O0), min(we, O1)) to the symbol buffer.
-      const unsigned long long lo = wb > O0 ? wb : O0, hi = we < O1 ? we : O1;
-      const uint32_t l = (uint32_t)(lo - wb), h = (uint32_t)(hi - wb);
-      const uint32_t la = (l + 15u) & ~15u, ha = h & ~15u;
-      if (la <= ha && (((uintptr_t)(out + wb)) & 15) == 0) {
-        for (uint32_t k = l + tid; k < la; k += kDecThreads) out[wb + k] = (uint8_t)(win[k >> 2] >> ((k & 3) * 8));
-        for (uint32_t k = la / 16 + tid; k < ha / 16; k += kDecThreads) {
-          uint4 q;
-          q.x = win[4 * k]; q.y = win[4 * k + 1]; q.z = win[4 * k + 2]; q.w = win[4 * k + 3];
-          *reinterpret_cast<uint4 *>(out + wb + 16ull * k) = q;
-        }
-        for (uint32_t k = ha + tid; k < h; k += kDecThreads) out[wb + k] = (uint8_t)(win[k >> 2] >> ((k & 3) * 8));
-      } else {
-        for (uint32_t k = l + tid; k < h; k += kDecThreads) out[wb + k] = (uint8_t)(win[k >> 2] >> ((k & 3) * 8));
-      }
-      __syncthreads();
-    }
-
-    // ---- advance to the next chunk ----
-    if (tid == kDecThreads - 1) nxt[0] = endpos;
-    __syncthreads();
-    const uint32_t last_end = nxt[0];
-    cur += (unsigned long long)(last_end - rel0);
-    O0 += tot;
-    if (last_end == rel0) break;  // no progress (cannot happen on a valid stream)
-    __syncthreads();
+template <bool FIX>
+__global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, const uint8_t *packed,
+                                                            size_t in_stride, const uint32_t *sizes) {
+  __shared__ uint32_t pay[kLresWps * (kDecThreads + 2)];
+  __shared__ uint32_t lut[1 << kLutBits];
+  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ StreamShared sh;
+  const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  const uint32_t pay_off = df->s[0].payload_off;
+  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
+  const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
+  const size_t slot = (size_t)f * ws.lres_chunks + k;
+  uint64_t *end_out = FIX ? ws.fix_end : ws.spec_end;
+  if (cur >= P1) {
+    if (tid == 0) { end_out[slot] = cur; ws.spec_tot[slot] = 0; }
+    return;
   }
-  __syncthreads();
-
-  // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
+  if (FIX && k == 0) {  // chunk 0 is exact already
+    if (tid == 0) ws.fix_end[slot] = ws.spec_end[slot];
+    return;
+  }
+  load_dec_tables(ws, df, f, 0, lut, ca, cb, sy);
+  DecTables tb;
+  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const PayView<kLresWps> pv = {pay};
+  const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
+                                              8ull * pay_off + cur, pay);
+  const unsigned long long rem = P1 - cur;
+  const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
+  const uint32_t my_b0 = rel0 + tid * (kLresWps * 32);
+  uint32_t lim = rel0 + (tid + 1) * (kLresWps * 32);
+  if (lim > rel_end) lim = rel_end;
+  uint32_t start = 0, endpos = 0, rounds = 0, first = rel0;
+  unsigned long long cnt = 0, tot;
+  if (FIX) {
+    const unsigned long long T = ws.spec_end[slot - 1];
+    // A token is at most 46 bits, so the true first token lies in lane 0's range.
+    if (T < cur || T >= cur + kLresWps * 32) {
+      if (tid == 0) ws.fix_end[slot] = ~0ull;  // forces the serial path
+      return;
+    }
+    first = rel0 + (uint32_t)(T - cur);
+    start = rel0 + ws.spec_start[slot * kDecThreads + tid];
+    endpos = rel0 + ws.spec_endpos[slot * kDecThreads + tid];
+    cnt = ws.spec_cnt[slot * kDecThreads + tid];
+  }
+  fixpoint_chunk<kLresWps>(pv, tb, &sh, first, my_b0, lim, rel_end, &start, &endpos, &cnt, &rounds,
+                           FIX);
+  block_scan_u64(cnt, sh.sm64, &tot);
+  ws.spec_start[slot * kDecThreads + tid] = start - rel0;
+  ws.spec_endpos[slot * kDecThreads + tid] = endpos - rel0;
+  ws.spec_cnt[slot * kDecThreads + tid] = (uint32_t)(cnt < 0xffffffffull ? cnt : 0xffffffffull);
+  if (tid == kDecThreads - 1) { end_out[slot] = cur + (endpos - rel0); ws.spec_tot[slot] = tot; }
   if (tid == 0) {
-    int bad = s_err;
-    if (O0 < out_size) bad = 1;                 // ran out of payload before the block was full
-    const unsigned long long E = s_endbit;      // bits consumed when the block became full
-    // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
-    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
-    if (bad) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
+    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1)) * 8;
+    atomicAdd(&st[FIX ? 2 : 0], 1u);
+    atomicAdd(&st[FIX ? 3 : 1], rounds);
   }
+}
+
+__global__ __launch_bounds__(kDecThreads) void k_lres_verify(Geom g, DecWs ws) {
+  __shared__ unsigned long long sm64[kDecThreads / 64];
+  __shared__ int s_bad;
+  const int f = blockIdx.x, k = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  if (k == 0) { ws.ver_ok[f] = 0; ws.lres_endbit[f] = ~0ull; s_bad = 0; }
+  if (df->status) return;
+  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - df->s[0].payload_off);
+  const int nact = (int)((P1 + kLresChunkBits - 1) / kLresChunkBits);
+  __syncthreads();
+  if (nact > ws.lres_chunks || nact > kDecThreads) return;  // ver_ok stays 0 -> serial path
+  const size_t slot = (size_t)f * ws.lres_chunks + k;
+  unsigned long long ntot = 0;
+  if (k < nact) {
+    ntot = ws.spec_tot[slot];
+    // The next chunk was corrected against spec_end[k]; that is the true end of
+    // chunk k iff the correction of chunk k did not move it.
+    if (k + 1 < nact && ws.fix_end[slot] != ws.spec_end[slot]) s_bad = 1;
+  }
+  unsigned long long tot;
+  const unsigned long long base = block_scan_u64(ntot, sm64, &tot);
+  if (k < nact) ws.ver_base[slot] = base;
+  __syncthreads();
+  if (k == 0) ws.ver_ok[f] = s_bad ? 0 : 1;
+}
+
+__global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, const uint8_t *packed,
+                                                            size_t in_stride, const uint32_t *sizes) {
+  __shared__ uint32_t pay[kLresWps * (kDecThreads + 2)];
+  __shared__ uint32_t win[kWinBytes / 4];
+  __shared__ uint32_t lut[1 << kLutBits];
+  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ StreamShared sh;
+  const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  if (df->status || !ws.ver_ok[f]) return;
+  const uint32_t pay_off = df->s[0].payload_off;
+  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
+  const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
+  if (cur >= P1) return;
+  const uint32_t out_size = (uint32_t)g.lres_size;
+  const size_t slot = (size_t)f * ws.lres_chunks + k;
+  const unsigned long long O0 = ws.ver_base[slot];
+  if (O0 >= out_size) return;
+  load_dec_tables(ws, df, f, 0, lut, ca, cb, sy);
+  if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
+  DecTables tb;
+  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const PayView<kLresWps> pv = {pay};
+  const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
+                                              8ull * pay_off + cur, pay);
+  const unsigned long long rem = P1 - cur;
+  const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
+  uint32_t lim = rel0 + (tid + 1) * (kLresWps * 32);
+  if (lim > rel_end) lim = rel_end;
+  const uint32_t start = rel0 + ws.spec_start[slot * kDecThreads + tid];
+  const unsigned long long cnt = ws.spec_cnt[slot * kDecThreads + tid];
+  unsigned long long tot;
+  const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
+  const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
+  write_chunk_windows<kLresWps>(pv, tb, &sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win,
+                                ws.lres_sym + (size_t)f * ws.lres_stride);
+  __syncthreads();
+  if (tid == 0) {
+    if (sh.err) atomicMax(&df->status, fmt_err(4, 1));
+    if (sh.endbit != ~0ull) ws.lres_endbit[f] = sh.endbit;
+  }
+}
+
+// Accept / reject the LRES stream like UncompressStream (huffman_dec.cpp:361-417).
+__global__ void k_lres_finish(DecWs ws, int batch) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= batch) return;
+  DecFrame *df = ws.frames + f;
+  if (df->status || !ws.ver_ok[f]) return;  // failed earlier, or handled by the serial path
+  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - df->s[0].payload_off);
+  const unsigned long long E = ws.lres_endbit[f];
+  if (!(E != ~0ull && E <= P1 && E + 8 > P1 && E > 0)) atomicMax(&df->status, fmt_err(4, 1));
 }
 
 // ---------------------------------------------------------------------------
@@ -650,6 +997,168 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_dec_row_fused: one 1024-lane workgroup per FRES block row, when the row's
+// symbols fit in LDS (row_block <= ~128 KiB, i.e. width <= 4096 for RGBA).
+//   1. entropy-decode the row into LDS (decode_stream<FUSED>);
+//   2. lane = tile: gather, dequantise, inverse WHT, + low-res, clamp; results
+//      overwrite the tile's own 64 symbol slots per channel (in place);
+//   3. lane = (tile, pixel row): colour inverse and two 16-byte stores, so a wave
+//      writes 2 KiB of contiguous pixels per pixel row.
+// The symbols never touch HBM: traffic is the packed row in, the pixels out.
+// ---------------------------------------------------------------------------
+struct FusedLayout {
+  uint32_t sym, pay, lut, ca, cb, sy, sh, unmap, shift, total;
+};
+__host__ __device__ inline FusedLayout fused_layout(int row_block, int wps) {
+  FusedLayout L;
+  uint32_t o = 0;
+  auto carve = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
+  L.sym = carve((uint32_t)row_block);
+  L.pay = carve((uint32_t)wps * (kDecThreads + 2) * 4u);
+  L.lut = carve((1u << kLutBits) * 4u);
+  L.ca = carve((kMaxNodes + 1) * 2u);
+  L.cb = carve((kMaxNodes + 1) * 2u);
+  L.sy = carve((kMaxNodes + 1) * 2u);
+  L.sh = carve((uint32_t)sizeof(StreamShared));
+  L.unmap = carve(512u);
+  L.shift = carve(128u);
+  L.total = o;
+  return L;
+}
+
+template <int WPS>
+__global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
+                                                               const uint8_t *packed,
+                                                               size_t in_stride,
+                                                               const uint32_t *sizes,
+                                                               uint8_t *out_frames) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const FusedLayout L = fused_layout(g.row_block, WPS);
+  uint8_t *sym = smem + L.sym;
+  uint32_t *pay = reinterpret_cast<uint32_t *>(smem + L.pay);
+  uint32_t *lut = reinterpret_cast<uint32_t *>(smem + L.lut);
+  short *ca = reinterpret_cast<short *>(smem + L.ca);
+  short *cb = reinterpret_cast<short *>(smem + L.cb);
+  short *sy = reinterpret_cast<short *>(smem + L.sy);
+  StreamShared *sh = reinterpret_cast<StreamShared *>(smem + L.sh);
+  int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
+  uint8_t *s_shift = smem + L.shift;
+
+  const int r = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  load_dec_tables(ws, df, f, 1, lut, ca, cb, sy);
+  if (tid < 256) {
+    const int sc = (int8_t)tid;
+    s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
+  } else if (tid < 384) {
+    s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
+  }
+  {
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0;
+    const int n16 = (g.row_block + 15) >> 4;
+    for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym)[k] = z;
+  }
+  __syncthreads();
+
+  DecTables tb;
+  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const int bad = decode_stream<WPS, true>(
+      p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
+      (uint32_t)g.row_block, pay, tb, sh, sym, nullptr, nullptr,
+      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8);
+  if (bad) {
+    if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
+    return;
+  }
+
+  const int ycbcr = df->ycbcr;
+  const int cols = g.cols, v = r;
+  const int v2 = min(v + 1, g.rows - 1);
+  // ---- phase 2: per-tile inverse transform, in place ----
+  for (int u = tid; u < cols; u += kDecThreads) {
+    const int u2 = min(u + 1, cols - 1);
+    for (int c = 0; c < g.C; ++c) {
+      const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * cols;
+      const bool chroma = ycbcr && (c == 1 || c == 2);  // decoder.cpp:376
+      const uint8_t *shift = s_shift + (chroma ? 64 : 0);
+      uint8_t *slot = sym + (size_t)c * 64 * cols + u;
+      int b[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int pos = kScanD[i];
+        const int code = slot[(size_t)i * cols];
+        b[pos] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));  // quantize.cpp:153-165
+      }
+#pragma unroll
+      for (int y = 0; y < 8; ++y)
+        iwht8(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
+              b[y * 8 + 6], b[y * 8 + 7]);
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+        iwht8(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
+      int left[9], right[9];
+      left[0] = m[(size_t)v * cols + u];   left[8] = m[(size_t)v2 * cols + u];
+      right[0] = m[(size_t)v * cols + u2]; right[8] = m[(size_t)v2 * cols + u2];
+      interp9d(left);
+      interp9d(right);
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        int a[9];
+        a[0] = left[y]; a[8] = right[y];
+        interp9d(a);
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          slot[(size_t)(y * 8 + x) * cols] = (uint8_t)clamp255d((int)(int16_t)(b[y * 8 + x] + a[x]));
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: colour inverse + coalesced stores ----
+  uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
+  const int bh = min(8, g.H - 8 * v);
+  const int items = cols * 8;
+  for (int it = tid; it < items; it += kDecThreads) {
+    const int y = it / cols, u = it - y * cols;
+    if (y >= bh) continue;
+    const int bw = min(8, g.W - 8 * u);
+    uint32_t px[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      uint32_t w = 0;
+      for (int c = 0; c < g.C; ++c)
+        w |= (uint32_t)sym[((size_t)c * 64 + y * 8 + x) * cols + u] << (8 * c);
+      if (ycbcr) {  // ycbcr.cpp:54-82
+        const int yy = w & 255;
+        const int cbv = (int)((w >> 8) & 255) * 2 - 255;
+        const int crv = (int)((w >> 16) & 255) * 2 - 255;
+        const int gg = yy - ((cbv + crv + 2) >> 2);
+        const int bb = gg + cbv, rr = gg + crv;
+        w = (w & 0xff000000u) | (uint32_t)clamp255d(rr) | ((uint32_t)clamp255d(gg) << 8) |
+            ((uint32_t)clamp255d(bb) << 16);
+      }
+      px[x] = w;
+    }
+    uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * g.C;
+    if (g.C == 4 && bw == 8) {
+      uint4 q0, q1;
+      q0.x = px[0]; q0.y = px[1]; q0.z = px[2]; q0.w = px[3];
+      q1.x = px[4]; q1.y = px[5]; q1.z = px[6]; q1.w = px[7];
+      reinterpret_cast<uint4 *>(dst)[0] = q0;
+      reinterpret_cast<uint4 *>(dst)[1] = q1;
+    } else {
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+        if (x < bw)
+          for (int c = 0; c < g.C; ++c) dst[x * g.C + c] = (uint8_t)(px[x] >> (8 * c));
+    }
+  }
+}
+
 // k_dec_status: copy the per-frame verdict out of the workspace.
 __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -665,13 +1174,49 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
-                   int32_t *d_status, hipStream_t stream, Profiler *prof) {
+                   int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused) {
   const unsigned gx = (unsigned)((g.cols + 255) / 256);
+  // Fused row kernel when the row's symbols + staging fit the 160 KiB LDS.
+  constexpr uint32_t kLdsMax = 160u * 1024u;
+  const int wps = !allow_fused                                    ? 0
+                  : fused_layout(g.row_block, 8).total <= kLdsMax ? 8
+                  : fused_layout(g.row_block, 4).total <= kLdsMax ? 4
+                                                                  : 0;
   HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
-  HIMG_LAUNCH(k_dec_huff, dim3(g.rows + 1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-              d_sizes);
-  HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
-  HIMG_LAUNCH(k_tile_inv, dim3(gx, g.rows, batch), dim3(256), g, ws, d_out);
+  // LRES: every chunk in parallel, chain verified, serial fallback if not.
+  (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
+  HIMG_LAUNCH(k_lres_chain<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+              d_packed, in_stride, d_sizes);
+  HIMG_LAUNCH(k_lres_chain<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+              d_packed, in_stride, d_sizes);
+  HIMG_LAUNCH(k_lres_verify, dim3(batch), dim3(kDecThreads), g, ws);
+  HIMG_LAUNCH(k_lres_write, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws, d_packed,
+              in_stride, d_sizes);
+  HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);
+  if (wps) {
+    HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
+                d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
+    HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
+    const uint32_t lds = fused_layout(g.row_block, wps).total;
+    prof_begin(prof, "k_dec_row_fused", stream);
+    if (wps == 8) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_dec_row_fused<8>, dim3(g.rows, batch), dim3(kDecThreads), lds, stream, g,
+                         ws, d_packed, in_stride, d_sizes, d_out);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_dec_row_fused<4>, dim3(g.rows, batch), dim3(kDecThreads), lds, stream, g,
+                         ws, d_packed, in_stride, d_sizes, d_out);
+    }
+    prof_end(prof, stream);
+  } else {
+    HIMG_LAUNCH(k_dec_huff, dim3(g.rows + 1, batch), dim3(kDecThreads), g, ws, d_packed,
+                in_stride, d_sizes, 0, 1);
+    HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
+    HIMG_LAUNCH(k_tile_inv, dim3(gx, g.rows, batch), dim3(256), g, ws, d_out);
+  }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
 }
 

@@ -45,17 +45,42 @@ def test_encode_stages_match_oracle(engine, kind, seed, w, h, q):
     _eq(packed_g, packed_o, "stream")
 
 
+@pytest.fixture(scope="module")
+def unfused_engine():
+    """Context that routes block rows through the generic decode path (symbols via
+    HBM) -- the path rows wider than the fused kernel's LDS budget always take."""
+    import os
+    os.environ["HIMG_FORCE_UNFUSED"] = "1"
+    try:
+        eng = himg_amd.Engine(0)
+    finally:
+        del os.environ["HIMG_FORCE_UNFUSED"]
+    yield eng
+    eng.close()
+
+
 @pytest.mark.parametrize("kind,seed,w,h,q", STAGE_CASES[:6])
-def test_decode_stages_match_oracle(engine, kind, seed, w, h, q):
+def test_decode_stages_match_oracle(engine, unfused_engine, kind, seed, w, h, q):
     img = himg_amd.synth(kind, seed, w, h)
     packed = ol.oracle_encode(img, q, True)
     rc, dt = ol.oracle_decode_trace(packed)
     assert rc == 0
-    pix = engine.decode(packed)
+    pix = engine.decode(packed)   # fused path: symbols stay in LDS
     _eq(engine.debug_read("lres_sym", 0, dt["lres_sym"].size, decoder=True), dt["lres_sym"], "LRES symbols")
     _eq(engine.debug_read("lowres", 0, dt["lowres"].size, decoder=True), dt["lowres"], "low-res plane")
-    _eq(engine.debug_read("fres_sym", 0, dt["fres_sym"].size, decoder=True), dt["fres_sym"], "FRES symbols")
-    _eq(pix, dt["pixels"], "pixels")
+    _eq(pix, dt["pixels"], "pixels (fused)")
+    pix2 = unfused_engine.decode(packed)
+    _eq(unfused_engine.debug_read("fres_sym", 0, dt["fres_sym"].size, decoder=True), dt["fres_sym"], "FRES symbols")
+    _eq(pix2, dt["pixels"], "pixels (generic)")
+
+
+def test_generic_decode_path_large(unfused_engine):
+    rec = GOLDEN["randtile_s0_1920x1080_q50"]
+    packed = unfused_engine.encode(make_input(rec), 50, True)
+    assert himg_amd.fnv1a64(unfused_engine.decode(packed)) == rec["decoded_fnv"]
+    rec = GOLDEN["rand_s0_2048x2048_q50"]
+    packed = unfused_engine.encode(make_input(rec), 50, True)
+    assert himg_amd.fnv1a64(unfused_engine.decode(packed)) == rec["decoded_fnv"]
 
 
 @pytest.mark.parametrize("name", cases(max_pixels=4096 * 4096))

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Print k_dec_huff diagnostics for one 4096x4096 frame (GPU box)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import himg_amd
+w = h = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+eng = himg_amd.Engine(0)
+img = himg_amd.synth("randtile", 0, w, h)
+packed = eng.encode(img, 50)
+eng.decode(packed)
+rows = h // 8
+st = eng.debug_read("dec_stats", 0, (rows + 1) * 32, np.uint32, decoder=True).reshape(rows + 1, 8)
+names = ["chunks", "rounds", "fix_chunks(lres)", "fix_rounds(lres)|clk_stage/16", "clk_sync/16", "clk_write/16", "pay_len", "out_size"]
+print("LRES:", dict(zip(names, st[0].tolist())))
+fr = st[1:].astype(np.float64)
+for i, n in enumerate(names):
+    print("FRES %-14s mean %.1f min %.0f max %.0f" % (n, fr[:, i].mean(), fr[:, i].min(), fr[:, i].max()))

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect rocprofv3 PMC counters for the bench workload, one counter group per
+# run (MI355X_MICROARCH.md: 8 SQ slots, FETCH_SIZE and WRITE_SIZE in separate
+# passes; never combined with trace domains other than kernel-trace).
+# Usage (on the GPU box, from the repo root): tools/profile_pmc.sh <outdir> [bench args...]
+set -u
+OUT=${1:-gpurun_out/pmc}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$ROOT/$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() {
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- \
+      python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} \
+      > "$ROOT/$OUT/$name.log" 2>&1
+  echo "$name exit=$?"
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAIT_INST_LDS
+run fetch FETCH_SIZE GRBM_GUI_ACTIVE
+run write WRITE_SIZE
+python3 "$ROOT/tools/summarize_pmc.py" "$ROOT/$OUT" > "$ROOT/$OUT/summary.txt" 2>&1
+tail -n 60 "$ROOT/$OUT/summary.txt"
