@@ -15,6 +15,8 @@
 //                     hadamard.cpp:90-103, ycbcr.cpp:54-82)
 #include "himg_dev.h"
 
+#include <type_traits>
+
 namespace himg_dev {
 
 __device__ static constexpr uint8_t kScanD[64] = {
@@ -264,23 +266,36 @@ struct PayView {
   }
 };
 
-// Plain (untransposed) view: word j at w[j].
-struct LinearView {
-  const uint32_t *w;
-  __device__ __forceinline__ uint32_t ld(uint32_t j) const { return w[j]; }
+// Payload read straight from global memory (L2): word j of the dword-aligned
+// window that starts at stream byte `gb`.  Bytes beyond the stream read as zero.
+struct GlobalView {
+  const uint8_t *p;       // stream base (4-byte aligned)
+  uint32_t gb;            // window start, multiple of 4
+  uint32_t stream_size;
+  __device__ __forceinline__ uint32_t ld(uint32_t j) const {
+    const uint32_t b = gb + 4u * j;
+    if (b + 4 <= stream_size) return *reinterpret_cast<const uint32_t *>(p + b);
+    uint32_t w = 0;
+    for (int k = 0; k < 4; ++k)
+      if (b + k < stream_size) w |= (uint32_t)p[b + k] << (8 * k);
+    return w;
+  }
 };
 
-// 64-bit bit window over a payload view.
+// 64-bit bit window over a payload view, with the next word prefetched so that
+// a refill never waits on the load it issues.
 struct BitReader {
   unsigned long long win;
   int nb;         // valid bits in win
-  uint32_t next;  // next staged word to load
+  uint32_t next;  // index of the word held in `pre`
+  uint32_t pre;   // prefetched word `next`
   template <class PV>
   __device__ __forceinline__ void init(const PV &pv, uint32_t pos) {
     const uint32_t j = pos >> 5, sh = pos & 31;
     win = (((unsigned long long)pv.ld(j + 1) << 32) | pv.ld(j)) >> sh;
     nb = 64 - (int)sh;
     next = j + 2;
+    pre = pv.ld(next);
   }
   __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
 };
@@ -299,12 +314,12 @@ struct Tok { int sym; int nbits; int count; };
 // when some lane of the wave needs it.
 template <class PV>
 __device__ __forceinline__ void refill_bf(BitReader &br, const PV &pv) {
-  const uint32_t w = pv.ld(br.next);
-  const bool need = br.nb <= 32;
-  const unsigned long long add = (unsigned long long)w << (br.nb & 63);
-  br.win |= need ? add : 0ull;
-  br.nb += need ? 32 : 0;
-  br.next += need ? 1u : 0u;
+  if (br.nb <= 32) {
+    br.win |= (unsigned long long)br.pre << br.nb;
+    br.nb += 32;
+    ++br.next;
+    br.pre = pv.ld(br.next);
+  }
 }
 
 template <class PV>
@@ -395,8 +410,8 @@ __device__ __forceinline__ uint32_t stage_chunk(const uint8_t *p, uint32_t strea
 // Speculative decode of one chunk to the self-synchronised fixpoint.  On return
 // lane t owns exactly the tokens that START in [start, lim) -- relative to lane
 // 0's start `first`, which the caller asserts (exact) or assumes (speculative).
-template <int WPS>
-__device__ __forceinline__ void fixpoint_chunk(const PayView<WPS> &pv, const DecTables &tb,
+template <class PV>
+__device__ __forceinline__ void fixpoint_chunk(const PV &pv, const DecTables &tb,
                                                StreamShared *sh, uint32_t first, uint32_t my_b0,
                                                uint32_t lim, uint32_t rel_end, uint32_t *start_io,
                                                uint32_t *endpos_io, unsigned long long *cnt_io,
@@ -432,17 +447,12 @@ __device__ __forceinline__ void fixpoint_chunk(const PayView<WPS> &pv, const Dec
       cnt = c;
     }
     sh->nxt[tid + 1] = endpos;
-    if (tid == 0) sh->flag = 0;
     __syncthreads();
     const uint32_t ns = tid == 0 ? first : sh->nxt[tid];
     dirty = (ns != start);
     start = ns;
-    if (dirty) sh->flag = 1;
-    __syncthreads();
-    const int any = sh->flag;
-    __syncthreads();
     ++*rounds;
-    if (!any) break;
+    if (!__syncthreads_or(dirty ? 1 : 0)) break;
   }
   *start_io = start;
   *endpos_io = endpos;
@@ -452,8 +462,8 @@ __device__ __forceinline__ void fixpoint_chunk(const PayView<WPS> &pv, const Dec
 // Write the symbols of one chunk through 32 KiB LDS windows (zero runs are the
 // window's zero fill; windows are flushed with 16-byte stores).  Lane t decodes
 // the tokens starting in [bp, lim) and places them from output offset `op`.
-template <int WPS>
-__device__ __forceinline__ void write_chunk_windows(const PayView<WPS> &pv, const DecTables &tb,
+template <class PV>
+__device__ __forceinline__ void write_chunk_windows(const PV &pv, const DecTables &tb,
                                                     StreamShared *sh, uint32_t bp, uint32_t lim,
                                                     unsigned long long op, unsigned long long O0,
                                                     unsigned long long O1, uint32_t out_size,
@@ -504,13 +514,33 @@ __device__ __forceinline__ void write_chunk_windows(const PayView<WPS> &pv, cons
   }
 }
 
+// Payload view of the chunk that starts at absolute stream bit `abs_bit`: either
+// staged in LDS (transposed) or read in place from global memory.
+template <int WPS>
+__device__ __forceinline__ void make_view(const uint8_t *p, uint32_t stream_size,
+                                          unsigned long long abs_bit, uint32_t *pay,
+                                          PayView<WPS> *pv, uint32_t *rel0) {
+  pv->pay = pay;
+  *rel0 = stage_chunk<WPS>(p, stream_size, abs_bit, pay);
+}
+template <int WPS>
+__device__ __forceinline__ void make_view(const uint8_t *p, uint32_t stream_size,
+                                          unsigned long long abs_bit, uint32_t *pay,
+                                          GlobalView *pv, uint32_t *rel0) {
+  (void)pay;
+  pv->p = p;
+  pv->gb = (uint32_t)(abs_bit >> 5) * 4u;
+  pv->stream_size = stream_size;
+  *rel0 = (uint32_t)(abs_bit - 8ull * pv->gb);
+}
+
 // Decode one whole stream with one workgroup, chunk after chunk (each chunk's
 // first token position is exact because the previous chunk has finished).
 // FUSED: the whole output (out_size bytes) lives in LDS at `lds_out` (pre-zeroed
 // by the caller) and literals are written there directly; otherwise they go
 // through the LDS window to `gout`.  Returns (to every lane) 0 when the stream is
 // accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
-template <int WPS, bool FUSED>
+template <int WPS, bool FUSED, bool USE_GLOBAL>
 __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
                              uint32_t pay_len, uint32_t out_size, uint32_t *pay,
                              const DecTables &tb, StreamShared *sh, uint8_t *lds_out,
@@ -518,7 +548,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   constexpr int kSubBits = WPS * 32;
   constexpr int kChunkBits = kDecThreads * kSubBits;
   const int tid = threadIdx.x;
-  const PayView<WPS> pv = {pay};
+  typedef typename std::conditional<USE_GLOBAL, GlobalView, PayView<WPS> >::type PV;
   if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
   __syncthreads();
 
@@ -529,7 +559,9 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   long long c_stage = 0, c_sync = 0, c_write = 0, c_t0 = clock64();
 
   while (cur < P1 && O0 < out_size) {
-    const uint32_t rel0 = stage_chunk<WPS>(p, stream_size, 8ull * pay_off + cur, pay);
+    PV pv;
+    uint32_t rel0;
+    make_view<WPS>(p, stream_size, 8ull * pay_off + cur, pay, &pv, &rel0);
     { const long long t = clock64(); c_stage += t - c_t0; c_t0 = t; ++st_chunks; }
 
     const unsigned long long rem = P1 - cur;
@@ -540,7 +572,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
 
     uint32_t start, endpos;
     unsigned long long cnt;
-    fixpoint_chunk<WPS>(pv, tb, sh, rel0, my_b0, lim, rel_end, &start, &endpos, &cnt, &st_rounds);
+    fixpoint_chunk(pv, tb, sh, rel0, my_b0, lim, rel_end, &start, &endpos, &cnt, &st_rounds);
     { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
 
     unsigned long long tot;
@@ -569,8 +601,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
       }
       __syncthreads();
     } else {
-      write_chunk_windows<WPS>(pv, tb, sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win,
-                               gout);
+      write_chunk_windows(pv, tb, sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win, gout);
     }
     { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
 
@@ -648,7 +679,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   __syncthreads();
   DecTables tb;
   tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const int bad = decode_stream<8, false>(p, sizes[f], pay_off, pay_len, out_size, pay, tb, &sh,
+  const int bad = decode_stream<8, false, false>(p, sizes[f], pay_off, pay_len, out_size, pay, tb, &sh,
                                           nullptr, win, out,
                                           ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
   if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
@@ -725,7 +756,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     endpos = rel0 + ws.spec_endpos[slot * kDecThreads + tid];
     cnt = ws.spec_cnt[slot * kDecThreads + tid];
   }
-  fixpoint_chunk<kLresWps>(pv, tb, &sh, first, my_b0, lim, rel_end, &start, &endpos, &cnt, &rounds,
+  fixpoint_chunk(pv, tb, &sh, first, my_b0, lim, rel_end, &start, &endpos, &cnt, &rounds,
                            FIX);
   block_scan_u64(cnt, sh.sm64, &tot);
   ws.spec_start[slot * kDecThreads + tid] = start - rel0;
@@ -799,7 +830,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   unsigned long long tot;
   const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
   const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
-  write_chunk_windows<kLresWps>(pv, tb, &sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win,
+  write_chunk_windows(pv, tb, &sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win,
                                 ws.lres_sym + (size_t)f * ws.lres_stride);
   __syncthreads();
   if (tid == 0) {
@@ -1010,12 +1041,12 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 struct FusedLayout {
   uint32_t sym, pay, lut, ca, cb, sy, sh, unmap, shift, total;
 };
-__host__ __device__ inline FusedLayout fused_layout(int row_block, int wps) {
+__host__ __device__ inline FusedLayout fused_layout(int row_block, int wps, bool stage_payload) {
   FusedLayout L;
   uint32_t o = 0;
   auto carve = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   L.sym = carve((uint32_t)row_block);
-  L.pay = carve((uint32_t)wps * (kDecThreads + 2) * 4u);
+  L.pay = carve(stage_payload ? (uint32_t)wps * (kDecThreads + 2) * 4u : 0u);
   L.lut = carve((1u << kLutBits) * 4u);
   L.ca = carve((kMaxNodes + 1) * 2u);
   L.cb = carve((kMaxNodes + 1) * 2u);
@@ -1027,14 +1058,14 @@ __host__ __device__ inline FusedLayout fused_layout(int row_block, int wps) {
   return L;
 }
 
-template <int WPS>
+template <int WPS, bool USE_GLOBAL>
 __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
                                                                const uint8_t *packed,
                                                                size_t in_stride,
                                                                const uint32_t *sizes,
                                                                uint8_t *out_frames) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const FusedLayout L = fused_layout(g.row_block, WPS);
+  const FusedLayout L = fused_layout(g.row_block, WPS, !USE_GLOBAL);
   uint8_t *sym = smem + L.sym;
   uint32_t *pay = reinterpret_cast<uint32_t *>(smem + L.pay);
   uint32_t *lut = reinterpret_cast<uint32_t *>(smem + L.lut);
@@ -1066,7 +1097,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 
   DecTables tb;
   tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const int bad = decode_stream<WPS, true>(
+  const int bad = decode_stream<WPS, true, USE_GLOBAL>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
       (uint32_t)g.row_block, pay, tb, sh, sym, nullptr, nullptr,
       ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8);
@@ -1075,6 +1106,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     return;
   }
 
+  const long long c_p2 = clock64();
   const int ycbcr = df->ycbcr;
   const int cols = g.cols, v = r;
   const int v2 = min(v + 1, g.rows - 1);
@@ -1117,6 +1149,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     }
   }
   __syncthreads();
+  const long long c_p3 = clock64();
 
   // ---- phase 3: colour inverse + coalesced stores ----
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
@@ -1157,6 +1190,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
           for (int c = 0; c < g.C; ++c) dst[x * g.C + c] = (uint8_t)(px[x] >> (8 * c));
     }
   }
+  if (tid == 0) {
+    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
+    st[2] = (uint32_t)((c_p3 - c_p2) >> 4);
+    st[7] = (uint32_t)((clock64() - c_p3) >> 4);
+  }
 }
 
 // k_dec_status: copy the per-frame verdict out of the workspace.
@@ -1176,12 +1214,15 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused) {
   const unsigned gx = (unsigned)((g.cols + 255) / 256);
-  // Fused row kernel when the row's symbols + staging fit the 160 KiB LDS.
+  // Fused row kernel when the row's symbols fit the 160 KiB LDS: with the payload
+  // staged in LDS too when that also fits, else with the payload read from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;
-  const int wps = !allow_fused                                    ? 0
-                  : fused_layout(g.row_block, 8).total <= kLdsMax ? 8
-                  : fused_layout(g.row_block, 4).total <= kLdsMax ? 4
-                                                                  : 0;
+  int fused = 0;  // 0 = unfused, 1 = staged payload, 2 = payload from global memory
+  if (allow_fused) {
+    if (fused_layout(g.row_block, 8, true).total <= kLdsMax) fused = 1;
+    else if (fused_layout(g.row_block, 8, false).total <= kLdsMax) fused = 2;
+  }
+  const int wps = fused;
   HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
   // LRES: every chunk in parallel, chain verified, serial fallback if not.
   (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
@@ -1197,18 +1238,18 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                 d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
-    const uint32_t lds = fused_layout(g.row_block, wps).total;
+    const uint32_t lds = fused_layout(g.row_block, 8, fused == 1).total;
     prof_begin(prof, "k_dec_row_fused", stream);
-    if (wps == 8) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8>),
+    if (fused == 1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_dec_row_fused<8>, dim3(g.rows, batch), dim3(kDecThreads), lds, stream, g,
-                         ws, d_packed, in_stride, d_sizes, d_out);
+      hipLaunchKernelGGL((k_dec_row_fused<8, false>), dim3(g.rows, batch), dim3(kDecThreads), lds,
+                         stream, g, ws, d_packed, in_stride, d_sizes, d_out);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<4>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_dec_row_fused<4>, dim3(g.rows, batch), dim3(kDecThreads), lds, stream, g,
-                         ws, d_packed, in_stride, d_sizes, d_out);
+      hipLaunchKernelGGL((k_dec_row_fused<8, true>), dim3(g.rows, batch), dim3(kDecThreads), lds,
+                         stream, g, ws, d_packed, in_stride, d_sizes, d_out);
     }
     prof_end(prof, stream);
   } else {

@@ -12,7 +12,7 @@ packed = eng.encode(img, 50)
 eng.decode(packed)
 rows = h // 8
 st = eng.debug_read("dec_stats", 0, (rows + 1) * 32, np.uint32, decoder=True).reshape(rows + 1, 8)
-names = ["chunks", "rounds", "fix_chunks(lres)", "fix_rounds(lres)|clk_stage/16", "clk_sync/16", "clk_write/16", "pay_len", "out_size"]
+names = ["chunks", "rounds", "clk_tile/16 (lres: fix chunks)", "clk_stage/16 (lres: fix rounds)", "clk_sync/16", "clk_write/16", "pay_len", "clk_store/16"]
 print("LRES:", dict(zip(names, st[0].tolist())))
 fr = st[1:].astype(np.float64)
 for i, n in enumerate(names):
