@@ -93,6 +93,7 @@ struct DecWs {
   DecFrame *frames;          // [f]
   int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
   uint32_t *lut;             // [f][2][1<<kLutBits]
+  uint2 *lut2;               // [f][2][1<<kLutBits] multi-token groups (kernels_dec.hip next_step)
   uint32_t *row_off;         // [f][rows] payload byte offset of each FRES row
   uint32_t *row_len;         // [f][rows]
   uint8_t *lres_sym;         size_t lres_stride;

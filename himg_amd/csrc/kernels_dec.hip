@@ -132,6 +132,8 @@ __device__ __forceinline__ uint32_t lut_node(int node, int bits) {
 __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_t *packed,
                                                   size_t in_stride, const uint32_t *sizes) {
   __shared__ TreeAux aux[2][kMaxNodes + 1];
+  __shared__ uint32_t s_lut[2][1 << kLutBits];
+  __shared__ uint8_t s_tree[kTreeStride + 16];  // serialised tree bytes (at most 359)
   __shared__ int s_status;
   const int f = blockIdx.x, lane = threadIdx.x;
   const uint8_t *p = packed + (size_t)f * in_stride;
@@ -162,7 +164,14 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       // decoder.cpp:214-232: LRES is one unblocked stream.
       if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { st = fmt_err(4, 0); break; }
       df->s[0].chunk_end = idx + sz;
-      st = recover_tree(p, idx, idx + sz, nodes0, aux[0], &df->s[0].num_nodes, &df->s[0].payload_off);
+      {
+        // The tree is at most 359 bytes: copy it to LDS with independent loads, then
+        // walk it there (the walk is a chain of dependent bit reads).
+        const uint32_t tn = sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride;
+        for (uint32_t k = 0; k < tn; ++k) s_tree[k] = p[idx + k];
+        st = recover_tree(s_tree, 0, tn, nodes0, aux[0], &df->s[0].num_nodes, &df->s[0].payload_off);
+        df->s[0].payload_off += idx;
+      }
       if (st) { if (st == kStFormat) st = fmt_err(4, 1); break; }
       df->s[0].root = 0;
       // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
@@ -185,7 +194,14 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       // Trap T2: the decoder derives use_blocks from the COMPRESSED size
       // (huffman_dec.cpp:215-219); UncompressBlock refuses when it is false (:265).
       if (!((uint32_t)g.row_block < sz)) { st = fmt_err(7, 1); break; }
-      st = recover_tree(p, idx, idx + sz, nodes1, aux[1], &df->s[1].num_nodes, &df->s[1].payload_off);
+      {
+        // The tree is at most 359 bytes: copy it to LDS with independent loads, then
+        // walk it there (the walk is a chain of dependent bit reads).
+        const uint32_t tn = sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride;
+        for (uint32_t k = 0; k < tn; ++k) s_tree[k] = p[idx + k];
+        st = recover_tree(s_tree, 0, tn, nodes1, aux[1], &df->s[1].num_nodes, &df->s[1].payload_off);
+        df->s[1].payload_off += idx;
+      }
       if (st) { if (st == kStFormat) st = fmt_err(7, 1); break; }
       df->s[1].root = 0;
       if (df->s[1].payload_off >= df->s[1].chunk_end) { st = fmt_err(7, 1); break; }
@@ -220,10 +236,10 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
   __syncthreads();
   if (s_status) return;
 
-  // First-level LUTs (kLutBits wide, LSB-first codes index them directly).
+  // First-level LUTs (kLutBits wide, LSB-first codes index them directly), then
+  // the multi-token table derived from them (see next_step).
   for (int s = 0; s < 2; ++s) {
     const int32_t *nodes = s ? nodes1 : nodes0;
-    uint32_t *lut = ws.lut + ((size_t)f * 2 + s) * (1u << kLutBits);
     const int nn = df->s[s].num_nodes;
     for (int k = lane; k < nn; k += 64) {
       const int depth = aux[s][k].depth;
@@ -231,10 +247,39 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       const int sym = nodes[3 * k + 2];
       if (sym >= 0 && depth <= kLutBits) {
         for (uint32_t i = 0; i < (1u << (kLutBits - depth)); ++i)
-          lut[(i << depth) | code] = lut_leaf(sym, depth);
+          s_lut[s][(i << depth) | code] = lut_leaf(sym, depth);
       } else if (sym < 0 && depth == kLutBits) {
-        lut[code] = lut_node(k, depth);
+        s_lut[s][code] = lut_node(k, depth);
       }
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < 2; ++s) {
+    uint32_t *lut = ws.lut + ((size_t)f * 2 + s) * (1u << kLutBits);
+    uint2 *lut2 = ws.lut2 + ((size_t)f * 2 + s) * (1u << kLutBits);
+    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += 64) {
+      lut[idx] = s_lut[s][idx];
+      // Greedy group of tokens that lie completely inside the kLutBits known bits.
+      uint32_t used = 0, nout = 0, bytes = 0, last = 0, eb_first = 0;
+      for (;;) {
+        const uint32_t e = s_lut[s][(idx >> used) & ((1u << kLutBits) - 1)];
+        const uint32_t len = (e >> 10) & 63u, eb = (e >> 16) & 15u, sym = e & 511u;
+        if ((e & 512u) || len == 0 || used + len > (uint32_t)kLutBits || sym > 260) break;
+        if (eb) {  // zero run with extra bits: only as a step of its own
+          if (nout == 0) { used = len; eb_first = eb; }
+          break;
+        }
+        const uint32_t out = sym == 256 ? 2u : 1u;
+        if (nout + out > 4) break;
+        if (sym < 256) bytes |= sym << (8 * nout);
+        last = used;
+        nout += out;
+        used += len;
+      }
+      uint2 r;
+      r.x = bytes;
+      r.y = (nout || eb_first) ? (used | (nout << 8) | (last << 12) | (eb_first << 16)) : 0u;
+      lut2[idx] = r;
     }
   }
 }
@@ -302,6 +347,7 @@ struct BitReader {
 
 struct DecTables {
   const uint32_t *lut;             // LDS, 1 << kLutBits entries
+  const uint2 *lut2;               // LDS, multi-token groups (see build_lut2)
   const short *ca, *cb, *sy;       // LDS tree nodes
 };
 
@@ -348,6 +394,48 @@ __device__ __forceinline__ Tok next_token(BitReader &br, const PV &pv, const Dec
   r.nbits = len + eb;
   // Symbols above 260 make the reference abort (huffman_dec.cpp:349-352).
   r.count = sym < 256 ? 1 : (sym <= 260 ? base + extra : -1);
+  return r;
+}
+
+// One decode STEP = one lookup in the multi-token table lut2: either a group of
+// up to 4 output bytes' worth of short tokens without extra bits (literals and
+// the two-zeros symbol), or one zero-run token with its extra bits.  The step is
+// only taken when every token of the group starts before `lim` (tokens are owned
+// by the lane whose range they START in), when it fits in the valid bits and in
+// `room` (symbols left in the block); otherwise -- and for codes longer than
+// kLutBits -- the lane falls back to one exact single-token step.
+struct Step {
+  int nbits;        // bits consumed
+  int count;        // output symbols produced (-1: invalid symbol, reference aborts)
+  int nlit;         // how many of them are explicit bytes in `bytes` (else zeros)
+  uint32_t bytes;
+};
+
+template <class PV>
+__device__ __forceinline__ Step next_step(BitReader &br, const PV &pv, const DecTables &t,
+                                          uint32_t pos, uint32_t lim, unsigned long long room) {
+  refill_bf(br, pv);
+  const uint2 e = t.lut2[(uint32_t)br.win & ((1u << kLutBits) - 1)];
+  const int nb = (int)(e.y & 63u), gn = (int)((e.y >> 8) & 15u), last = (int)((e.y >> 12) & 15u);
+  const int eb = (int)((e.y >> 16) & 15u);
+  const bool fast = nb != 0 && pos + (uint32_t)last < lim && nb + eb <= br.nb &&
+                    (eb != 0 || (unsigned long long)gn <= room);
+  Step r;
+  if (__builtin_expect(!fast, 0)) {
+    const Tok k = next_token(br, pv, t);
+    r.nbits = k.nbits;
+    r.count = k.count;
+    r.nlit = k.sym < 256 ? 1 : 0;
+    r.bytes = (uint32_t)k.sym;
+    return r;
+  }
+  const int extra = (int)((uint32_t)(br.win >> nb) & ((1u << eb) - 1u));
+  br.consume(nb + eb);
+  const int base = eb == 2 ? 3 : eb == 4 ? 7 : eb == 8 ? 23 : 279;
+  r.nbits = nb + eb;
+  r.count = eb ? base + extra : gn;
+  r.nlit = eb ? 0 : gn;
+  r.bytes = e.x;
   return r;
 }
 
@@ -438,7 +526,7 @@ __device__ __forceinline__ void fixpoint_chunk(const PV &pv, const DecTables &tb
         BitReader br;
         br.init(pv, pos);
         do {
-          const Tok t = next_token(br, pv, tb);
+          const Step t = next_step(br, pv, tb, pos, lim, ~0ull);
           pos += t.nbits ? t.nbits : 1;
           c += (unsigned long long)(t.count > 0 ? t.count : 0);
         } while (pos < lim);
@@ -478,10 +566,17 @@ __device__ __forceinline__ void write_chunk_windows(const PV &pv, const DecTable
     __syncthreads();
     const unsigned long long we = wb + kWinBytes;
     while (!done && op < we) {
-      const Tok t = next_token(br, pv, tb);
+      // A group may not straddle the window end: cap `room` at the window.
+      const unsigned long long room = (out_size < we ? out_size : we) - op;
+      const Step t = next_step(br, pv, tb, bp, lim, room);
       if (t.count < 0 || t.nbits == 0) { sh->err = 1; done = true; break; }
-      if (t.sym < 256) {
-        if (t.sym) reinterpret_cast<uint8_t *>(win)[(uint32_t)(op - wb)] = (uint8_t)t.sym;
+      if (t.nlit) {
+        uint8_t *o = reinterpret_cast<uint8_t *>(win) + (uint32_t)(op - wb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t b = (t.bytes >> (8 * i)) & 255u;
+          if (i < t.nlit && b) o[i] = (uint8_t)b;
+        }
       } else if (op + (unsigned long long)t.count > out_size) {
         sh->err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
         done = true;
@@ -586,10 +681,14 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
       BitReader br;
       if (!done) br.init(pv, bp);
       while (!done) {
-        const Tok t = next_token(br, pv, tb);
+        const Step t = next_step(br, pv, tb, bp, lim, (unsigned long long)out_size - op);
         if (t.count < 0 || t.nbits == 0) { sh->err = 1; break; }
-        if (t.sym < 256) {
-          if (t.sym) lds_out[op] = (uint8_t)t.sym;
+        if (t.nlit) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t b = (t.bytes >> (8 * i)) & 255u;
+            if (i < t.nlit && b) lds_out[op + i] = (uint8_t)b;
+          }
         } else if (op + (unsigned long long)t.count > out_size) {
           sh->err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
           break;
@@ -631,14 +730,16 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
 }
 
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
-                                                uint32_t *lut, short *ca, short *cb, short *sy) {
+                                                uint32_t *lut, uint2 *lut2, short *ca, short *cb,
+                                                short *sy) {
   const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
   const int nn = df->s[strm].num_nodes;
   for (int k = threadIdx.x; k < nn; k += kDecThreads) {
     ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
   }
   const uint32_t *gl = ws.lut + ((size_t)f * 2 + strm) * (1u << kLutBits);
-  for (int k = threadIdx.x; k < (1 << kLutBits); k += kDecThreads) lut[k] = gl[k];
+  const uint2 *gl2 = ws.lut2 + ((size_t)f * 2 + strm) * (1u << kLutBits);
+  for (int k = threadIdx.x; k < (1 << kLutBits); k += kDecThreads) { lut[k] = gl[k]; lut2[k] = gl2[k]; }
 }
 
 // ---------------------------------------------------------------------------
@@ -652,6 +753,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   __shared__ uint32_t pay[8 * (kDecThreads + 2)];
   __shared__ uint32_t win[kWinBytes / 4];
   __shared__ uint32_t lut[1 << kLutBits];
+  __shared__ uint2 lut2[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
 
@@ -675,10 +777,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
   }
-  load_dec_tables(ws, df, f, strm, lut, ca, cb, sy);
+  load_dec_tables(ws, df, f, strm, lut, lut2, ca, cb, sy);
   __syncthreads();
   DecTables tb;
-  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<8, false, false>(p, sizes[f], pay_off, pay_len, out_size, pay, tb, &sh,
                                           nullptr, win, out,
                                           ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
@@ -713,6 +815,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
                                                             size_t in_stride, const uint32_t *sizes) {
   __shared__ uint32_t pay[kLresWps * (kDecThreads + 2)];
   __shared__ uint32_t lut[1 << kLutBits];
+  __shared__ uint2 lut2[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -731,9 +834,9 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     if (tid == 0) ws.fix_end[slot] = ws.spec_end[slot];
     return;
   }
-  load_dec_tables(ws, df, f, 0, lut, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, lut, lut2, ca, cb, sy);
   DecTables tb;
-  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const PayView<kLresWps> pv = {pay};
   const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
                                               8ull * pay_off + cur, pay);
@@ -801,6 +904,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   __shared__ uint32_t pay[kLresWps * (kDecThreads + 2)];
   __shared__ uint32_t win[kWinBytes / 4];
   __shared__ uint32_t lut[1 << kLutBits];
+  __shared__ uint2 lut2[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -814,10 +918,10 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const size_t slot = (size_t)f * ws.lres_chunks + k;
   const unsigned long long O0 = ws.ver_base[slot];
   if (O0 >= out_size) return;
-  load_dec_tables(ws, df, f, 0, lut, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, lut, lut2, ca, cb, sy);
   if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
   DecTables tb;
-  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const PayView<kLresWps> pv = {pay};
   const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
                                               8ull * pay_off + cur, pay);
@@ -1039,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // The symbols never touch HBM: traffic is the packed row in, the pixels out.
 // ---------------------------------------------------------------------------
 struct FusedLayout {
-  uint32_t sym, pay, lut, ca, cb, sy, sh, unmap, shift, total;
+  uint32_t sym, pay, lut, lut2, ca, cb, sy, sh, unmap, shift, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int row_block, int wps, bool stage_payload) {
   FusedLayout L;
@@ -1048,6 +1152,7 @@ __host__ __device__ inline FusedLayout fused_layout(int row_block, int wps, bool
   L.sym = carve((uint32_t)row_block);
   L.pay = carve(stage_payload ? (uint32_t)wps * (kDecThreads + 2) * 4u : 0u);
   L.lut = carve((1u << kLutBits) * 4u);
+  L.lut2 = carve((1u << kLutBits) * 8u);
   L.ca = carve((kMaxNodes + 1) * 2u);
   L.cb = carve((kMaxNodes + 1) * 2u);
   L.sy = carve((kMaxNodes + 1) * 2u);
@@ -1069,6 +1174,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint8_t *sym = smem + L.sym;
   uint32_t *pay = reinterpret_cast<uint32_t *>(smem + L.pay);
   uint32_t *lut = reinterpret_cast<uint32_t *>(smem + L.lut);
+  uint2 *lut2 = reinterpret_cast<uint2 *>(smem + L.lut2);
   short *ca = reinterpret_cast<short *>(smem + L.ca);
   short *cb = reinterpret_cast<short *>(smem + L.cb);
   short *sy = reinterpret_cast<short *>(smem + L.sy);
@@ -1080,7 +1186,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  load_dec_tables(ws, df, f, 1, lut, ca, cb, sy);
+  load_dec_tables(ws, df, f, 1, lut, lut2, ca, cb, sy);
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -1096,7 +1202,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   __syncthreads();
 
   DecTables tb;
-  tb.lut = lut; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<WPS, true, USE_GLOBAL>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
       (uint32_t)g.row_block, pay, tb, sh, sym, nullptr, nullptr,
@@ -1111,9 +1217,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const int cols = g.cols, v = r;
   const int v2 = min(v + 1, g.rows - 1);
   // ---- phase 2: per-tile inverse transform, in place ----
-  for (int u = tid; u < cols; u += kDecThreads) {
+  for (int it = tid; it < cols * g.C; it += kDecThreads) {
+    const int c = it / cols, u = it - c * cols;
     const int u2 = min(u + 1, cols - 1);
-    for (int c = 0; c < g.C; ++c) {
+    {
       const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * cols;
       const bool chroma = ycbcr && (c == 1 || c == 2);  // decoder.cpp:376
       const uint8_t *shift = s_shift + (chroma ? 64 : 0);

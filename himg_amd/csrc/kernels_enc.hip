@@ -217,7 +217,54 @@ __device__ __forceinline__ void wht8(int &x0, int &x1, int &x2, int &x3, int &x4
 // k_tile_fwd: one lane per 8x8 tile, a wavefront covers 64 horizontally
 // adjacent tiles of one block row, so for every coefficient the 64 lanes write
 // 64 consecutive symbol bytes (encoder.cpp:320-323 layout).
+//
+// Channels are processed one after the other and the tile's pixels are re-read
+// for each (L1 hits after the first pass) instead of being held in registers:
+// that keeps the kernel under 128 VGPRs, i.e. 4 waves per SIMD instead of 1,
+// which is what hides the load/store latency of this kernel.
 // ---------------------------------------------------------------------------
+enum { kChanRaw = 0, kChanY = 1, kChanCb = 2, kChanCr = 3 };
+
+// One channel value of a packed RGBA pixel, with the colour lift of
+// ycbcr.cpp:32-37 applied on the fly.
+template <int MODE>
+__device__ __forceinline__ int channel_value(uint32_t px, int sh) {
+  if (MODE == kChanRaw) return (int)((px >> sh) & 255u);
+  const int c0 = px & 255, c1 = (px >> 8) & 255, c2 = (px >> 16) & 255;
+  if (MODE == kChanY) return (c0 + 2 * c1 + c2 + 2) >> 2;
+  if (MODE == kChanCb) return (c2 - c1 + 256) >> 1;
+  return (c0 - c1 + 256) >> 1;
+}
+
+// Residual of one full tile of one channel: pixel - bilinear low-res block
+// (downsampled.cpp:116-169, encoder.cpp:304-309).  `row0` points at the tile's
+// first pixel (RGBA8, 16-byte aligned), `pitch` is the image row pitch in bytes.
+template <int MODE>
+__device__ __forceinline__ void residual_full_tile(const uint8_t *row0, size_t pitch, int sh,
+                                                   const int left[9], const int right[9],
+                                                   int b[64]) {
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const uint4 *rp = reinterpret_cast<const uint4 *>(row0 + (size_t)y * pitch);
+    const uint4 q0 = rp[0], q1 = rp[1];
+    int a[9];
+    a[0] = left[y]; a[8] = right[y];
+    interp9(a);
+    b[y * 8 + 0] = channel_value<MODE>(q0.x, sh) - a[0];
+    b[y * 8 + 1] = channel_value<MODE>(q0.y, sh) - a[1];
+    b[y * 8 + 2] = channel_value<MODE>(q0.z, sh) - a[2];
+    b[y * 8 + 3] = channel_value<MODE>(q0.w, sh) - a[3];
+    b[y * 8 + 4] = channel_value<MODE>(q1.x, sh) - a[4];
+    b[y * 8 + 5] = channel_value<MODE>(q1.y, sh) - a[5];
+    b[y * 8 + 6] = channel_value<MODE>(q1.z, sh) - a[6];
+    b[y * 8 + 7] = channel_value<MODE>(q1.w, sh) - a[7];
+  }
+}
+
+// FAST: every tile is full and pixels are packed RGBA8 (the BASELINE configs);
+// otherwise the generic path handles ragged edges, other channel counts and
+// pixel strides.
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_tile_fwd(Geom g, const uint8_t *frames,
                                                   const uint8_t *low, size_t plane_stride,
                                                   uint8_t *fres_sym, size_t fres_stride,
@@ -228,45 +275,12 @@ __global__ __launch_bounds__(256) void k_tile_fwd(Geom g, const uint8_t *frames,
   if (u >= g.cols) return;
   const uint8_t *img = frames + (long long)f * g.frame_bytes;
   const int bw = min(8, g.W - 8 * u), bh = min(8, g.H - 8 * v);
-
-  // Pixels of the tile, channels packed 8 bits each, already lifted.
-  uint32_t px[64];
-  if (bw == 8 && bh == 8 && g.stride == 4 && g.C == 4) {
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      const uint4 *rp = reinterpret_cast<const uint4 *>(
-          img + ((long long)(8 * v + y) * g.W + 8 * u) * 4);
-      const uint4 q0 = rp[0], q1 = rp[1];
-      px[y * 8 + 0] = q0.x; px[y * 8 + 1] = q0.y; px[y * 8 + 2] = q0.z; px[y * 8 + 3] = q0.w;
-      px[y * 8 + 4] = q1.x; px[y * 8 + 5] = q1.y; px[y * 8 + 6] = q1.z; px[y * 8 + 7] = q1.w;
-    }
-    if (g.ycbcr) {
-#pragma unroll
-      for (int i = 0; i < 64; ++i) {
-        int c0 = px[i] & 255, c1 = (px[i] >> 8) & 255, c2 = (px[i] >> 16) & 255;
-        lift_fwd(c0, c1, c2);
-        px[i] = (px[i] & 0xff000000u) | (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
-      }
-    }
-  } else {
-    // Partial tiles replicate the last valid pixel of the row, rows below the
-    // image repeat the bottom-right valid pixel (encoder.cpp:26-52).
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        const int yy = y < bh ? y : bh - 1;
-        const int xx = y < bh ? min(x, bw - 1) : bw - 1;
-        int ch[4];
-        load_pixel(img, g, 8 * u + xx, 8 * v + yy, ch);
-        px[y * 8 + x] = (uint32_t)ch[0] | ((uint32_t)ch[1] << 8) | ((uint32_t)ch[2] << 16) |
-                        ((uint32_t)ch[3] << 24);
-      }
-  }
-
   const int u2 = min(u + 1, g.cols - 1), v2 = min(v + 1, g.rows - 1);
   uint8_t *dst_row = fres_sym + (size_t)f * fres_stride + (size_t)v * g.row_block + u;
+  const uint8_t *row0 = img + ((long long)(8 * v) * g.W + 8 * u) * 4;
+  const size_t pitch = (size_t)g.W * 4;
 
+#pragma unroll 1
   for (int c = 0; c < g.C; ++c) {
     const uint8_t *m = low + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
     // Bilinear low-res block from the four corners (downsampled.cpp:116-169).
@@ -277,14 +291,29 @@ __global__ __launch_bounds__(256) void k_tile_fwd(Geom g, const uint8_t *frames,
     interp9(right);
 
     int b[64];
-    const int sh = 8 * c;
+    if (FAST) {
+      const int mode = (g.ycbcr && c < 3) ? (c + 1) : kChanRaw;  // wave-uniform
+      if (mode == kChanRaw) residual_full_tile<kChanRaw>(row0, pitch, 8 * c, left, right, b);
+      else if (mode == kChanY) residual_full_tile<kChanY>(row0, pitch, 0, left, right, b);
+      else if (mode == kChanCb) residual_full_tile<kChanCb>(row0, pitch, 0, left, right, b);
+      else residual_full_tile<kChanCr>(row0, pitch, 0, left, right, b);
+    } else {
+      // Partial tiles replicate the last valid pixel of the row, rows below the
+      // image repeat the bottom-right valid pixel (encoder.cpp:26-52).
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      int a[9];
-      a[0] = left[y]; a[8] = right[y];
-      interp9(a);
+      for (int y = 0; y < 8; ++y) {
+        int a[9];
+        a[0] = left[y]; a[8] = right[y];
+        interp9(a);
 #pragma unroll
-      for (int x = 0; x < 8; ++x) b[y * 8 + x] = (int)((px[y * 8 + x] >> sh) & 255) - a[x];
+        for (int x = 0; x < 8; ++x) {
+          const int yy = y < bh ? y : bh - 1;
+          const int xx = y < bh ? min(x, bw - 1) : bw - 1;
+          int ch[4];
+          load_pixel(img, g, 8 * u + xx, 8 * v + yy, ch);
+          b[y * 8 + x] = ch[c] - a[x];
+        }
+      }
     }
     // Forward 2-D WHT: rows, then columns (hadamard.cpp:78-88).
 #pragma unroll
@@ -302,14 +331,15 @@ __global__ __launch_bounds__(256) void k_tile_fwd(Geom g, const uint8_t *frames,
     for (int i = 0; i < 64; ++i) {
       const int pos = kScan[i];
       const int s = shift[pos];
-      int x = (int)(int16_t)b[pos];  // the reference's int16 wrap
+      const int x = (int)(int16_t)b[pos];  // the reference's int16 wrap
       // Sign-magnitude rounding shift (quantize.cpp:135-148).
       const int r = s ? (1 << (s - 1)) : 0;
       const int mag = x < 0 ? ((-x + r) >> s) : ((x + r) >> s);
-      // Companding through the LUT of Mapper::MapTo8Bit (mapper.cpp:159-182).
-      const uint32_t code = fmap_lut[mag];
-      const uint8_t out = (x < 0) ? (uint8_t)(0u - code) : (uint8_t)code;
-      dst[(size_t)i * g.cols] = out;
+      // Companding (mapper.cpp:159-182): the full-res table is the identity up to
+      // 50; larger magnitudes go through the LUT of the restated search.
+      uint32_t code = (uint32_t)mag;
+      if (mag > 50) code = fmap_lut[mag];
+      dst[(size_t)i * g.cols] = (x < 0) ? (uint8_t)(0u - code) : (uint8_t)code;
     }
   }
 }
@@ -393,43 +423,56 @@ __device__ __forceinline__ void emit_run(int len, F &&f) {
   else f(260, 14, len - 279);
 }
 
-// Walk one thread's 16 symbols.  A zero run is tokenised by the thread that
-// holds the run's LAST zero (the run start comes in through run_in), which
-// keeps token order == thread order with a forward scan only.
-template <class F>
-__device__ __forceinline__ void walk16(const uint32_t w[4], int nvalid, int run_in, bool flush,
-                                       F &&f) {
-  int run = run_in;
+// Bit k of the result is set when symbol k (byte k of the 16-byte chunk) is
+// non-zero; symbols at or beyond nvalid read as zero.
+__device__ __forceinline__ uint32_t nonzero_mask16(const uint32_t w[4], int nvalid) {
+  uint32_t m = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < nvalid) {
-      const int s = (w[k >> 2] >> ((k & 3) * 8)) & 255;
-      if (s == 0) {
-        ++run;
-      } else {
-        if (run) emit_run(run, f);
-        run = 0;
-        f(s, 0, 0);
-      }
-    }
+  for (int q = 0; q < 4; ++q) {
+    // Bit 7 of every byte = (byte != 0), then gather bits 7,15,23,31 into a nibble
+    // (the four partial products of the multiply land on distinct bits).
+    const uint32_t t = ((((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u) >> 7;
+    m |= (((t * 0x00204081u) >> 21) & 0xfu) << (4 * q);
   }
-  if (flush && run) emit_run(run, f);
+  return nvalid >= 16 ? m : (m & ((1u << nvalid) - 1u));
+}
+
+__device__ __forceinline__ int symbol_at(const uint32_t w[4], int k) {
+  const unsigned long long lo = ((unsigned long long)w[1] << 32) | w[0];
+  const unsigned long long hi = ((unsigned long long)w[3] << 32) | w[2];
+  return (int)(((k < 8 ? lo : hi) >> ((k & 7) * 8)) & 255ull);
+}
+
+// Walk one thread's 16 symbols: iterate over the NON-ZERO symbols only (set bits
+// of the mask); the zeros in front of each are one run.  A zero run is tokenised
+// by the thread that holds the run's LAST zero (the run start comes in through
+// run_in), which keeps token order == thread order with a forward scan only.
+// f(symbol, extra_bits, extra_value).
+template <class F>
+__device__ __forceinline__ void walk16(const uint32_t w[4], uint32_t mask, int nvalid, int run_in,
+                                       bool flush, F &&f) {
+  int prev = -1;
+  uint32_t m = mask;
+  while (m) {
+    const int k = __ffs(m) - 1;
+    m &= m - 1;
+    const int run = k - prev - 1 + (prev < 0 ? run_in : 0);
+    if (run) emit_run(run, f);
+    f(symbol_at(w, k), 0, 0);
+    prev = k;
+  }
+  if (flush) {
+    const int run = nvalid - 1 - prev + (prev < 0 ? run_in : 0);
+    if (run) emit_run(run, f);
+  }
 }
 
 // Zero-run summary of one thread's chunk.  Chunks with fewer than 16 valid
 // symbols only occur at the very end of a span; an empty chunk is the identity.
-__device__ __forceinline__ ZR summarize16(const uint32_t w[4], int nvalid) {
+__device__ __forceinline__ ZR summarize16(uint32_t mask, int nvalid) {
   ZR z;
-  int tz = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < nvalid) {
-      const int s = (w[k >> 2] >> ((k & 3) * 8)) & 255;
-      tz = s ? 0 : tz + 1;
-    }
-  }
-  z.tz = tz;
-  z.az = (tz == nvalid) ? 1 : 0;
+  z.tz = mask ? nvalid - (32 - __clz(mask)) : nvalid;
+  z.az = mask ? 0 : 1;
   return z;
 }
 
@@ -498,7 +541,7 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
     const int nvalid = max(0, min(16, s.len - off));
     uint32_t w[4];
     load16(s.sym + off, s.len - off, w);
-    const ZR mine = summarize16(w, nvalid);
+    const ZR mine = summarize16(nonzero_mask16(w, nvalid), nvalid);
     block_scan_zr(mine, carry, sm, &total);
     carry = total;
   }
@@ -523,13 +566,14 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws) {
     const int nvalid = max(0, min(16, s.len - off));
     uint32_t w[4];
     load16(s.sym + off, s.len - off, w);
-    const ZR mine = summarize16(w, nvalid);
+    const uint32_t mask = nonzero_mask16(w, nvalid);
+    const ZR mine = summarize16(mask, nvalid);
     ZR total;
     const ZR ex = block_scan_zr(mine, carry, sm, &total);
     carry = total;
     carry.az = 0;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
-    walk16(w, nvalid, ex.tz, flush, [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); });
+    walk16(w, mask, nvalid, ex.tz, flush, [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); });
   }
   __syncthreads();
   uint32_t *sh = (s.is_lres ? ws.span_hist_l + ((size_t)f * g.lres_spans + sp) * kHistStride
@@ -811,7 +855,8 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     const int nvalid = max(0, min(16, s.len - off));
     uint32_t w[4];
     load16(s.sym + off, s.len - off, w);
-    const ZR mine = summarize16(w, nvalid);
+    const uint32_t mask = nonzero_mask16(w, nvalid);
+    const ZR mine = summarize16(mask, nvalid);
     ZR total;
     const ZR ex = block_scan_zr(mine, carry, sm_zr, &total);
     carry = total;
@@ -819,7 +864,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
 
     uint32_t mybits = 0;
-    walk16(w, nvalid, ex.tz, flush, [&](int sym, int eb, int) { mybits += s_len[sym] + eb; });
+    walk16(w, mask, nvalid, ex.tz, flush, [&](int sym, int eb, int) { mybits += s_len[sym] + eb; });
     uint32_t iter_bits;
     const uint32_t myoff = block_scan_u32(mybits, sm_u, &iter_bits);
 
@@ -838,7 +883,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
         accb -= 32;
       }
     };
-    walk16(w, nvalid, ex.tz, flush, [&](int sym, int eb, int ev) {
+    walk16(w, mask, nvalid, ex.tz, flush, [&](int sym, int eb, int ev) {
       put(s_code[sym], s_len[sym]);
       if (eb) put((uint32_t)ev, eb);
     });
@@ -936,8 +981,13 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
               ws.plane_stride);
   HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws.low,
               ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
-  HIMG_LAUNCH(k_tile_fwd, dim3(gx, g.rows, batch), b256, g, d_frames, ws.low, ws.plane_stride,
-              ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+  if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
+    HIMG_LAUNCH(k_tile_fwd<true>, dim3(gx, g.rows, batch), b256, g, d_frames, ws.low,
+                ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+  } else {
+    HIMG_LAUNCH(k_tile_fwd<false>, dim3(gx, g.rows, batch), b256, g, d_frames, ws.low,
+                ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+  }
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
   HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws);
