@@ -25,6 +25,10 @@ __device__ static constexpr uint8_t kScanD[64] = {
     43, 42, 41, 40, 48, 49, 50, 51, 52, 53, 54, 46, 38, 30, 22, 14,
     6,  7,  15, 23, 31, 39, 47, 55, 63, 62, 61, 60, 59, 58, 57, 56};
 
+// Inverse of kScanD: kInvScanD[row-major position] = index in the coefficient scan.
+__device__ static constexpr uint8_t kInvScanD[64] = {
+    0, 1, 8, 9, 24, 25, 48, 49, 3, 2, 7, 10, 23, 26, 47, 50, 4, 5, 6, 11, 22, 27, 46, 51, 15, 14, 13, 12, 21, 28, 45, 52, 16, 17, 18, 19, 20, 29, 44, 53, 35, 34, 33, 32, 31, 30, 43, 54, 36, 37, 38, 39, 40, 41, 42, 55, 63, 62, 61, 60, 59, 58, 57, 56};
+
 // Device status values (host maps them to HIMG_ERR_*): 0 ok, 1 geometry
 // mismatch, 3 outside the built scope, 4 the reference would return false.
 // A format error also carries the decoder stage that failed in bits 4..7 and
@@ -1163,7 +1167,11 @@ __host__ __device__ inline FusedLayout fused_layout(int row_block, int wps, bool
   return L;
 }
 
-template <int WPS, bool USE_GLOBAL>
+// COLS != 0 fixes the tile count per block row at compile time (512 = 4096-pixel
+// rows): the 64 symbol slots of a tile are then at immediate LDS offsets instead
+// of 64 live address registers, which is what keeps the transform phase from
+// spilling.
+template <int WPS, bool USE_GLOBAL, int COLS>
 __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
                                                                const uint8_t *packed,
                                                                size_t in_stride,
@@ -1214,9 +1222,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 
   const long long c_p2 = clock64();
   const int ycbcr = df->ycbcr;
-  const int cols = g.cols, v = r;
+  const int cols = COLS ? COLS : g.cols, v = r;
   const int v2 = min(v + 1, g.rows - 1);
   // ---- phase 2: per-tile inverse transform, in place ----
+#pragma unroll 1
   for (int it = tid; it < cols * g.C; it += kDecThreads) {
     const int c = it / cols, u = it - c * cols;
     const int u2 = min(u + 1, cols - 1);
@@ -1225,33 +1234,55 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       const bool chroma = ycbcr && (c == 1 || c == 2);  // decoder.cpp:376
       const uint8_t *shift = s_shift + (chroma ? 64 : 0);
       uint8_t *slot = sym + (size_t)c * 64 * cols + u;
-      int b[64];
-#pragma unroll
-      for (int i = 0; i < 64; ++i) {
-        const int pos = kScanD[i];
-        const int code = slot[(size_t)i * cols];
-        b[pos] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));  // quantize.cpp:153-165
-      }
-#pragma unroll
-      for (int y = 0; y < 8; ++y)
-        iwht8(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
-              b[y * 8 + 6], b[y * 8 + 7]);
-#pragma unroll
-      for (int x = 0; x < 8; ++x)
-        iwht8(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
-      int left[9], right[9];
-      left[0] = m[(size_t)v * cols + u];   left[8] = m[(size_t)v2 * cols + u];
-      right[0] = m[(size_t)v * cols + u2]; right[8] = m[(size_t)v2 * cols + u2];
-      interp9d(left);
-      interp9d(right);
+      // Row pass: gather one row of coefficients at a time (row-major position ->
+      // scan index through kInvScanD), dequantise (quantize.cpp:153-165, int16
+      // wrap), butterfly, and keep the int16 results packed two per register.
+      uint32_t P[32];
 #pragma unroll
       for (int y = 0; y < 8; ++y) {
-        int a[9];
-        a[0] = left[y]; a[8] = right[y];
-        interp9d(a);
+        int r[8];
 #pragma unroll
-        for (int x = 0; x < 8; ++x)
-          slot[(size_t)(y * 8 + x) * cols] = (uint8_t)clamp255d((int)(int16_t)(b[y * 8 + x] + a[x]));
+        for (int x = 0; x < 8; ++x) {
+          const int pos = y * 8 + x;
+          const int code = slot[(size_t)kInvScanD[pos] * cols];
+          r[x] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
+        }
+        iwht8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+#pragma unroll
+        for (int x = 0; x < 8; x += 2)
+          P[y * 4 + x / 2] = ((uint32_t)r[x] & 0xffffu) | ((uint32_t)r[x + 1] << 16);
+      }
+      // Bilinear low-res block (downsampled.cpp:116-169), packed one byte per pixel.
+      uint32_t L[16];
+      {
+        int left[9], right[9];
+        left[0] = m[(size_t)v * cols + u];   left[8] = m[(size_t)v2 * cols + u];
+        right[0] = m[(size_t)v * cols + u2]; right[8] = m[(size_t)v2 * cols + u2];
+        interp9d(left);
+        interp9d(right);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+          int a[9];
+          a[0] = left[y]; a[8] = right[y];
+          interp9d(a);
+          L[2 * y] = (uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24);
+          L[2 * y + 1] = (uint32_t)a[4] | ((uint32_t)a[5] << 8) | ((uint32_t)a[6] << 16) | ((uint32_t)a[7] << 24);
+        }
+      }
+      // Column pass, one column at a time; results go straight back to the tile's
+      // own slots (buf0[i] += lowres[i] in int16, ClampTo8Bit: decoder.cpp:401-413).
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        int cv[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+          cv[y] = (int)(int16_t)(P[y * 4 + x / 2] >> ((x & 1) * 16));
+        iwht8(cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+          const int lo = (int)((L[2 * y + x / 4] >> ((x & 3) * 8)) & 255u);
+          slot[(size_t)(y * 8 + x) * cols] = (uint8_t)clamp255d((int)(int16_t)(cv[y] + lo));
+        }
       }
     }
   }
@@ -1347,17 +1378,17 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     const uint32_t lds = fused_layout(g.row_block, 8, fused == 1).total;
     prof_begin(prof, "k_dec_row_fused", stream);
-    if (fused == 1) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_dec_row_fused<8, false>), dim3(g.rows, batch), dim3(kDecThreads), lds,
-                         stream, g, ws, d_packed, in_stride, d_sizes, d_out);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((k_dec_row_fused<8, true>), dim3(g.rows, batch), dim3(kDecThreads), lds,
-                         stream, g, ws, d_packed, in_stride, d_sizes, d_out);
-    }
+#define HIMG_FUSED_LAUNCH(G, COLS)                                                              \
+  do {                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8, G, COLS>),     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+    hipLaunchKernelGGL((k_dec_row_fused<8, G, COLS>), dim3(g.rows, batch), dim3(kDecThreads),   \
+                       lds, stream, g, ws, d_packed, in_stride, d_sizes, d_out);                \
+  } while (0)
+    if (fused == 1) HIMG_FUSED_LAUNCH(false, 0);
+    else if (g.cols == 512) HIMG_FUSED_LAUNCH(true, 512);
+    else HIMG_FUSED_LAUNCH(true, 0);
+#undef HIMG_FUSED_LAUNCH
     prof_end(prof, stream);
   } else {
     HIMG_LAUNCH(k_dec_huff, dim3(g.rows + 1, batch), dim3(kDecThreads), g, ws, d_packed,

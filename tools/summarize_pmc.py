@@ -8,17 +8,34 @@ import os
 import sys
 
 root = sys.argv[1]
+
+
+def kname(full):
+    """'void himg_dev::k_x<8, true>(himg_dev::Geom, ...)' -> 'k_x<8, true>'"""
+    n = full.replace("himg_dev::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    depth = 0
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return n[:i]
+    return n
+
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 dur = collections.defaultdict(lambda: [0.0, 0])
 for path in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("himg_dev::", "")
+        k = kname(r["Kernel_Name"])
         a = acc[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"])
         a[1] += 1
 for path in glob.glob(os.path.join(root, "*", "*", "*kernel_trace.csv")):
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0].replace("himg_dev::", "")
+        k = kname(r["Kernel_Name"])
         d = dur[k]
         d[0] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
         d[1] += 1
