@@ -72,6 +72,10 @@ def lib():
     L.himg_hip_free.restype = None
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
     L.himg_hip_decode_device.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_shard_stats.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_shard_row_bits.argtypes = [vp, vp, vp, vp]
+    L.himg_hip_shard_emit.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.himg_hip_shard_assemble.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.himg_hip_debug_read.argtypes = [vp, i32, i32, vp, sz, P(sz)]
     L.himg_hip_profile_enable.argtypes = [vp, i32]
     L.himg_hip_profile_reset.argtypes = [vp]
@@ -190,6 +194,31 @@ class Engine:
                                           batch, width, height, channels, _ptr(d_out),
                                           _ptr(d_status), C.c_void_p(stream))
         self._check(rc, "decode_device")
+
+    # row-sharded encode (see himg_amd/sharded.py) --------------------------------------
+    def shard_stats(self, d_frame_base, width, height, pixel_stride, channels, quality, use_ycbcr,
+                    row0, row1, d_hist, d_low_rows, stream=0):
+        rc = lib().himg_hip_shard_stats(self._ctx, _ptr(d_frame_base), width, height, pixel_stride,
+                                        channels, quality, 1 if use_ycbcr else 0, row0, row1,
+                                        _ptr(d_hist), _ptr(d_low_rows), C.c_void_p(stream))
+        self._check(rc, "shard_stats")
+
+    def shard_row_bits(self, d_hist_global, d_row_bits, stream=0):
+        rc = lib().himg_hip_shard_row_bits(self._ctx, _ptr(d_hist_global), _ptr(d_row_bits),
+                                           C.c_void_p(stream))
+        self._check(rc, "shard_row_bits")
+
+    def shard_emit(self, d_all_row_bits, d_rel, rel_cap, d_rel_size, stream=0):
+        rc = lib().himg_hip_shard_emit(self._ctx, _ptr(d_all_row_bits), _ptr(d_rel), rel_cap,
+                                       _ptr(d_rel_size), C.c_void_p(stream))
+        self._check(rc, "shard_emit")
+
+    def shard_assemble(self, d_low_full, d_all_row_bits, d_rel, rel_bytes, d_out, out_cap, d_size,
+                       d_status, stream=0):
+        rc = lib().himg_hip_shard_assemble(self._ctx, _ptr(d_low_full), _ptr(d_all_row_bits),
+                                           _ptr(d_rel), rel_bytes, _ptr(d_out), out_cap,
+                                           _ptr(d_size), _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "shard_assemble")
 
     # introspection ---------------------------------------------------------------
     def debug_read(self, what, frame, nbytes, dtype=np.uint8, decoder=False):

@@ -126,6 +126,20 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused);
 
+// Row-sharded encode of one frame (multi-GPU): phases between the collectives.
+void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,
+                        const ShiftTables &st, const uint8_t *d_fmap_lut, int r0, int r1,
+                        hipStream_t stream, Profiler *prof);
+void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
+                           hipStream_t stream, Profiler *prof);
+void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
+                       const uint32_t *d_all_row_bits, uint8_t *d_rel, size_t rel_cap,
+                       uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof);
+void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &sc,
+                           const LresTables &lt, const uint32_t *d_all_row_bits,
+                           const uint8_t *d_rel, size_t rel_bytes, uint8_t *d_out, size_t out_cap,
+                           uint32_t *d_size, hipStream_t stream, Profiler *prof);
+
 // Stage timing hook: called before/after every kernel launch when profiling.
 void prof_begin(Profiler *p, const char *stage, hipStream_t s);
 void prof_end(Profiler *p, hipStream_t s);

@@ -119,6 +119,16 @@ struct himg_hip_ctx {
 
   // Staging for the host-buffer API.
   DevBuf h_in, h_out, h_sizes, h_status;
+
+  // Row-sharded encode state (himg_hip_shard_*).
+  struct {
+    bool valid = false;
+    Geom g{};
+    StaticChunks sc{};
+    ShiftTables st{};
+    LresTables lt{};
+    int r0 = 0, r1 = 0;
+  } shard;
 };
 
 static int fail(himg_hip_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
@@ -548,6 +558,86 @@ extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t 
   HIP_TRY(ctx, hipMemcpy(buf, ctx->h_out.p, out_bytes, hipMemcpyDeviceToHost));
   *out = buf;
   *width = W; *height = H; *num_channels = C;
+  return HIMG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Row-sharded encode of one frame over several GPUs (one context per rank).
+// ---------------------------------------------------------------------------
+extern "C" int himg_hip_shard_stats(himg_hip_ctx *ctx, const void *d_frame_base, int width,
+                                    int height, int pixel_stride, int num_channels, int quality,
+                                    int use_ycbcr, int row0, int row1, uint32_t *d_fres_hist,
+                                    uint8_t *d_low_rows, void *stream) {
+  if (!ctx || !d_frame_base || !d_fres_hist || !d_low_rows) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, pixel_stride, num_channels, use_ycbcr, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  if (row0 < 0 || row1 > g.rows || row0 >= row1 || g.rows > 65535)
+    return fail(ctx, HIMG_ERR_ARG, "bad block-row range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_enc_ws(ctx, g, 1);
+  if (rc) return rc;
+  auto &sh = ctx->shard;
+  rc = build_static(g, quality, &sh.sc, &sh.st, &sh.lt);
+  if (rc) return fail(ctx, rc, "unsupported table configuration");
+  sh.g = g; sh.r0 = row0; sh.r1 = row1; sh.valid = true;
+  hipStream_t s = (hipStream_t)stream;
+  launch_shard_stats(g, ctx->enc_ws, (const uint8_t *)d_frame_base, sh.st,
+                     (const uint8_t *)ctx->fmap_lut.p, row0, row1, s, &ctx->prof);
+  HIP_TRY(ctx, hipMemcpyAsync(d_fres_hist, ctx->enc_ws.hist + kHistStride, kNumSym * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
+  const size_t n = (size_t)(row1 - row0) * g.cols;
+  for (int c = 0; c < g.C; ++c)
+    HIP_TRY(ctx, hipMemcpyAsync(d_low_rows + (size_t)c * n,
+                                ctx->enc_ws.low + ((size_t)c * g.rows + row0) * g.cols, n,
+                                hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_shard_row_bits(himg_hip_ctx *ctx, const uint32_t *d_fres_hist_global,
+                                       uint32_t *d_row_bits, void *stream) {
+  if (!ctx || !ctx->shard.valid || !d_fres_hist_global || !d_row_bits) return HIMG_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  auto &sh = ctx->shard;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->enc_ws.hist + kHistStride, d_fres_hist_global,
+                              kNumSym * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+  launch_shard_row_bits(sh.g, ctx->enc_ws, sh.r0, sh.r1, d_row_bits, s, &ctx->prof);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_shard_emit(himg_hip_ctx *ctx, const uint32_t *d_all_row_bits, void *d_rel,
+                                   size_t rel_cap, uint32_t *d_rel_size, void *stream) {
+  if (!ctx || !ctx->shard.valid || !d_all_row_bits || !d_rel || !d_rel_size) return HIMG_ERR_ARG;
+  if ((rel_cap & 3) || ((uintptr_t)d_rel & 15)) return fail(ctx, HIMG_ERR_ARG, "bad relative buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto &sh = ctx->shard;
+  hipStream_t s = (hipStream_t)stream;
+  launch_shard_emit(sh.g, ctx->enc_ws, sh.sc, d_all_row_bits, (uint8_t *)d_rel, rel_cap, d_rel_size,
+                    sh.r0, sh.r1, s, &ctx->prof);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_shard_assemble(himg_hip_ctx *ctx, const uint8_t *d_low_full,
+                                       const uint32_t *d_all_row_bits, const void *d_rel,
+                                       size_t rel_bytes, void *d_out, size_t out_cap,
+                                       uint32_t *d_size, int32_t *d_status, void *stream) {
+  if (!ctx || !ctx->shard.valid || !d_low_full || !d_all_row_bits || !d_rel || !d_out || !d_size)
+    return HIMG_ERR_ARG;
+  if ((out_cap & 255) || ((uintptr_t)d_out & 15)) return fail(ctx, HIMG_ERR_ARG, "bad output buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto &sh = ctx->shard;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->enc_ws.low, d_low_full, (size_t)sh.g.C * sh.g.rows * sh.g.cols,
+                              hipMemcpyDeviceToDevice, s));
+  launch_shard_assemble(sh.g, ctx->enc_ws, sh.sc, sh.lt, d_all_row_bits, (const uint8_t *)d_rel,
+                        rel_bytes, (uint8_t *)d_out, out_cap, d_size, s, &ctx->prof);
+  if (d_status)
+    hipLaunchKernelGGL(k_copy_status, dim3(1), dim3(64), 0, s, ctx->enc_ws.status, d_status, 1);
+  HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }
 

@@ -58,9 +58,9 @@ __device__ __forceinline__ void load_pixel(const uint8_t *img, const Geom &g, in
 // [8v-3, 8v+4], clipped to the image (downsampled.cpp:76-96).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lowres_avg(Geom g, const uint8_t *frames,
-                                                    uint8_t *avg, size_t plane_stride) {
+                                                    uint8_t *avg, size_t plane_stride, int v0) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y, f = blockIdx.z;
+  const int v = blockIdx.y + v0, f = blockIdx.z;
   if (u >= g.cols) return;
   const uint8_t *img = frames + (long long)f * g.frame_bytes;
   const int x0 = max(0, 8 * u - 3), x1 = min(g.W - 1, 8 * u + 4);
@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256) void k_lowres_avg(Geom g, const uint8_t *frame
 
 // k_lowres_blend: m = blend of the averages at (v-1,v) x (u-1,u) (downsampled.cpp:98-113).
 __global__ __launch_bounds__(256) void k_lowres_blend(Geom g, const uint8_t *avg, uint8_t *low,
-                                                      size_t plane_stride) {
+                                                      size_t plane_stride, int v0) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y;
+  const int v = blockIdx.y + v0;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
   if (u >= g.cols) return;
   const uint8_t *a = avg + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
@@ -273,9 +273,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_fwd(Geom g, const uint8_t
                                                   const uint8_t *low, size_t plane_stride,
                                                   uint8_t *fres_sym, size_t fres_stride,
                                                   const uint8_t *__restrict__ fmap_lut,
-                                                  ShiftTables st) {
+                                                  ShiftTables st, int v0) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y, f = blockIdx.z;
+  const int v = blockIdx.y + v0, f = blockIdx.z;
   if (u >= g.cols) return;
   const uint8_t *img = frames + (long long)f * g.frame_bytes;
   const int bw = min(8, g.W - 8 * u), bh = min(8, g.H - 8 * v);
@@ -556,10 +556,10 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
 }
 
 // k_tok_hist: token histogram of one span (huffman_enc.cpp:98-144).
-__global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws) {
+__global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
   __shared__ ZR sm[4];
-  const int sp = blockIdx.x, f = blockIdx.y;
+  const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
   for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
   ZR carry;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws) {
 // becomes child_a (bit 0).  Then a pre-order walk serialises the tree and
 // assigns LSB-first codes (huffman_enc.cpp:148-180).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_tree(EncWs ws) {
+__global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   __shared__ int cnt[2 * kNumSym];
   __shared__ short ca[2 * kNumSym], cb[2 * kNumSym], nsym[2 * kNumSym];
   __shared__ uint32_t bits[kTreeStride / 4];
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws) {
   __shared__ uint64_t stk_code[kNumSym + 8];
   __shared__ int s_num;
 
-  const int strm = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  const int strm = blockIdx.x + strm0, f = blockIdx.y, lane = threadIdx.x;
   const size_t tab = ((size_t)f * 2 + strm) * kHistStride;
   const uint32_t *hist = ws.hist + tab;
   uint64_t *codes = ws.codes + tab;
@@ -708,8 +708,14 @@ __device__ __forceinline__ int extra_bits_of(int sym) {
 // serialised trees, QCFG/FMAP/'FRES', the per-row size headers
 // (huffman_enc.cpp:342-352) and all size fields (encoder.cpp:131-137,347-350).
 // ---------------------------------------------------------------------------
+// row_bits_in (optional): payload bits of EVERY block row, used instead of the
+// local span histograms (multi-GPU: rows live on other ranks).
+// fres_rel != 0: lay out the FRES rows only, relative to the first row header
+// (no LRES, no container, no tree) -- every rank of a row-sharded encode runs
+// this identically and emits its rows at the same relative offsets.
 __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc, uint8_t *out,
-                                               size_t out_stride, uint32_t *sizes) {
+                                               size_t out_stride, uint32_t *sizes,
+                                               const uint32_t *row_bits_in, int fres_rel) {
   __shared__ uint32_t sm[4];
   __shared__ uint32_t cost[2][kHistStride];
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -723,12 +729,12 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
     cost[s][sym] = sym < kNumSym ? ws.lens[((size_t)f * 2 + s) * kHistStride + sym] + extra_bits_of(sym) : 0;
   }
   __syncthreads();
-  const uint32_t tree_l = ws.tree_nbytes[(size_t)f * 2 + 0];
-  const uint32_t tree_f = ws.tree_nbytes[(size_t)f * 2 + 1];
+  const uint32_t tree_l = fres_rel ? 0u : ws.tree_nbytes[(size_t)f * 2 + 0];
+  const uint32_t tree_f = fres_rel ? 0u : ws.tree_nbytes[(size_t)f * 2 + 1];
 
   // LRES spans: one continuous bit stream after the byte-aligned tree.
   unsigned long long run = 8ull * (kHeadLen + tree_l);
-  for (int base = 0; base < g.lres_spans; base += 256) {
+  for (int base = 0; base < (fres_rel ? 0 : g.lres_spans); base += 256) {
     const int s = base + tid;
     uint32_t b = 0;
     if (s < g.lres_spans) {
@@ -744,14 +750,19 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
   const uint32_t lres_bytes = (uint32_t)(((lres_end_bit + 7) >> 3) - kHeadLen);
 
   // FRES rows: byte aligned payloads, each behind a 2- or 4-byte size header.
-  const unsigned long long fres_base = (unsigned long long)kHeadLen + lres_bytes + sc.mid_len;
+  const unsigned long long fres_base =
+      fres_rel ? 0ull : (unsigned long long)kHeadLen + lres_bytes + sc.mid_len;
   unsigned long long pos = fres_base + tree_f;  // running byte position
   for (int base = 0; base < g.rows; base += 256) {
     const int r = base + tid;
     uint32_t b = 0, nbytes = 0, hdr = 0;
     if (r < g.rows) {
-      const uint32_t *h = ws.span_hist_f + ((size_t)f * g.rows + r) * kHistStride;
-      for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[1][k];
+      if (row_bits_in) {
+        b = row_bits_in[r];
+      } else {
+        const uint32_t *h = ws.span_hist_f + ((size_t)f * g.rows + r) * kHistStride;
+        for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[1][k];
+      }
       nbytes = (b + 7) >> 3;
       hdr = g.use_blocks ? (nbytes <= 0x7fffu ? 2u : 4u) : 0u;
     }
@@ -780,7 +791,7 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
     if (!fits) atomicMax(&ws.status[f], 5);
     sizes[f] = (fits && ws.status[f] == 0) ? (uint32_t)total : 0u;
   }
-  if (!fits) return;
+  if (!fits || fres_rel) return;
 
   // Static container bytes with the data-dependent size fields patched in.
   for (int k = tid; k < kHeadLen; k += 256) {
@@ -811,14 +822,14 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
 constexpr int kStageWords = 6144;  // >= (31 + (4096+32)*46) / 32
 
 __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
-                                              const uint32_t *sizes) {
+                                              const uint32_t *sizes, int sp0) {
   __shared__ uint32_t stage[kStageWords];
   __shared__ uint32_t s_code[kHistStride];
   __shared__ uint8_t s_len[kHistStride];
   __shared__ ZR sm_zr[4];
   __shared__ uint32_t sm_u[4];
 
-  const int sp = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int sp = blockIdx.x + sp0, f = blockIdx.y, tid = threadIdx.x;
   if (sizes[f] == 0) return;  // frame failed (status says why)
   const Span s = get_span(g, ws, sp, f);
   const int nsp = g.lres_spans + g.rows;
@@ -952,6 +963,41 @@ __global__ __launch_bounds__(256) void k_padfix(Geom g, EncWs ws, uint8_t *out, 
 }
 
 // ---------------------------------------------------------------------------
+// Row-sharded (multi-GPU) helpers.
+// ---------------------------------------------------------------------------
+
+// Payload bits of the local block rows [r0, r0+n) from their span histograms and
+// the (globally agreed) FRES code lengths.
+__global__ __launch_bounds__(256) void k_row_bits(Geom g, EncWs ws, int r0, int n, uint32_t *bits_out) {
+  __shared__ uint32_t cost[kHistStride];
+  for (int k = threadIdx.x; k < kHistStride; k += 256)
+    cost[k] = k < kNumSym ? ws.lens[(size_t)1 * kHistStride + k] + extra_bits_of(k) : 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *h = ws.span_hist_f + (size_t)(r0 + i) * kHistStride;
+  uint32_t b = 0;
+  for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[k];
+  bits_out[i] = b;
+}
+
+// Copy the gathered FRES rows (headers + payloads, laid out relative to the first
+// row header) behind the FRES tree of the final stream.  The destination offset
+// is data dependent (LRES size) and lives on the device.
+__global__ __launch_bounds__(256) void k_place_fres(Geom g, EncWs ws, const uint8_t *rel,
+                                                    size_t rel_bytes, uint8_t *out,
+                                                    const uint32_t *sizes) {
+  if (sizes[0] == 0) return;
+  const uint32_t b0 = ws.span_bits[g.lres_spans];  // row 0
+  const uint32_t n0 = (b0 + 7) >> 3;
+  const uint32_t hdr0 = g.use_blocks ? (n0 <= 0x7fffu ? 2u : 4u) : 0u;
+  uint8_t *dst = out + (ws.span_bit0[g.lres_spans] >> 3) - hdr0;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < rel_bytes;
+       k += (size_t)gridDim.x * blockDim.x)
+    dst[k] = rel[k];
+}
+
+// ---------------------------------------------------------------------------
 // Host-side launch sequence.
 // ---------------------------------------------------------------------------
 #define HIMG_LAUNCH(name, grid, block, ...)                    \
@@ -981,31 +1027,105 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   }
   prof_end(prof, stream);
 
-  HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride);
+  HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride, 0);
   HIMG_LAUNCH(k_lowres_blend, dim3(gx, g.rows, batch * g.C), b256, g, ws.avg, ws.low,
-              ws.plane_stride);
+              ws.plane_stride, 0);
   HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws.low,
               ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
   if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
     if (g.cols == 512) {
       HIMG_LAUNCH((k_tile_fwd<true, 512>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g,
-                  d_frames, ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+                  d_frames, ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
     } else {
       HIMG_LAUNCH((k_tile_fwd<true, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g,
-                  d_frames, ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+                  d_frames, ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
     }
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,
-                ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st);
+                ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
-  HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws);
-  HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws);
-  HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes);
-  HIMG_LAUNCH(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes);
+  HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
+  HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws, 0);
+  HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
+              (const uint32_t *)nullptr, 0);
+  HIMG_LAUNCH(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes, 0);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 255) / 256, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
+}
+
+// ---- row-sharded encode of ONE frame (see himg_hip.h, "row-sharded encode") ----
+
+static void launch_tile_rows(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,
+                             const ShiftTables &st, const uint8_t *d_fmap_lut, int r0, int n,
+                             hipStream_t stream, Profiler *prof) {
+  const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
+  if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
+    if (g.cols == 512) {
+      HIMG_LAUNCH((k_tile_fwd<true, 512>), dim3(gxt, n, 1), dim3(kTileThreads), g, d_frame_base,
+                  ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, r0);
+    } else {
+      HIMG_LAUNCH((k_tile_fwd<true, 0>), dim3(gxt, n, 1), dim3(kTileThreads), g, d_frame_base,
+                  ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, r0);
+    }
+  } else {
+    HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, n, 1), dim3(kTileThreads), g, d_frame_base,
+                ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, r0);
+  }
+}
+
+void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,
+                        const ShiftTables &st, const uint8_t *d_fmap_lut, int r0, int r1,
+                        hipStream_t stream, Profiler *prof) {
+  const dim3 b256(256);
+  const unsigned gx = (unsigned)((g.cols + 255) / 256);
+  (void)hipMemsetAsync(ws.hist, 0, 2 * kHistStride * sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(ws.status, 0, sizeof(int32_t), stream);
+  // low[v] needs avg[v-1..v]; the tiles of row v need low[v..v+1].
+  const int a0 = r0 > 0 ? r0 - 1 : 0, a1 = r1 < g.rows ? r1 + 1 : g.rows;
+  const int l1 = r1 < g.rows ? r1 + 1 : g.rows;
+  HIMG_LAUNCH(k_lowres_avg, dim3(gx, a1 - a0, 1), b256, g, d_frame_base, ws.avg, ws.plane_stride, a0);
+  HIMG_LAUNCH(k_lowres_blend, dim3(gx, l1 - r0, g.C), b256, g, ws.avg, ws.low, ws.plane_stride, r0);
+  launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
+  HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
+}
+
+void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
+                           hipStream_t stream, Profiler *prof) {
+  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(64), ws, 1);
+  HIMG_LAUNCH(k_row_bits, dim3((r1 - r0 + 255) / 256), dim3(256), g, ws, r0, r1 - r0, d_bits_out);
+}
+
+void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
+                       const uint32_t *d_all_row_bits, uint8_t *d_rel, size_t rel_cap,
+                       uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof) {
+  HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1);
+  HIMG_LAUNCH(k_emit, dim3(r1 - r0, 1), dim3(256), g, ws, d_rel, rel_cap, d_rel_size,
+              g.lres_spans + r0);
+}
+
+void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &sc,
+                           const LresTables &lt, const uint32_t *d_all_row_bits,
+                           const uint8_t *d_rel, size_t rel_bytes, uint8_t *d_out, size_t out_cap,
+                           uint32_t *d_size, hipStream_t stream, Profiler *prof) {
+  const dim3 b256(256);
+  (void)hipMemsetAsync(ws.hist, 0, kHistStride * sizeof(uint32_t), stream);  // LRES histogram only
+  {
+    const size_t start = (size_t)(kHeadLen & ~3);
+    size_t width = (size_t)g.lres_size + kTreeStride + 64;
+    if (start + width > out_cap) width = out_cap - start;
+    (void)hipMemsetAsync(d_out + start, 0, width, stream);
+  }
+  HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, g.C), dim3(64), g, ws.low, ws.plane_stride,
+              ws.lres_sym, ws.lres_stride, lt);
+  HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, 1), b256, g, ws);
+  HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, 1), b256, g, ws, 0);
+  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(64), ws, 0);
+  HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0);
+  HIMG_LAUNCH(k_emit, dim3(g.lres_spans, 1), b256, g, ws, d_out, out_cap, d_size, 0);
+  HIMG_LAUNCH(k_place_fres, dim3(1024), b256, g, ws, d_rel, rel_bytes, d_out, d_size);
+  HIMG_LAUNCH(k_padfix, dim3((g.rows + 255) / 256, 1), b256, g, ws, d_out, out_cap, d_size);
 }
 
 }  // namespace himg_dev

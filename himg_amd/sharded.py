@@ -1,0 +1,198 @@
+"""Row-sharded encode of ONE large frame over several GPUs (BASELINE config 4).
+
+FRES block rows are independently coded units behind size headers (reference
+huffman_enc.cpp:342-358), so the frame shards by block rows, aligned to 16 rows
+(one low-res macro-block row).  One process per GPU; this module runs the
+collectives of SURVEY.md 8(e) between the device phases of the C ABI
+(include/himg_hip.h, himg_hip_shard_*):
+
+    stats      -> all-reduce(sum) 261-bin FRES token histogram   (1 KiB, latency bound)
+               -> gather low-res rows to rank 0                  (1/64 of the pixels)
+    row_bits   -> all-gather payload bits of every block row     (rows x u32)
+    emit       -> gather the packed rows to rank 0               (the only large message;
+                                                                   each peer -> rank 0 over
+                                                                   its own xGMI link)
+    assemble   (rank 0) LRES stream, container, FRES tree, rows, stale pad bits
+
+The result on rank 0 is byte-identical to encoding the whole frame on one GPU.
+`backend` hides the device: EngineBackend drives the HIP engine; the tests use a
+stub to exercise exactly this orchestration under gloo on CPU.
+"""
+import numpy as np
+
+
+def shard_rows(rows, world):
+    """Split `rows` block rows over `world` ranks in multiples of 16 rows (a
+    low-res macro-block row never straddles two ranks).  Ranks may get nothing."""
+    macro = (rows + 15) // 16
+    out = []
+    for r in range(world):
+        m0 = macro * r // world
+        m1 = macro * (r + 1) // world
+        out.append((min(16 * m0, rows), min(16 * m1, rows)))
+    return out
+
+
+def fres_layout(row_bits, use_blocks):
+    """Byte layout of the FRES rows relative to the first row header
+    (huffman_enc.cpp:342-358): per row a 2-byte size header, or 4 bytes when the
+    payload exceeds 0x7fff bytes; none for single-row images.
+    Returns (header_off, payload_off, nbytes, total)."""
+    bits = np.asarray(row_bits, np.int64)
+    nbytes = (bits + 7) >> 3
+    hdr = np.where(nbytes <= 0x7FFF, 2, 4) if use_blocks else np.zeros_like(nbytes)
+    step = hdr + nbytes
+    header_off = np.concatenate([[0], np.cumsum(step)[:-1]]) if len(step) else np.zeros(0, np.int64)
+    return header_off, header_off + hdr, nbytes, int(step.sum())
+
+
+def piece_range(layout, r0, r1):
+    """Byte range [start, end) of rows [r0, r1) in the relative FRES layout."""
+    header_off, payload_off, nbytes, total = layout
+    if r0 >= r1:
+        return 0, 0
+    return int(header_off[r0]), int(payload_off[r1 - 1] + nbytes[r1 - 1])
+
+
+def _pad(t, n):
+    import torch
+    if t.numel() == n:
+        return t.contiguous()
+    out = torch.zeros(n, dtype=t.dtype, device=t.device)
+    out[: t.numel()] = t.reshape(-1)
+    return out
+
+
+def encode_sharded(backend, rows, cols, channels, use_blocks, group=None):
+    """Run the sharded encode.  Returns the packed stream (uint8 numpy array) on
+    rank 0 and None elsewhere.  `backend` provides:
+        stats(r0, r1)          -> (hist int64[261], low uint8[C*(r1-r0)*cols])   comm tensors
+        row_bits(hist_global)  -> int32[r1-r0]
+        emit(all_bits int32[rows], start, end) -> uint8[end-start]   (the local byte range)
+        assemble(low_full uint8[C*rows*cols], all_bits, rel_full uint8[total]) -> numpy uint8
+    All tensors live where the process group can move them (CUDA for nccl/RCCL,
+    CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    parts = shard_rows(rows, world)
+    r0, r1 = parts[rank]
+    max_rows = max(b - a for a, b in parts)
+
+    hist, low = backend.stats(r0, r1)
+    if world > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)        # 261 x i64, latency bound
+    # Low-res rows to rank 0 (1/64 of the pixels): padded gather.
+    low_pad = _pad(low, channels * max_rows * cols)
+    if world > 1:
+        low_list = [torch.empty_like(low_pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(low_pad, low_list, dst=0, group=group)
+    else:
+        low_list = [low_pad]
+
+    bits = backend.row_bits(hist)
+    bits_pad = _pad(bits, max_rows)
+    if world > 1:
+        bits_list = [torch.empty_like(bits_pad) for _ in range(world)]
+        dist.all_gather(bits_list, bits_pad, group=group)                 # rows x i32
+    else:
+        bits_list = [bits_pad]
+    all_bits = torch.cat([b[: (p1 - p0)] for b, (p0, p1) in zip(bits_list, parts)])
+    layout = fres_layout(all_bits.cpu().numpy(), use_blocks)
+    ranges = [piece_range(layout, p0, p1) for p0, p1 in parts]
+    max_piece = max(e - s for s, e in ranges)
+
+    start, end = ranges[rank]
+    piece = backend.emit(all_bits, start, end)
+    piece_pad = _pad(piece, max_piece)
+    if world > 1:
+        piece_list = [torch.empty_like(piece_pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(piece_pad, piece_list, dst=0, group=group)           # the large message
+    else:
+        piece_list = [piece_pad]
+    if rank != 0:
+        return None
+
+    total = layout[3]
+    rel_full = torch.empty(total, dtype=torch.uint8, device=piece.device)
+    for pl, (s, e) in zip(piece_list, ranges):
+        rel_full[s:e] = pl[: e - s]
+    low_full = torch.empty(channels * rows * cols, dtype=torch.uint8, device=low.device)
+    lf = low_full.view(channels, rows, cols)
+    for ll, (p0, p1) in zip(low_list, parts):
+        if p1 > p0:
+            lf[:, p0:p1, :] = ll[: channels * (p1 - p0) * cols].view(channels, p1 - p0, cols)
+    return backend.assemble(low_full, all_bits, rel_full)
+
+
+class EngineBackend:
+    """Device phases on the HIP engine.  `d_frame` is this rank's view of the
+    frame: a CUDA uint8 tensor holding pixel rows [y_first, y_first + n) of the
+    W x H image (at least rows 8*r0-11 .. 8*r1+4 clipped to the image)."""
+
+    def __init__(self, engine, d_frame, y_first, width, height, quality=50, use_ycbcr=True,
+                 comm_device=None, stream=0):
+        import torch
+        self.eng, self.W, self.H, self.q, self.ycbcr = engine, width, height, quality, use_ycbcr
+        self.d_frame, self.y_first, self.stream = d_frame, y_first, stream
+        self.dev = d_frame.device
+        self.comm = torch.device(comm_device) if comm_device is not None else self.dev
+        self.rows, self.cols, self.C = (height + 7) // 8, (width + 7) // 8, 4
+        self.r0 = self.r1 = 0
+
+    def _to_comm(self, t):
+        return t.to(self.comm) if t.device != self.comm else t
+
+    def stats(self, r0, r1):
+        import torch
+        self.r0, self.r1 = r0, r1
+        hist = torch.zeros(264, dtype=torch.int32, device=self.dev)
+        low = torch.zeros(max(1, self.C * (r1 - r0) * self.cols), dtype=torch.uint8, device=self.dev)
+        if r1 > r0:
+            base = self.d_frame.data_ptr() - self.y_first * self.W * 4   # virtual frame base
+            self.eng.shard_stats(base, self.W, self.H, 4, 4, self.q, self.ycbcr, r0, r1, hist, low,
+                                 self.stream)
+        torch.cuda.synchronize(self.dev)
+        h64 = (hist[:261].to(torch.int64) & 0xFFFFFFFF)
+        return self._to_comm(h64), self._to_comm(low[: self.C * (r1 - r0) * self.cols])
+
+    def row_bits(self, hist_global):
+        import torch
+        n = self.r1 - self.r0
+        bits = torch.zeros(max(1, n), dtype=torch.int32, device=self.dev)
+        if n > 0:
+            h32 = torch.zeros(264, dtype=torch.int32, device=self.dev)
+            h32[:261] = hist_global.to(self.dev).to(torch.int32)
+            self.eng.shard_row_bits(h32, bits, self.stream)
+            torch.cuda.synchronize(self.dev)
+        return self._to_comm(bits[:n])
+
+    def emit(self, all_bits, start, end):
+        import torch
+        if end <= start:
+            return torch.zeros(0, dtype=torch.uint8, device=self.comm)
+        cap = (self.rows * self.cols * 64 * self.C + 4 * self.rows + 256 + 255) // 256 * 256
+        rel = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        size = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        self._all_bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
+        self.eng.shard_emit(self._all_bits_dev, rel, cap, size, self.stream)
+        torch.cuda.synchronize(self.dev)
+        return self._to_comm(rel[start:end])
+
+    def assemble(self, low_full, all_bits, rel_full):
+        import torch
+        import himg_amd
+        cap = himg_amd.max_packed_size(self.W, self.H, self.C)
+        out = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        size = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        status = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
+        rel_dev = rel_full.to(self.dev).contiguous()
+        self.eng.shard_assemble(low_full.to(self.dev).contiguous(), bits_dev, rel_dev, rel_dev.numel(),
+                                out, cap, size, status, self.stream)
+        torch.cuda.synchronize(self.dev)
+        if int(status[0]) != 0:
+            raise himg_amd.HimgError(-int(status[0]), "sharded assemble failed")
+        return out[: int(size[0])].cpu().numpy()

@@ -96,6 +96,46 @@ int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, size_t in_st
                            int num_channels, void *d_out, int32_t *d_status,
                            void *stream);
 
+/* ---- row-sharded encode of ONE frame over several GPUs -------------------- */
+/*
+ * FRES block rows are independently coded units behind size headers
+ * (reference huffman_enc.cpp:342-358), so one large frame shards by block rows:
+ * rank r owns rows [row0, row1) (multiples of 16 = one low-res macro-block row,
+ * except the last).  One context per rank; the host runs the collectives
+ * (himg_amd/sharded.py: RCCL via torch.distributed) between the phases:
+ *
+ *   shard_stats     local rows: colour lift, low-res rows, tiles -> symbols, token
+ *                   histogram.  Reads pixel rows [8*row0-11, 8*row1+5) of the
+ *                   frame only (d_frame_base may be a virtual base pointer).
+ *                   Out: local FRES histogram (261 x u32), low-res rows
+ *                   [C][row1-row0][cols].
+ *     -> all-reduce(sum) of the histograms; gather of the low-res rows to rank 0
+ *   shard_row_bits  Huffman tree from the GLOBAL histogram (identical on every
+ *                   rank, reference tie-breaking), payload bits of the local rows.
+ *     -> all-gather of the row bit counts
+ *   shard_emit      lay out ALL rows relative to the first row header (same on
+ *                   every rank), pack the local rows into d_rel (capacity rel_cap >=
+ *                   FRES symbols + 4*rows, 16-byte aligned) at those offsets; the
+ *                   local byte range follows from the row bit counts
+ *                   (himg_amd.sharded.fres_layout).
+ *     -> gather of the byte ranges to rank 0
+ *   shard_assemble  rank 0: LRES stream from the gathered low-res plane, container,
+ *                   FRES tree, the gathered rows, stale pad bits (trap T1).
+ * The result is byte-identical to himg_hip_encode of the whole frame.
+ */
+int himg_hip_shard_stats(himg_hip_ctx *ctx, const void *d_frame_base, int width, int height,
+                         int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                         int row0, int row1, uint32_t *d_fres_hist, uint8_t *d_low_rows,
+                         void *stream);
+int himg_hip_shard_row_bits(himg_hip_ctx *ctx, const uint32_t *d_fres_hist_global,
+                            uint32_t *d_row_bits, void *stream);
+int himg_hip_shard_emit(himg_hip_ctx *ctx, const uint32_t *d_all_row_bits, void *d_rel,
+                        size_t rel_cap, uint32_t *d_rel_size, void *stream);
+int himg_hip_shard_assemble(himg_hip_ctx *ctx, const uint8_t *d_low_full,
+                            const uint32_t *d_all_row_bits, const void *d_rel, size_t rel_bytes,
+                            void *d_out, size_t out_cap, uint32_t *d_size, int32_t *d_status,
+                            void *stream);
+
 /* ---- introspection for parity tests and bench.py ------------------------ */
 
 /* Intermediate device buffers of the LAST encode/decode on this context

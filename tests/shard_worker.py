@@ -1,0 +1,127 @@
+"""Worker for the multi-process sharded-encode tests (one process per rank).
+
+    python tests/shard_worker.py <mode> <kind> <seed> <W> <H> <q> <outfile>
+mode = stub : CPU only, gloo, device phases replaced by a stub built from the
+              oracle's trace (checks partitioning, collectives, layout, placement)
+mode = gpu  : every rank drives the HIP engine on cuda:0, collectives over gloo
+              with CPU staging (the GPU box has one GPU; RCCL needs one per rank)
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the environment.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import himg_amd  # noqa: E402
+from himg_amd import sharded  # noqa: E402
+
+
+def riff_chunks(stream):
+    out, idx = {}, 12
+    while idx + 8 <= len(stream):
+        tag = bytes(stream[idx:idx + 4]).decode("latin1")
+        sz = int.from_bytes(bytes(stream[idx + 4:idx + 8]), "little")
+        out[tag] = (idx + 8, sz)
+        idx += 8 + sz
+    return out
+
+
+def row_token_hist(row):
+    """Token histogram of one block row (huffman_enc.cpp:98-144), numpy."""
+    h = np.zeros(261, np.int64)
+    nz = np.flatnonzero(row)
+    np.add.at(h, row[nz].astype(np.int64), 1)
+    edges = np.concatenate([[-1], nz, [row.size]])
+    runs = np.diff(edges) - 1
+    for r in runs[runs > 0]:
+        r = int(r)
+        while r >= 16662:
+            h[260] += 1
+            r -= 16662
+        if r == 1:
+            h[0] += 1
+        elif r == 2:
+            h[256] += 1
+        elif 3 <= r <= 6:
+            h[257] += 1
+        elif 7 <= r <= 22:
+            h[258] += 1
+        elif 23 <= r <= 278:
+            h[259] += 1
+        elif r >= 279:
+            h[260] += 1
+    return h
+
+
+class StubBackend:
+    """Device phases answered from the oracle's trace of the WHOLE frame."""
+
+    def __init__(self, img, q):
+        import oracle_lib as ol
+        self.stream, self.tr = ol.oracle_encode(img, q, True, trace=True)
+        self.rows, self.cols, self.C = self.tr["rows"], self.tr["cols"], 4
+        self.row_block = self.cols * self.C * 64
+        self.chunks = riff_chunks(self.stream)
+        self.extra = np.array([0] * 257 + [2, 4, 8, 14], np.int64)
+
+    def stats(self, r0, r1):
+        self.r0, self.r1 = r0, r1
+        sym = self.tr["fres_sym"].reshape(self.rows, self.row_block)
+        self.row_hists = [row_token_hist(sym[r]) for r in range(r0, r1)]
+        hist = np.sum(self.row_hists, axis=0) if r1 > r0 else np.zeros(261, np.int64)
+        low = self.tr["lowres"].reshape(self.C, self.rows, self.cols)[:, r0:r1, :]
+        return torch.from_numpy(hist.astype(np.int64)), torch.from_numpy(np.ascontiguousarray(low).ravel())
+
+    def row_bits(self, hist_global):
+        assert np.array_equal(hist_global.numpy(), self.tr["fres_hist"].astype(np.int64)), \
+            "all-reduced histogram differs from the whole-frame histogram"
+        cost = self.tr["fres_len"].astype(np.int64) + self.extra
+        bits = [int((h * cost).sum()) for h in self.row_hists]
+        return torch.tensor(bits, dtype=torch.int32)
+
+    def emit(self, all_bits, start, end):
+        off, sz = self.chunks["FRES"]
+        rel = self.stream[off + self.tr["fres_tree_bytes"]: off + sz]
+        return torch.from_numpy(rel[start:end].copy())
+
+    def assemble(self, low_full, all_bits, rel_full):
+        assert np.array_equal(low_full.numpy(), self.tr["lowres"]), "gathered low-res plane is wrong"
+        off, sz = self.chunks["FRES"]
+        head = self.stream[: off + self.tr["fres_tree_bytes"]]
+        assert rel_full.numel() == sz - self.tr["fres_tree_bytes"]
+        return np.concatenate([head, rel_full.numpy()])
+
+
+def main():
+    mode, kind, seed, W, H, q, outfile = sys.argv[1:8]
+    seed, W, H, q = int(seed), int(W), int(H), int(q)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    img = himg_amd.synth(kind, seed, W, H)
+    rows, cols = (H + 7) // 8, (W + 7) // 8
+    if mode == "stub":
+        backend = StubBackend(img, q)
+    else:
+        eng = himg_amd.Engine(0)
+        r0, r1 = sharded.shard_rows(rows, world)[rank]
+        # This rank only uploads its shard plus the halo (11 pixel rows above, 5 below).
+        y0, y1 = max(0, 8 * r0 - 11), min(H, 8 * r1 + 5)
+        if r1 <= r0:
+            y0, y1 = 0, 1
+        d_shard = torch.from_numpy(np.ascontiguousarray(img[y0:y1])).to("cuda:0")
+        backend = sharded.EngineBackend(eng, d_shard, y0, W, H, q, True, comm_device="cpu")
+    out = sharded.encode_sharded(backend, rows, cols, 4, rows > 1)
+    if rank == 0:
+        np.asarray(out, np.uint8).tofile(outfile)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""Row-sharded (multi-GPU) encode: partitioning, layout math, the collectives
+under gloo with world_size 2 and 3 on CPU, and (GPU) the device phases."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import himg_amd
+import oracle_lib as ol
+from himg_amd import sharded
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "shard_worker.py")
+
+
+def test_shard_rows_is_a_16_aligned_partition():
+    for rows in (1, 8, 15, 16, 17, 64, 135, 512, 2048):
+        for world in (1, 2, 3, 4, 8):
+            parts = sharded.shard_rows(rows, world)
+            assert parts[0][0] == 0 and parts[-1][1] == rows
+            for (a0, a1), (b0, b1) in zip(parts, parts[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert all(a % 16 == 0 for a, _ in parts)
+    assert sharded.shard_rows(512, 8) == [(64 * i, 64 * i + 64) for i in range(8)]
+
+
+def test_fres_layout_matches_reference_stream():
+    img = himg_amd.synth("randtile", 3, 256, 512)
+    for q in (10, 90):   # 2-byte headers only / a mix with payloads above 0x7fff? (small rows: all 2-byte)
+        stream, tr = ol.oracle_encode(img, q, True, trace=True)
+        layout = sharded.fres_layout(tr["fres_row_bytes"].astype(np.int64) * 8, True)
+        idx = 12
+        while bytes(stream[idx:idx + 4]) != b"FRES":
+            idx += 8 + int.from_bytes(bytes(stream[idx + 4:idx + 8]), "little")
+        size = int.from_bytes(bytes(stream[idx + 4:idx + 8]), "little")
+        base = idx + 8 + tr["fres_tree_bytes"]
+        assert layout[3] == size - tr["fres_tree_bytes"]
+        for r in range(tr["rows"]):
+            n = int(tr["fres_row_bytes"][r])
+            h = base + int(layout[0][r])
+            assert int(stream[h]) | (int(stream[h + 1]) << 8) == n   # 2-byte header
+            assert int(layout[1][r]) - int(layout[0][r]) == 2
+    # 4-byte headers above 0x7fff payload bytes
+    lay = sharded.fres_layout([8 * 0x7FFF, 8 * 0x8000, 9], True)
+    assert list(lay[1] - lay[0]) == [2, 4, 2] and lay[2][2] == 2
+    assert sharded.fres_layout([100], False)[3] == 13
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(world, args, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, WORKER] + [str(a) for a in args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 256, 512), (3, 128, 520), (2, 64, 16)])
+def test_sharded_orchestration_gloo_cpu(tmp_path, world, w, h):
+    """world_size > 1 over gloo on CPU: the device phases are answered by a stub
+    built from the oracle, everything else is the product's orchestration."""
+    out = tmp_path / "out.himg"
+    _run_ranks(world, ["stub", "randtile", 4, w, h, 50, out])
+    want = ol.oracle_encode(himg_amd.synth("randtile", 4, w, h), 50, True)
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,q,parts", [
+    ("randtile", 256, 512, 50, 2), ("randtile", 512, 1024, 50, 4), ("gradn", 256, 264, 90, 3),
+    ("rand", 128, 512, 50, 2), ("randtile", 2048, 2048, 50, 8)])
+def test_sharded_device_phases_simulated_ranks(kind, w, h, q, parts):
+    """All ranks simulated in one process (one engine context per rank): the
+    exchanges are done by hand exactly as encode_sharded does them."""
+    import torch
+    img = himg_amd.synth(kind, 1, w, h)
+    rows, cols = h // 8, w // 8
+    ranges = sharded.shard_rows(rows, parts)
+    backs = []
+    for (r0, r1) in ranges:
+        y0, y1 = max(0, 8 * r0 - 11), min(h, 8 * r1 + 5)
+        if r1 <= r0:
+            y0, y1 = 0, 1
+        d = torch.from_numpy(np.ascontiguousarray(img[y0:y1])).to("cuda:0")
+        backs.append(sharded.EngineBackend(himg_amd.Engine(0), d, y0, w, h, q, True))
+    stats = [b.stats(r0, r1) for b, (r0, r1) in zip(backs, ranges)]
+    hist = sum(s[0] for s in stats)
+    bits = [b.row_bits(hist) for b in backs]
+    all_bits = torch.cat(bits)
+    layout = sharded.fres_layout(all_bits.cpu().numpy(), rows > 1)
+    rel_full = torch.empty(layout[3], dtype=torch.uint8, device="cuda:0")
+    for b, (r0, r1) in zip(backs, ranges):
+        s, e = sharded.piece_range(layout, r0, r1)
+        rel_full[s:e] = b.emit(all_bits, s, e)
+    low_full = torch.empty(4 * rows * cols, dtype=torch.uint8, device="cuda:0")
+    lf = low_full.view(4, rows, cols)
+    for (r0, r1), s in zip(ranges, stats):
+        if r1 > r0:
+            lf[:, r0:r1, :] = s[1].view(4, r1 - r0, cols)
+    out = backs[0].assemble(low_full, all_bits, rel_full)
+    want = ol.oracle_encode(img, q, True)
+    assert out.size == want.size
+    d = np.nonzero(out != want)[0]
+    assert d.size == 0, "first mismatch at %d of %d" % (d[0], want.size)
+    for b in backs:
+        b.eng.close()
+
+
+@pytest.mark.gpu
+def test_sharded_encode_two_processes(tmp_path):
+    """Two ranks, two processes, real collectives (gloo with CPU staging because the
+    test box has a single GPU), real kernels on both ranks."""
+    out = tmp_path / "out.himg"
+    _run_ranks(2, ["gpu", "randtile", 2, 512, 1024, 50, out])
+    want = ol.oracle_encode(himg_amd.synth("randtile", 2, 512, 1024), 50, True)
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
