@@ -49,10 +49,14 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one engine context each) the batch is split over, so the short "
                          "serial kernels of one group overlap the wide kernels of the other")
-    ap.add_argument("--width", type=int, default=4096)
-    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--width", type=int, default=None, help="default 4096 (frames) / 16384 (rows)")
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--quality", type=int, default=50)
     ap.add_argument("--kind", default="randtile")
+    ap.add_argument("--mode", default="frames", choices=["frames", "rows"],
+                    help="frames: independent frames sharded over ranks (default, the headline "
+                         "metric); rows: ONE frame (default 16384x16384, BASELINE config 4) sharded by "
+                         "block rows with RCCL all-reduce / all-gather / gather (encode only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     return ap.parse_args()
@@ -102,6 +106,87 @@ def cpu_baseline(frame, quality, budget_s):
     }
 
 
+GOLDEN_16384 = {"packed_size": 275620945, "stream_fnv": "5bdcdb7a140df481"}
+
+
+def bench_rows(args, rank, local_rank, world, dev):
+    """BASELINE config 4: one large frame, block rows sharded over the ranks, FRES
+    histogram all-reduced, row sizes all-gathered, packed rows gathered to rank 0
+    over RCCL/xGMI (himg_amd/sharded.py).  Strong scaling: the frame is fixed."""
+    import torch
+    import torch.distributed as dist
+    import himg_amd
+    from himg_amd import sharded
+
+    W = args.width or 16384
+    H = args.height or 16384
+    Q = args.quality
+    rows, cols = (H + 7) // 8, (W + 7) // 8
+    img = himg_amd.synth(args.kind, 0, W, H)          # every rank generates, then keeps its shard
+    r0, r1 = sharded.shard_rows(rows, world)[rank]
+    y0, y1 = max(0, 8 * r0 - 11), min(H, 8 * r1 + 5)
+    if r1 <= r0:
+        y0, y1 = 0, 1
+    d_shard = torch.from_numpy(np.ascontiguousarray(img[y0:y1])).to(dev)
+    want = None
+    if rank == 0 and not (W == 16384 and H == 16384 and Q == 50 and args.kind == "randtile"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        want = ol.oracle_encode(img, Q, True)
+    del img
+    eng = himg_amd.Engine(local_rank)
+    backend = sharded.EngineBackend(eng, d_shard, y0, W, H, Q, True)
+
+    def step():
+        return sharded.encode_sharded(backend, rows, cols, 4, rows > 1)
+
+    out = step()
+    verified = "n/a"
+    if rank == 0:
+        if want is None:
+            assert out.size == GOLDEN_16384["packed_size"], out.size
+            assert himg_amd.fnv1a64(out) == GOLDEN_16384["stream_fnv"], "stream differs from the reference"
+            verified = "golden"
+        else:
+            assert np.array_equal(out, want), "stream differs from the oracle"
+            verified = "oracle"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.cpu()[0])
+    if rank == 0:
+        value = W * H * args.steps / dt / 1e6
+        print(json.dumps({
+            "metric": "Mpixels/s encode, one RGBA frame row-sharded over the GPUs, q=%d" % Q,
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8/i16/i32 integer", "data": "synthetic",
+            "config": {"workload": "%dx%d RGBA %s q=%d, encode, block rows sharded over %d rank(s), "
+                                   "host-orchestrated collectives (all-reduce 261xi64, all-gather row "
+                                   "bits, gather low-res rows and packed rows to rank 0), result includes "
+                                   "D2H of the final stream" % (W, H, args.kind, Q, world),
+                       "bit_exact": verified}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -122,7 +207,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    W, H, B, Q = args.width, args.height, args.batch, args.quality
+    if args.mode == "rows":
+        return bench_rows(args, rank, local_rank, world, dev)
+
+    W, H, B, Q = args.width or 4096, args.height or 4096, args.batch, args.quality
     S = max(1, min(args.streams, B))
     while B % S:
         S -= 1
