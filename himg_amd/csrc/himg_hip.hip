@@ -98,6 +98,10 @@ struct himg_hip_ctx {
   // HIMG_FORCE_UNFUSED=1 routes every block row through the generic decode path
   // (symbols via HBM), the one rows wider than the LDS budget always take.
   bool allow_fused = true;
+  bool use_side = true;  // HIMG_SIDE_STREAM=0 keeps the row-header walk on the caller's stream
+  // Side stream + events: the decoder forks its serial row-header walk onto it.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   // Fixed table: LUT of the full-res companding search (FullResMapper is the
   // same for every quality, mapper.cpp:213-223), 32769 entries.
@@ -189,6 +193,7 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   himg_hip_ctx *ctx = new himg_hip_ctx();
   ctx->device = device;
   if (const char *e = std::getenv("HIMG_FORCE_UNFUSED")) ctx->allow_fused = !(e[0] == '1');
+  if (const char *e = std::getenv("HIMG_SIDE_STREAM")) ctx->use_side = !(e[0] == '0');
   // Companding LUT for every magnitude an int16 can take.
   std::vector<uint8_t> lut(32769);
   int16_t fmap[128];
@@ -200,6 +205,12 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
     delete ctx;
     return HIMG_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete ctx;
+    return HIMG_ERR_HIP;
+  }
   *out = ctx;
   return HIMG_OK;
 }
@@ -208,6 +219,9 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->side) hipStreamDestroy(ctx->side);
   ctx->prof.collect();
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
                    &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_lut, &ctx->d_lut2, &ctx->d_rows,
@@ -462,7 +476,7 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, h_sizes, (size_t)batch * 4, hipMemcpyHostToDevice, s));
   launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
                 (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof,
-                ctx->allow_fused);
+                ctx->allow_fused, ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join);
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }

@@ -77,15 +77,27 @@ __device__ bool parse_map(const uint8_t *in, uint32_t size, int16_t *t) {
 // low bits of its code and its depth are kept in aux[] for the LUT fill.
 struct TreeAux { uint32_t code; int32_t depth; };
 
-__device__ int recover_tree(const uint8_t *p, uint32_t begin, uint32_t end, int32_t *nodes,
-                            TreeAux *aux, int32_t *num_nodes, uint32_t *payload_off) {
+// The explicit stack lives in LDS: as a per-lane array it would sit in scratch
+// (global) memory and every push/pop would be a dependent global access.
+struct TreeStack {
+  int32_t par[kMaxDepth + 4], depth[kMaxDepth + 4];
+  uint32_t code[kMaxDepth + 4];
+  uint8_t which[kMaxDepth + 4];
+};
+
+__device__ int recover_tree(const uint32_t *w /* LDS words */, uint32_t nbytes, int32_t *nodes,
+                            TreeAux *aux, int32_t *num_nodes, uint32_t *tree_bytes,
+                            TreeStack *stk /* LDS */) {
   // Explicit stack of pending subtrees: (parent, which child, code, depth).
-  int32_t st_par[kMaxDepth + 4], st_depth[kMaxDepth + 4];
-  uint32_t st_code[kMaxDepth + 4];
-  uint8_t st_which[kMaxDepth + 4];
+  int32_t *st_par = stk->par, *st_depth = stk->depth;
+  uint32_t *st_code = stk->code;
+  uint8_t *st_which = stk->which;
   int sp = 0, count = 0;
-  unsigned long long bit = 8ull * begin;
-  const unsigned long long bit_end = 8ull * end;
+  // 64-bit window over the tree bits (a node costs 1 or 10 bits).
+  unsigned long long win = ((unsigned long long)w[1] << 32) | w[0];
+  int nb = 64;
+  uint32_t next = 2, bit = 0;
+  const uint32_t bit_end = 8u * nbytes;
   st_par[0] = -1; st_which[0] = 0; st_code[0] = 0; st_depth[0] = 0; sp = 1;
   while (sp > 0) {
     --sp;
@@ -96,15 +108,15 @@ __device__ int recover_tree(const uint8_t *p, uint32_t begin, uint32_t end, int3
     if (par >= 0) nodes[3 * par + which] = me;
     nodes[3 * me + 0] = -1; nodes[3 * me + 1] = -1; nodes[3 * me + 2] = -1;
     aux[me].code = code; aux[me].depth = depth;
+    if (nb <= 32) { win |= (unsigned long long)w[next++] << nb; nb += 32; }
     if (bit >= bit_end) return kStFormat;  // ReadBitChecked, huffman_dec.cpp:51-60
-    const int leaf = (p[bit >> 3] >> (bit & 7)) & 1;
-    ++bit;
+    const int leaf = (int)(win & 1ull);
     if (leaf) {
-      if (bit + 9 > bit_end) return kStFormat;  // ReadBitsChecked, huffman_dec.cpp:94-106
-      int sym = 0;
-      for (int i = 0; i < 9; ++i, ++bit) sym |= ((p[bit >> 3] >> (bit & 7)) & 1) << i;
-      nodes[3 * me + 2] = sym;
+      if (bit + 10 > bit_end) return kStFormat;  // ReadBitsChecked, huffman_dec.cpp:94-106
+      nodes[3 * me + 2] = (int)((win >> 1) & 511ull);
+      win >>= 10; nb -= 10; bit += 10;
     } else {
+      win >>= 1; nb -= 1; bit += 1;
       if (depth + 1 > kMaxDepth) return kStUnsupported;
       // child_b is pushed first so that child_a is parsed first (pre-order).
       st_par[sp] = me; st_which[sp] = 1; st_depth[sp] = depth + 1;
@@ -113,8 +125,22 @@ __device__ int recover_tree(const uint8_t *p, uint32_t begin, uint32_t end, int3
     }
   }
   *num_nodes = count;
-  *payload_off = (uint32_t)((bit + 7) >> 3);  // AlignToByte, huffman_dec.cpp:229
+  *tree_bytes = (bit + 7) >> 3;  // AlignToByte, huffman_dec.cpp:229
   return 0;
+}
+
+// parse_map on bytes staged in LDS (mapper.cpp:127-157).
+__device__ bool parse_map_lds(const uint8_t *in, uint32_t size, int16_t *t) {
+  if (size < 1) return false;
+  const int n1 = in[0];
+  if (n1 > 127 || (uint32_t)(1 + n1 + 2 * (127 - n1)) != size) return false;
+  const uint8_t *q = in + 1;
+  t[0] = 0;
+  for (int i = 1; i <= 127; ++i) {
+    if (i <= n1) { t[i] = (int16_t)*q++; }
+    else { t[i] = (int16_t)(uint16_t)(q[0] | (q[1] << 8)); q += 2; }
+  }
+  return true;
 }
 
 // LUT entry: [8:0] symbol | [9] "continue at node" flag | [15:10] code bits |
@@ -137,7 +163,9 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
                                                   size_t in_stride, const uint32_t *sizes) {
   __shared__ TreeAux aux[2][kMaxNodes + 1];
   __shared__ uint32_t s_lut[2][1 << kLutBits];
-  __shared__ uint8_t s_tree[kTreeStride + 16];  // serialised tree bytes (at most 359)
+  __shared__ uint32_t s_buf[(kTreeStride + 16) / 4];  // staged chunk bytes (tree / mapping table)
+  __shared__ uint32_t s_idx, s_sz;                     // chunk body offset / size found by lane 0
+  __shared__ TreeStack s_stack;
   __shared__ int s_status;
   const int f = blockIdx.x, lane = threadIdx.x;
   const uint8_t *p = packed + (size_t)f * in_stride;
@@ -145,99 +173,110 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
   DecFrame *df = ws.frames + f;
   int32_t *nodes0 = ws.nodes + ((size_t)f * 2 + 0) * (kMaxNodes + 1) * 3;
   int32_t *nodes1 = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
+  uint8_t *s_bytes = reinterpret_cast<uint8_t *>(s_buf);
 
-  if (lane == 0) {
+  // The container walk is serial (lane 0); the bodies it needs to read byte by
+  // byte (mapping tables, serialised trees) are first staged in LDS by the whole
+  // wave, because a dependent global load costs ~1 us and an LDS read ~50 ns.
+  auto stage = [&]() {   // copies min(s_sz, capacity) bytes from p + s_idx; all lanes
+    __syncthreads();
+    const uint32_t cnt = s_status ? 0u : (s_sz < (uint32_t)kTreeStride ? s_sz : (uint32_t)kTreeStride);
+    for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16; k += 64)
+      s_bytes[k] = k < cnt ? p[s_idx + k] : (uint8_t)0;
+    __syncthreads();
+  };
+  if (lane == 0) { s_status = 0; s_idx = 0; s_sz = 0; }
+  uint32_t idx = 12, sz = 0;   // lane 0's cursor
+
+  if (lane == 0) {   // ---- A: RIFF, FRMT, locate LMAP (decoder.cpp:144-212)
     int st = 0;
-    uint32_t idx = 12, sz = 0;
     do {
-      // decoder.cpp:144-166
       if (n < 12 || rd32(p) != 0x46464952u /*RIFF*/ || rd32(p + 4) + 8u != n ||
           rd32(p + 8) != 0x474d4948u /*HIMG*/) { st = fmt_err(1, 0); break; }
-      // decoder.cpp:168-200
       if (!find_chunk(p, n, &idx, 0x544d5246u /*FRMT*/, &sz) || sz < 11 || p[idx] != 1) { st = fmt_err(2, 0); break; }
-      {
-        const uint32_t w = rd32(p + idx + 1), h = rd32(p + idx + 5);
-        const int c = p[idx + 9];
-        df->ycbcr = (p[idx + 10] != 0 && c >= 3) ? 1 : 0;
-        if ((int)w != g.W || (int)h != g.H || c != g.C) { st = kStGeom; break; }
-        idx += sz;
-      }
-      // decoder.cpp:202-212
-      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz) || !parse_map(p + idx, sz, df->lmap)) { st = fmt_err(3, 0); break; }
+      const uint32_t w = rd32(p + idx + 1), h = rd32(p + idx + 5);
+      const int c = p[idx + 9];
+      df->ycbcr = (p[idx + 10] != 0 && c >= 3) ? 1 : 0;
+      if ((int)w != g.W || (int)h != g.H || c != g.C) { st = kStGeom; break; }
       idx += sz;
-      // decoder.cpp:214-232: LRES is one unblocked stream.
+      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz)) { st = fmt_err(3, 0); break; }
+      s_idx = idx; s_sz = sz;
+    } while (0);
+    s_status = st;
+  }
+  stage();
+  if (lane == 0 && !s_status) {   // ---- B: LMAP body, locate LRES (decoder.cpp:202-232)
+    int st = 0;
+    do {
+      if (sz > (uint32_t)kTreeStride || !parse_map_lds(s_bytes, sz, df->lmap)) { st = fmt_err(3, 0); break; }
+      idx += sz;
       if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { st = fmt_err(4, 0); break; }
       df->s[0].chunk_end = idx + sz;
-      {
-        // The tree is at most 359 bytes: copy it to LDS with independent loads, then
-        // walk it there (the walk is a chain of dependent bit reads).
-        const uint32_t tn = sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride;
-        for (uint32_t k = 0; k < tn; ++k) s_tree[k] = p[idx + k];
-        st = recover_tree(s_tree, 0, tn, nodes0, aux[0], &df->s[0].num_nodes, &df->s[0].payload_off);
-        df->s[0].payload_off += idx;
-      }
+      s_idx = idx; s_sz = sz;
+    } while (0);
+    s_status = st;
+  }
+  stage();
+  if (lane == 0 && !s_status) {   // ---- C: LRES tree, QCFG, locate FMAP (decoder.cpp:250-272)
+    int st = 0;
+    do {
+      uint32_t tb = 0;
+      st = recover_tree(s_buf, sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes0, aux[0],
+                        &df->s[0].num_nodes, &tb, &s_stack);
       if (st) { if (st == kStFormat) st = fmt_err(4, 1); break; }
       df->s[0].root = 0;
+      df->s[0].payload_off = idx + tb;
       // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
       if (df->s[0].payload_off >= df->s[0].chunk_end) { st = fmt_err(4, 1); break; }
       idx += sz;
-      // decoder.cpp:250-260, quantize.cpp:190-213
       if (!find_chunk(p, n, &idx, 0x47464351u /*QCFG*/, &sz) || sz != (df->ycbcr ? 64u : 32u)) { st = fmt_err(5, 0); break; }
-      for (int i = 0; i < 32; ++i) {
+      for (int i = 0; i < 32; ++i) {   // quantize.cpp:190-213
         df->shift[0][2 * i] = p[idx + i] >> 4; df->shift[0][2 * i + 1] = p[idx + i] & 15;
         const uint8_t x = df->ycbcr ? p[idx + 32 + i] : 0;
         df->shift[1][2 * i] = x >> 4; df->shift[1][2 * i + 1] = x & 15;
       }
       idx += sz;
-      // decoder.cpp:262-272
-      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz) || !parse_map(p + idx, sz, df->fmap)) { st = fmt_err(6, 0); break; }
+      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz)) { st = fmt_err(6, 0); break; }
+      s_idx = idx; s_sz = sz;
+    } while (0);
+    s_status = st;
+  }
+  stage();
+  if (lane == 0 && !s_status) {   // ---- D: FMAP body, locate FRES (decoder.cpp:262-290)
+    int st = 0;
+    do {
+      if (sz > (uint32_t)kTreeStride || !parse_map_lds(s_bytes, sz, df->fmap)) { st = fmt_err(6, 0); break; }
       idx += sz;
-      // decoder.cpp:274-290
       if (!find_chunk(p, n, &idx, 0x53455246u /*FRES*/, &sz)) { st = fmt_err(7, 0); break; }
       df->s[1].chunk_end = idx + sz;
       // Trap T2: the decoder derives use_blocks from the COMPRESSED size
       // (huffman_dec.cpp:215-219); UncompressBlock refuses when it is false (:265).
       if (!((uint32_t)g.row_block < sz)) { st = fmt_err(7, 1); break; }
-      {
-        // The tree is at most 359 bytes: copy it to LDS with independent loads, then
-        // walk it there (the walk is a chain of dependent bit reads).
-        const uint32_t tn = sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride;
-        for (uint32_t k = 0; k < tn; ++k) s_tree[k] = p[idx + k];
-        st = recover_tree(s_tree, 0, tn, nodes1, aux[1], &df->s[1].num_nodes, &df->s[1].payload_off);
-        df->s[1].payload_off += idx;
-      }
+      s_idx = idx; s_sz = sz;
+    } while (0);
+    s_status = st;
+  }
+  stage();
+  if (lane == 0 && !s_status) {   // ---- E: FRES tree
+    int st = 0;
+    do {
+      uint32_t tb = 0;
+      st = recover_tree(s_buf, sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes1, aux[1],
+                        &df->s[1].num_nodes, &tb, &s_stack);
       if (st) { if (st == kStFormat) st = fmt_err(7, 1); break; }
       df->s[1].root = 0;
+      df->s[1].payload_off = idx + tb;
       if (df->s[1].payload_off >= df->s[1].chunk_end) { st = fmt_err(7, 1); break; }
-      // Row index: serial walk over the size headers (huffman_dec.cpp:232-248).
-      uint32_t q = df->s[1].payload_off, end = df->s[1].chunk_end;
-      uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
-      int r = 0;
-      while (q != end) {
-        if (q + 2 > end) { st = fmt_err(7, 1); break; }
-        uint32_t len = p[q] | (p[q + 1] << 8);
-        q += 2;
-        if (len & 0x8000u) {
-          if (q + 2 > end) { st = fmt_err(7, 1); break; }
-          len = (len & 0x7fffu) | ((uint32_t)(p[q] | (p[q + 1] << 8)) << 15);
-          q += 2;
-        }
-        if (len > end - q) { st = fmt_err(7, 1); break; }
-        if (r < g.rows) { ro[r] = q; rl[r] = len; }
-        ++r;
-        q += len;
-      }
-      if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
+      // A tree that is a single leaf decodes without consuming code bits in the
+      // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
+      // the encoder's 1-bit codes; such streams are rejected here.
+      if (nodes0[2] >= 0) { st = fmt_err(4, 1); break; }
+      if (nodes1[2] >= 0) { st = fmt_err(7, 1); break; }
     } while (0);
-    // A tree that is a single leaf decodes without consuming code bits in the
-    // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
-    // the encoder's 1-bit codes; such streams are rejected here.
-    if (!st && nodes0[2] >= 0) st = fmt_err(4, 1);
-    if (!st && nodes1[2] >= 0) st = fmt_err(7, 1);
-    df->status = st;
     s_status = st;
   }
   __syncthreads();
+  if (lane == 0) df->status = s_status;
   if (s_status) return;
 
   // First-level LUTs (kLutBits wide, LSB-first codes index them directly), then
@@ -286,6 +325,43 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       lut2[idx] = r;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_dec_rowwalk: index of the FRES block rows (huffman_dec.cpp:232-248).  Every
+// row's size header sits right behind the previous row's payload, so this is a
+// chain of dependent loads (~1.4 us per hop from HBM) that nothing can
+// parallelise; it runs on a side stream, concurrently with the LRES kernels,
+// which do not need it.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint8_t *packed,
+                                                    size_t in_stride) {
+  const int f = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  int st = 0;
+  uint32_t q = df->s[1].payload_off;
+  const uint32_t end = df->s[1].chunk_end;
+  uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
+  int r = 0;
+  while (q != end) {
+    if (q + 2 > end) { st = fmt_err(7, 1); break; }
+    uint32_t len = p[q] | (p[q + 1] << 8);
+    q += 2;
+    if (len & 0x8000u) {
+      if (q + 2 > end) { st = fmt_err(7, 1); break; }
+      len = (len & 0x7fffu) | ((uint32_t)(p[q] | (p[q + 1] << 8)) << 15);
+      q += 2;
+    }
+    if (len > end - q) { st = fmt_err(7, 1); break; }
+    if (r < g.rows) { ro[r] = q; rl[r] = len; }
+    ++r;
+    q += len;
+  }
+  if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
+  if (st) atomicMax(&df->status, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -841,6 +917,48 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
   load_dec_tables(ws, df, f, 0, lut, lut2, ca, cb, sy);
   DecTables tb;
   tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  if (FIX) {
+    // Cheap test first: lane 0 re-decodes its own sub-sequence from the true start
+    // T (payload read in place, nothing staged).  If it ends where its speculative
+    // chain ended, no other lane changes and the chunk is done.
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long T = ws.spec_end[slot - 1];
+      sh.flag = 0;
+      if (T >= cur && T < cur + kLresWps * 32) {
+        GlobalView gv;
+        uint32_t grel0;
+        make_view<kLresWps>(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur, nullptr,
+                            &gv, &grel0);
+        unsigned long long lim_abs = cur + kLresWps * 32;
+        if (lim_abs > P1) lim_abs = P1;
+        uint32_t pos = grel0 + (uint32_t)(T - cur);
+        const uint32_t lim = grel0 + (uint32_t)(lim_abs - cur);
+        unsigned long long c = 0;
+        if (pos < lim) {
+          BitReader br;
+          br.init(gv, pos);
+          do {
+            const Step t = next_step(br, gv, tb, pos, lim, ~0ull);
+            pos += t.nbits ? t.nbits : 1;
+            c += (unsigned long long)(t.count > 0 ? t.count : 0);
+          } while (pos < lim);
+        }
+        if (pos - grel0 == ws.spec_endpos[slot * kDecThreads]) {
+          const unsigned long long oldc = ws.spec_cnt[slot * kDecThreads];
+          ws.spec_start[slot * kDecThreads] = (uint32_t)(T - cur);
+          ws.spec_cnt[slot * kDecThreads] = (uint32_t)(c < 0xffffffffull ? c : 0xffffffffull);
+          ws.spec_tot[slot] = ws.spec_tot[slot] - oldc + c;
+          ws.fix_end[slot] = ws.spec_end[slot];
+          sh.flag = 1;
+          uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1)) * 8;
+          atomicAdd(&st[2], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    if (sh.flag) return;
+  }
   const PayView<kLresWps> pv = {pay};
   const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
                                               8ull * pay_off + cur, pay);
@@ -1350,7 +1468,8 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
-                   int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused) {
+                   int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const unsigned gx = (unsigned)((g.cols + 255) / 256);
   // Fused row kernel when the row's symbols fit the 160 KiB LDS: with the payload
   // staged in LDS too when that also fits, else with the payload read from L2.
@@ -1362,6 +1481,19 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   }
   const int wps = fused;
   HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
+  // Fork: the serial FRES row-header walk runs on the side stream while this
+  // stream decodes the LRES chain; they join before the first FRES row kernel.
+  // (side == nullptr: run it in line.)
+  if (side) {
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+    prof_begin(prof, "k_dec_rowwalk", side);
+    hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride);
+    prof_end(prof, side);
+    (void)hipEventRecord(ev_join, side);
+  } else {
+    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride);
+  }
   // LRES: every chunk in parallel, chain verified, serial fallback if not.
   (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
   HIMG_LAUNCH(k_lres_chain<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
@@ -1376,6 +1508,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                 d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
+    if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     const uint32_t lds = fused_layout(g.row_block, 8, fused == 1).total;
     prof_begin(prof, "k_dec_row_fused", stream);
 #define HIMG_FUSED_LAUNCH(G, COLS)                                                              \
@@ -1391,6 +1524,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
 #undef HIMG_FUSED_LAUNCH
     prof_end(prof, stream);
   } else {
+    if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     HIMG_LAUNCH(k_dec_huff, dim3(g.rows + 1, batch), dim3(kDecThreads), g, ws, d_packed,
                 in_stride, d_sizes, 0, 1);
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);

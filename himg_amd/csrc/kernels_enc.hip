@@ -66,12 +66,37 @@ __global__ __launch_bounds__(256) void k_lowres_avg(Geom g, const uint8_t *frame
   const int x0 = max(0, 8 * u - 3), x1 = min(g.W - 1, 8 * u + 4);
   const int y0 = max(0, 8 * v - 3), y1 = min(g.H - 1, 8 * v + 4);
   int sum[4] = {0, 0, 0, 0};
-  for (int y = y0; y <= y1; ++y)
-    for (int x = x0; x <= x1; ++x) {
-      int ch[4];
-      load_pixel(img, g, x, y, ch);
-      sum[0] += ch[0]; sum[1] += ch[1]; sum[2] += ch[2]; sum[3] += ch[3];
+  if (g.stride == 4 && g.C == 4 && (g.W & 7) == 0) {
+    // Packed RGBA8: the window spans pixels 8u-3 .. 8u+4 = the last three of the
+    // 16-byte group before the tile, the tile's first group, and the first pixel
+    // of its second group -> three 16-byte loads per pixel row instead of eight
+    // 4-byte ones.
+    const bool has_left = u > 0;
+    for (int y = y0; y <= y1; ++y) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(img + ((long long)y * g.W + 8 * u) * 4);
+      const uint4 b = rp[0];
+      const uint32_t c0 = rp[1].x;
+      uint4 a;
+      a.x = a.y = a.z = a.w = 0;
+      if (has_left) a = rp[-1];
+      uint32_t px[8] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w, c0};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < 3 && !has_left) continue;
+        int ch[4] = {(int)(px[k] & 255), (int)((px[k] >> 8) & 255), (int)((px[k] >> 16) & 255),
+                     (int)(px[k] >> 24)};
+        if (g.ycbcr) lift_fwd(ch[0], ch[1], ch[2]);
+        sum[0] += ch[0]; sum[1] += ch[1]; sum[2] += ch[2]; sum[3] += ch[3];
+      }
     }
+  } else {
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x) {
+        int ch[4];
+        load_pixel(img, g, x, y, ch);
+        sum[0] += ch[0]; sum[1] += ch[1]; sum[2] += ch[2]; sum[3] += ch[3];
+      }
+  }
   const int cnt = (x1 - x0 + 1) * (y1 - y0 + 1);
   uint8_t *a = avg + (size_t)f * plane_stride;
   for (int c = 0; c < g.C; ++c)
