@@ -331,12 +331,16 @@ def main():
         roofline = None
         if dom:
             ach = alg_bytes_launch / (stages[dom]["ms"] * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC measurement (per frame, same
+            # workload; tools/profile_pmc.sh) -- null when the workload differs.
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                key = "%s@%dx%dx%d" % (dom, W, H, G)
-                traffic = tj.get(key)
+            if os.path.exists(tpath) and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
+                per_frame = {k.split("<")[0]: v for k, v in
+                             json.load(open(tpath)).get("bytes_per_frame", {}).items()}
+                key = dom.strip("()").split("<")[0]
+                if key in per_frame:
+                    traffic = per_frame[key] * G
             roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom in enc_stages else "decode",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
