@@ -467,7 +467,8 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   if ((in_stride & 3) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
     return fail(ctx, HIMG_ERR_ARG, "in_stride must be a multiple of 4; buffers 16-byte aligned");
   for (int i = 0; i < batch; ++i)
-    if (h_sizes[i] > in_stride && batch > 1) return fail(ctx, HIMG_ERR_ARG, "stream larger than in_stride");
+    if (((size_t)h_sizes[i] + 3) / 4 * 4 > in_stride)
+      return fail(ctx, HIMG_ERR_ARG, "in_stride must cover every stream rounded up to 4 bytes");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ensure_dec_ws(ctx, g, batch);
   if (rc) return rc;

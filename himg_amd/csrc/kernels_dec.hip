@@ -396,14 +396,16 @@ struct PayView {
 struct GlobalView {
   const uint8_t *p;       // stream base (4-byte aligned)
   uint32_t gb;            // window start, multiple of 4
-  uint32_t stream_size;
+  uint32_t stream_size;   // >= 12; the buffer is readable up to the next multiple of 4
+  // Branch-free: clamp the address to the dword holding the stream's last byte and
+  // mask off the bytes beyond the stream (this sits in the decoder's hot loop).
   __device__ __forceinline__ uint32_t ld(uint32_t j) const {
     const uint32_t b = gb + 4u * j;
-    if (b + 4 <= stream_size) return *reinterpret_cast<const uint32_t *>(p + b);
-    uint32_t w = 0;
-    for (int k = 0; k < 4; ++k)
-      if (b + k < stream_size) w |= (uint32_t)p[b + k] << (8 * k);
-    return w;
+    const uint32_t last = (stream_size - 1u) & ~3u;
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(p + (b < last ? b : last));
+    const uint32_t tail = stream_size - last;  // 1..4 valid bytes in the last dword
+    const uint32_t m_last = tail >= 4 ? 0xffffffffu : ((1u << (8 * tail)) - 1u);
+    return b < last ? w : (b == last ? (w & m_last) : 0u);
   }
 };
 

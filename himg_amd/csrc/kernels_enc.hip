@@ -846,15 +846,43 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
 // ---------------------------------------------------------------------------
 constexpr int kStageWords = 6144;  // >= (31 + (4096+32)*46) / 32
 
+// Wave-level inclusive scans (no barrier); lane 63 holds the wave total.
+__device__ __forceinline__ ZR wave_scan_zr(ZR v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    ZR t;
+    t.tz = __shfl_up(v.tz, d);
+    t.az = __shfl_up(v.az, d);
+    if (lane >= d) v = zr_combine(t, v);
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Three barriers per 4096-symbol iteration: (A) after the waves publish their
+// zero-run totals, (B) after they publish their bit totals, (C) after the bits
+// have been OR-ed into the staging buffer.  The exchange slots are double
+// buffered by iteration parity, and the staging buffer is circular: the partial
+// last word stays where it is and every thread flushes AND re-zeroes its own
+// words, so neither needs a barrier of its own.
 __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
                                               const uint32_t *sizes, int sp0) {
   __shared__ uint32_t stage[kStageWords];
-  __shared__ uint32_t s_code[kHistStride];
-  __shared__ uint8_t s_len[kHistStride];
-  __shared__ ZR sm_zr[4];
-  __shared__ uint32_t sm_u[4];
+  __shared__ unsigned long long s_cl[kHistStride];  // code | length << 32
+  __shared__ ZR sm_zr[2][4];
+  __shared__ uint32_t sm_u[2][4];
 
   const int sp = blockIdx.x + sp0, f = blockIdx.y, tid = threadIdx.x;
+  const int lane = lane_id(), wave = wave_id();
   if (sizes[f] == 0) return;  // frame failed (status says why)
   const Span s = get_span(g, ws, sp, f);
   const int nsp = g.lres_spans + g.rows;
@@ -864,16 +892,13 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
 
   const size_t tab = ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
-  for (int k = tid; k < kHistStride; k += 256) {
-    s_code[k] = (uint32_t)ws.codes[tab + k];
-    s_len[k] = (uint8_t)ws.lens[tab + k];
-  }
+  for (int k = tid; k < kHistStride; k += 256)
+    s_cl[k] = (unsigned long long)(uint32_t)ws.codes[tab + k] | ((unsigned long long)ws.lens[tab + k] << 32);
   for (int k = tid; k < kStageWords; k += 256) stage[k] = 0;
-  ZR carry;
-  carry.tz = span_carry_in(g, ws, sp, f);
-  carry.az = 0;
-  unsigned long long gword = B0 >> 5;           // global dword of stage[0]
-  uint32_t carry_bits = (uint32_t)(B0 & 31);    // bits of stage[0] that precede this span
+  int run_carry = span_carry_in(g, ws, sp, f);  // zeros pending in front of this iteration
+  unsigned long long gword = B0 >> 5;           // global dword of stage[woff]
+  uint32_t carry_bits = (uint32_t)(B0 & 31);    // bits of stage[woff] already taken
+  uint32_t woff = 0;                            // staging word of the current partial word
   __syncthreads();
 
   auto store_word = [&](unsigned long long gw, uint32_t val) {
@@ -891,27 +916,54 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     }
   };
 
-  for (int base = 0; base < s.len; base += kIterSyms) {
+  uint32_t w[4], wn[4];
+  load16(s.sym + tid * 16, s.len - tid * 16, w);
+  int par = 0;
+  for (int base = 0; base < s.len; base += kIterSyms, par ^= 1) {
     const int off = base + tid * 16;
     const int nvalid = max(0, min(16, s.len - off));
-    uint32_t w[4];
-    load16(s.sym + off, s.len - off, w);
+    // Prefetch the next iteration's symbols.
+    if (base + kIterSyms < s.len) load16(s.sym + off + kIterSyms, s.len - off - kIterSyms, wn);
     const uint32_t mask = nonzero_mask16(w, nvalid);
-    const ZR mine = summarize16(mask, nvalid);
-    ZR total;
-    const ZR ex = block_scan_zr(mine, carry, sm_zr, &total);
-    carry = total;
-    carry.az = 0;
+
+    // (A) zero-run state in front of every lane.
+    const ZR incl = wave_scan_zr(summarize16(mask, nvalid));
+    if (lane == 63) sm_zr[par][wave] = incl;
+    ZR ex;
+    ex.tz = __shfl_up(incl.tz, 1);
+    ex.az = __shfl_up(incl.az, 1);
+    if (lane == 0) { ex.tz = 0; ex.az = 1; }
+    __syncthreads();
+    ZR pre, tot;
+    pre.tz = run_carry; pre.az = 0;
+    tot = pre;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < wave) pre = zr_combine(pre, sm_zr[par][k]);
+      tot = zr_combine(tot, sm_zr[par][k]);
+    }
+    const int run_in = zr_combine(pre, ex).tz;
+    run_carry = tot.tz;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
 
+    // (B) bit offset of every lane.
     uint32_t mybits = 0;
-    walk16(w, mask, nvalid, ex.tz, flush, [&](int sym, int eb, int) { mybits += s_len[sym] + eb; });
-    uint32_t iter_bits;
-    const uint32_t myoff = block_scan_u32(mybits, sm_u, &iter_bits);
+    walk16(w, mask, nvalid, run_in, flush,
+           [&](int sym, int eb, int) { mybits += (uint32_t)(s_cl[sym] >> 32) + eb; });
+    const uint32_t bincl = wave_scan_u32(mybits);
+    if (lane == 63) sm_u[par][wave] = bincl;
+    __syncthreads();
+    uint32_t bpre = 0, iter_bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < wave) bpre += sm_u[par][k];
+      iter_bits += sm_u[par][k];
+    }
 
-    // Append this thread's tokens at its bit offset inside the staging buffer.
-    uint32_t pos = carry_bits + myoff;
-    uint32_t widx = pos >> 5;
+    // Append this thread's tokens at its bit offset inside the circular staging buffer.
+    uint32_t pos = carry_bits + bpre + bincl - mybits;
+    uint32_t widx = woff + (pos >> 5);
+    if (widx >= (uint32_t)kStageWords) widx -= kStageWords;
     uint32_t accb = pos & 31;
     unsigned long long acc = 0;
     auto put = [&](uint32_t v, int n) {  // n <= 32
@@ -919,31 +971,36 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
       accb += n;
       if (accb >= 32) {
         atomicOr(&stage[widx], (uint32_t)acc);
-        ++widx;
+        widx = widx + 1 == (uint32_t)kStageWords ? 0u : widx + 1;
         acc >>= 32;
         accb -= 32;
       }
     };
-    walk16(w, mask, nvalid, ex.tz, flush, [&](int sym, int eb, int ev) {
-      put(s_code[sym], s_len[sym]);
+    walk16(w, mask, nvalid, run_in, flush, [&](int sym, int eb, int ev) {
+      const unsigned long long cl = s_cl[sym];
+      put((uint32_t)cl, (int)(cl >> 32));
       if (eb) put((uint32_t)ev, eb);
     });
     if (accb && acc) atomicOr(&stage[widx], (uint32_t)acc);
-    __syncthreads();
+    __syncthreads();   // (C)
 
+    // Flush the complete words; each thread re-zeroes what it flushed.
     const uint32_t end_bits = carry_bits + iter_bits;
     const uint32_t nfull = end_bits >> 5;
-    for (uint32_t k = tid; k < nfull; k += 256) store_word(gword + k, stage[k]);
-    const uint32_t partial = stage[nfull];
-    __syncthreads();
-    for (uint32_t k = tid; k <= nfull; k += 256) stage[k] = 0;
-    __syncthreads();
-    if (tid == 0) stage[0] = partial;
+    for (uint32_t k = tid; k < nfull; k += 256) {
+      uint32_t i = woff + k;
+      if (i >= (uint32_t)kStageWords) i -= kStageWords;
+      store_word(gword + k, stage[i]);
+      stage[i] = 0;
+    }
     gword += nfull;
+    woff += nfull;
+    if (woff >= (uint32_t)kStageWords) woff -= kStageWords;
     carry_bits = end_bits & 31;
-    __syncthreads();
+    w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
   }
-  if (tid == 0 && carry_bits) store_word(gword, stage[0]);
+  __syncthreads();
+  if (tid == 0 && carry_bits) store_word(gword, stage[woff]);
 }
 
 // ---------------------------------------------------------------------------

@@ -87,7 +87,9 @@ int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, int batch,
 
 /* Decode `batch` streams that already live in HBM; all must have the stated
  * geometry (it is validated on the device against each stream's FRMT chunk).
- *   d_packed : device pointer, stream f starts at d_packed + f*in_stride
+ *   d_packed : device pointer, stream f starts at d_packed + f*in_stride; in_stride
+ *              is a multiple of 4 and >= every packed size rounded up to 4 (the
+ *              decoder reads whole dwords)
  *   h_sizes  : HOST array, batch packed sizes
  *   d_out    : device pointer, batch * width*height*num_channels bytes
  *   d_status : device pointer, batch x int32 */
