@@ -144,7 +144,8 @@ __device__ bool parse_map_lds(const uint8_t *in, uint32_t size, int16_t *t) {
 }
 
 // LUT entry: [8:0] symbol | [9] "continue at node" flag | [15:10] code bits |
-// [19:16] RLE extra bits of the symbol | [31:20] node index (flagged entries).
+// [19:16] RLE extra bits of the symbol | [31:20] node index (the leaf itself, or
+// for flagged entries the branch reached after kLutBits bits).
 __device__ __forceinline__ int rle_extra_bits(int sym) {
   return sym < 257 ? 0 : sym == 257 ? 2 : sym == 258 ? 4 : sym == 259 ? 8 : 14;
 }
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       const int sym = nodes[3 * k + 2];
       if (sym >= 0 && depth <= kLutBits) {
         for (uint32_t i = 0; i < (1u << (kLutBits - depth)); ++i)
-          s_lut[s][(i << depth) | code] = lut_leaf(sym, depth);
+          s_lut[s][(i << depth) | code] = lut_leaf(sym, depth) | ((uint32_t)k << 20);
       } else if (sym < 0 && depth == kLutBits) {
         s_lut[s][code] = lut_node(k, depth);
       }
@@ -323,6 +324,47 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
       r.x = bytes;
       r.y = (nout || eb_first) ? (used | (nout << 8) | (last << 12) | (eb_first << 16)) : 0u;
       lut2[idx] = r;
+    }
+    // Group table of the lean decoder (GrpTables below).  A group is a greedy
+    // sequence of tokens whose CODES lie inside the kLutBits known bits:
+    // literals / single zeros / the two-zeros symbol for at most 4 output bytes,
+    // optionally closed by ONE zero-run token (its zeros need no explicit bytes;
+    // its extra bits are read from the stream at decode time).
+    uint2 *grp = ws.grp + ((size_t)f * 2 + s) * (1u << kLutBits);
+    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += 64) {
+      uint32_t used = 0, nout = 0, bytes = 0, g_eb = 0, s_tb = 0, s_class = 0, ntok = 0;
+      const uint32_t e0 = s_lut[s][idx];
+      for (;;) {
+        const uint32_t e = s_lut[s][(idx >> used) & ((1u << kLutBits) - 1)];
+        const uint32_t len = (e >> 10) & 63u, sym = e & 511u;
+        if ((e & 512u) || len == 0 || sym > 260 || used + len > (uint32_t)kLutBits) break;
+        uint32_t cls;
+        if (sym <= 256) {
+          const uint32_t cnt = sym == 256 ? 2u : 1u;
+          if (nout + cnt > 4) break;
+          if (sym < 256) bytes |= sym << (8 * nout);
+          nout += cnt;
+          cls = sym == 256 ? 1u : 0u;
+        } else {
+          cls = sym - 255u;  // 2..5
+          nout += cls == 2 ? 3u : cls == 3 ? 7u : cls == 4 ? 23u : 279u;
+          g_eb = cls == 2 ? 2u : cls == 3 ? 4u : cls == 4 ? 8u : 14u;
+        }
+        used += len;
+        if (ntok++ == 0) { s_tb = len; s_class = cls; }
+        if (sym > 256) break;
+      }
+      uint2 r;
+      if (ntok) {
+        r.x = bytes;
+        r.y = used | (g_eb << 4) | (nout << 8) | (s_tb << 17) | (s_class << 21);
+      } else {
+        // The first code is longer than the table: .x says where the tree walk
+        // continues (node | depth << 16).
+        r.x = (e0 >> 20) | (((e0 >> 10) & 63u) << 16);
+        r.y = 0;
+      }
+      grp[idx] = r;
     }
   }
 }
@@ -811,6 +853,276 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   return bad;
 }
 
+// ---------------------------------------------------------------------------
+// Lean decode path (fused row kernel, payload read in place from L2).
+//
+// The decode passes are bound by VALU issue, so their inner loops are kept to a
+// handful of instructions per step: one 64-bit bit window with a two-deep word
+// prefetch, ONE table read per step, and no per-token classification.
+//
+// Group table entry (uint2), indexed by the next kLutBits stream bits:
+//   .x  the first 4 output bytes of the group (0 where the output is a zero)
+//   .y  [3:0]   code bits of the whole group   [7:4]   extra bits that follow them
+//       [16:8]  symbols it produces, before the extra-bits value is added
+//       [20:17] code bits of its first token    [23:21] class of the first token:
+//               0 literal / single zero, 1 two zeros, 2..5 zero runs 257..260
+//   .y == 0: the first code is longer than the table; .x = node | depth << 16
+//            is where the tree walk continues.
+// A lane owns the tokens that START in [start, lim): the whole group is taken
+// while pos + kLutBits <= lim (every token of it then starts before lim), the
+// first token alone otherwise.
+// ---------------------------------------------------------------------------
+struct GrpTables {
+  const uint2 *grp;           // LDS, 1 << kLutBits entries
+  const short *ca, *cb, *sy;  // LDS tree nodes
+};
+
+struct __attribute__((packed)) PackedU32 { uint32_t v; };
+
+// Bit window over the stream's dwords in global memory.  Word indices are
+// clamped to the dword that holds the stream's last byte: bits past the end of
+// the stream repeat that dword, which only a token that overruns the payload can
+// see -- and such a stream is rejected whatever those bits are.
+struct GReader {
+  const uint32_t *w;   // dword-aligned window base
+  uint32_t jmax;       // index of the stream's last dword
+  unsigned long long win;
+  int nb;              // valid bits in win
+  uint32_t next;       // index of the word held in pre
+  uint32_t pre;        // prefetched word: the load issued by one refill is first
+                       // touched by the next one, so its latency hides behind ~3 steps.
+                       // (It must land in `pre` untouched -- any move or mask of the
+                       // loaded register makes the compiler wait for it on the spot.)
+  __device__ __forceinline__ uint32_t ld(uint32_t j) const { return w[j < jmax ? j : jmax]; }
+  __device__ __forceinline__ void init(uint32_t pos) {
+    const uint32_t j = pos >> 5, sh = pos & 31;
+    win = (((unsigned long long)ld(j + 1) << 32) | ld(j)) >> sh;
+    nb = 64 - (int)sh;
+    next = j + 2;
+    pre = ld(next);
+  }
+  __device__ __forceinline__ void refill() {   // afterwards nb >= 33
+    if (nb <= 32) {
+      win |= (unsigned long long)pre << nb;
+      nb += 32;
+      ++next;
+      pre = ld(next);
+    }
+  }
+  __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
+};
+
+// Extra bits and run base per token class (huffman_common.h:24-28).
+__device__ __forceinline__ uint32_t class_eb(uint32_t c) { return (0xE84200u >> (4u * c)) & 15u; }
+__device__ __forceinline__ uint32_t class_base(uint32_t c) {
+  const unsigned long long kBases = 1ull | (2ull << 9) | (3ull << 18) | (7ull << 27) | (23ull << 36) | (279ull << 45);
+  return (uint32_t)(kBases >> (9u * c)) & 511u;
+}
+
+// One decode step.  Reads the table at the window, resolves group / first token
+// / long code, consumes the bits and returns what the step produced.  The common
+// case is branch free; `single` is true only in a lane's last kLutBits bits, and
+// codes longer than the table are rare.  bad is set (never cleared) on symbols
+// the reference rejects (huffman_dec.cpp:349-352).
+template <bool WANT_BYTES>
+__device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool single,
+                                          uint32_t *nbits, uint32_t *count, uint32_t *bytes,
+                                          bool *bad) {
+  rd.refill();
+  const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
+  uint32_t y, bx = 0;
+  if (WANT_BYTES) { const uint2 e = t.grp[idx]; bx = e.x; y = e.y; }
+  else y = reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
+  uint32_t tb = y & 15u, eb = (y >> 4) & 15u, cb = (y >> 8) & 511u, pre = 0, by = bx;
+  if (single) {
+    const uint32_t c = (y >> 21) & 7u;
+    tb = (y >> 17) & 15u;
+    eb = class_eb(c);
+    cb = class_base(c);
+    by &= 255u;
+  }
+  if (__builtin_expect(tb == 0, 0)) {
+    // Code longer than the table: walk the tree (huffman_dec.cpp:291-328).
+    const uint32_t ex = WANT_BYTES ? bx : t.grp[idx].x;
+    int node = (int)(ex & 0xffffu), len = (int)(ex >> 16);
+    while (t.sy[node] < 0 && len < kMaxDepth) {
+      node = ((rd.win >> len) & 1ull) ? t.cb[node] : t.ca[node];
+      ++len;
+    }
+    const int sym = t.sy[node];
+    const bool ok = sym >= 0 && sym <= 260 && len > 0;
+    if (!ok) *bad = true;
+    if (len == 0) len = 1;  // keep moving on a degenerate tree
+    rd.consume(len);
+    rd.refill();
+    pre = (uint32_t)len;
+    const uint32_t c = !ok ? 0u : (sym < 256 ? 0u : (uint32_t)sym - 255u);
+    eb = class_eb(c);
+    cb = ok ? class_base(c) : 0u;
+    by = (ok && sym < 256) ? (uint32_t)sym : 0u;
+  }
+  const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, tb, eb);
+  const uint32_t n = tb + eb;
+  rd.consume((int)n);
+  *nbits = pre + n;
+  *count = cb + extra;
+  *bytes = by;
+}
+
+// Count pass: the tokens that start in [pos, lim).  Returns where the last one
+// ends and how many symbols they produce.
+__device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint32_t pos,
+                                           uint32_t lim, uint32_t *endpos, uint32_t *count) {
+  uint32_t c = 0;
+  if (pos < lim) {
+    rd.init(pos);
+    const int limk = (int)lim - kLutBits;
+    bool bad = false;
+    do {
+      uint32_t nbits, cnt, by;
+      lean_step<false>(rd, t, (int)pos > limk, &nbits, &cnt, &by, &bad);
+      pos += nbits;
+      c += cnt;
+    } while (pos < lim);
+  }
+  *endpos = pos;
+  *count = c;
+}
+
+// Write pass of one lane: the tokens that start in [bp, lim) go to lds_out
+// (pre-zeroed) from offset op.  The group's bytes are OR-ed in with two aligned
+// ds_or (the bytes past the group are zeros, so neighbours are never disturbed).
+// The caller guarantees that all of the lane's symbols lie inside the block.
+__device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint32_t bp,
+                                           uint32_t lim, uint32_t op, uint8_t *lds_out) {
+  bool bad = false;
+  if (bp < lim) {
+    rd.init(bp);
+    const int limk = (int)lim - kLutBits;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
+    do {
+      uint32_t nbits, cnt, by;
+      lean_step<true>(rd, t, (int)bp > limk, &nbits, &cnt, &by, &bad);
+      const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
+      atomicOr(&o32[op >> 2], (uint32_t)v);
+      atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      op += cnt;
+      bp += nbits;
+    } while (bp < lim);
+  }
+  return !bad;
+}
+
+// The lane in whose range the block completes: exact token-by-token decode with
+// the reference's end-of-block checks (huffman_dec.cpp:353-354,361-417).
+// Returns false on a stream error; *end_bp = bit position where the block became
+// complete (~0u if it did not).
+__device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uint32_t bp,
+                                            uint32_t lim, uint32_t op, uint32_t out_size,
+                                            uint8_t *lds_out, uint32_t *end_bp) {
+  *end_bp = ~0u;
+  if (!(bp < lim) || op >= out_size) return true;
+  rd.init(bp);
+  bool bad = false;
+  for (;;) {
+    uint32_t nbits, cnt, by;
+    lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
+    if (bad) return false;
+    if (op + cnt > out_size) return false;  // a zero run overruns the block
+    if (by) lds_out[op] = (uint8_t)by;
+    op += cnt;
+    bp += nbits;
+    if (op >= out_size) { *end_bp = bp; return true; }
+    if (!(bp < lim)) return true;
+  }
+}
+
+// Fused decode of one FRES block row into LDS with the lean passes.  Same
+// contract as decode_stream<.., FUSED = true, USE_GLOBAL = true>.  The row is
+// normally ONE chunk: the sub-sequence length is chosen so that the 1024 lanes
+// cover the whole payload.
+__device__ int decode_row_lean(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
+                               uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
+                               StreamShared *sh, uint8_t *lds_out, uint32_t *stats) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
+  __syncthreads();
+
+  const unsigned long long P1 = 8ull * pay_len;
+  unsigned long long cur = 0, O0 = 0;
+  uint32_t st_chunks = 0, st_rounds = 0;
+  long long c_sync = 0, c_write = 0, c_t0 = clock64();
+
+  while (cur < P1 && O0 < out_size) {
+    const unsigned long long abs_bit = 8ull * pay_off + cur;
+    const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;
+    const uint32_t rel0 = (uint32_t)(abs_bit - 8ull * gb);
+    GReader rd;
+    rd.w = reinterpret_cast<const uint32_t *>(p + gb);
+    rd.jmax = ((stream_size - 1u) >> 2) - (gb >> 2);
+    ++st_chunks;
+
+    const unsigned long long rem = P1 - cur;
+    uint32_t sub = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
+    sub = (sub + 31u) & ~31u;
+    sub = sub < 256u ? 256u : (sub > 4096u ? 4096u : sub);
+    const unsigned long long chunk_bits = (unsigned long long)sub * kDecThreads;
+    const uint32_t rel_end = rel0 + (uint32_t)(rem < chunk_bits ? rem : chunk_bits);
+    const uint32_t my_b0 = rel0 + (uint32_t)tid * sub;
+    uint32_t lim = my_b0 + sub;
+    if (lim > rel_end) lim = rel_end;
+
+    // Speculative decode to the self-synchronised fixpoint (see fixpoint_chunk).
+    uint32_t start = my_b0 < rel_end ? my_b0 : rel_end;
+    uint32_t endpos = start, cnt = 0;
+    bool dirty = true;
+    for (;;) {
+      if (dirty) lean_count(rd, tb, start, lim, &endpos, &cnt);
+      sh->nxt[tid + 1] = endpos;
+      __syncthreads();
+      const uint32_t ns = tid == 0 ? rel0 : sh->nxt[tid];
+      dirty = (ns != start);
+      start = ns;
+      ++st_rounds;
+      if (!__syncthreads_or(dirty ? 1 : 0)) break;
+    }
+    { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
+
+    unsigned long long tot;
+    const unsigned long long off = block_scan_u64(cnt, sh->sm64, &tot);
+    const unsigned long long opl = O0 + off;
+    uint32_t end_bp = ~0u;
+    if (opl + cnt < out_size) {
+      if (!lean_write(rd, tb, start, lim, (uint32_t)opl, lds_out)) sh->err = 1;
+    } else if (opl < out_size) {
+      if (!exact_write(rd, tb, start, lim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
+    }
+    if (end_bp != ~0u) sh->endbit = cur + (end_bp - rel0);
+    __syncthreads();
+    { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
+
+    if (tid == kDecThreads - 1) sh->nxt[0] = endpos;
+    __syncthreads();
+    const uint32_t last_end = sh->nxt[0];
+    cur += (unsigned long long)(last_end - rel0);
+    O0 += tot;
+    if (last_end == rel0) break;
+    __syncthreads();
+  }
+  __syncthreads();
+
+  int bad = sh->err;
+  if (O0 < out_size) bad = 1;
+  const unsigned long long E = sh->endbit;
+  if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+  if (tid == 0 && stats) {
+    stats[0] = st_chunks; stats[1] = st_rounds; stats[2] = 0;
+    stats[3] = 0; stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
+    stats[6] = pay_len; stats[7] = out_size;
+  }
+  return bad;
+}
+
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
                                                 uint32_t *lut, uint2 *lut2, short *ca, short *cb,
                                                 short *sy) {
@@ -1267,16 +1579,14 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // The symbols never touch HBM: traffic is the packed row in, the pixels out.
 // ---------------------------------------------------------------------------
 struct FusedLayout {
-  uint32_t sym, pay, lut, lut2, ca, cb, sy, sh, unmap, shift, total;
+  uint32_t sym, grp, ca, cb, sy, sh, unmap, shift, total;
 };
-__host__ __device__ inline FusedLayout fused_layout(int row_block, int wps, bool stage_payload) {
+__host__ __device__ inline FusedLayout fused_layout(int row_block) {
   FusedLayout L;
   uint32_t o = 0;
   auto carve = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   L.sym = carve((uint32_t)row_block);
-  L.pay = carve(stage_payload ? (uint32_t)wps * (kDecThreads + 2) * 4u : 0u);
-  L.lut = carve((1u << kLutBits) * 4u);
-  L.lut2 = carve((1u << kLutBits) * 8u);
+  L.grp = carve((1u << kLutBits) * 8u);
   L.ca = carve((kMaxNodes + 1) * 2u);
   L.cb = carve((kMaxNodes + 1) * 2u);
   L.sy = carve((kMaxNodes + 1) * 2u);
@@ -1291,18 +1601,16 @@ __host__ __device__ inline FusedLayout fused_layout(int row_block, int wps, bool
 // rows): the 64 symbol slots of a tile are then at immediate LDS offsets instead
 // of 64 live address registers, which is what keeps the transform phase from
 // spilling.
-template <int WPS, bool USE_GLOBAL, int COLS>
+template <int COLS>
 __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
                                                                const uint8_t *packed,
                                                                size_t in_stride,
                                                                const uint32_t *sizes,
                                                                uint8_t *out_frames) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const FusedLayout L = fused_layout(g.row_block, WPS, !USE_GLOBAL);
+  const FusedLayout L = fused_layout(g.row_block);
   uint8_t *sym = smem + L.sym;
-  uint32_t *pay = reinterpret_cast<uint32_t *>(smem + L.pay);
-  uint32_t *lut = reinterpret_cast<uint32_t *>(smem + L.lut);
-  uint2 *lut2 = reinterpret_cast<uint2 *>(smem + L.lut2);
+  uint2 *grp = reinterpret_cast<uint2 *>(smem + L.grp);
   short *ca = reinterpret_cast<short *>(smem + L.ca);
   short *cb = reinterpret_cast<short *>(smem + L.cb);
   short *sy = reinterpret_cast<short *>(smem + L.sy);
@@ -1314,7 +1622,15 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  load_dec_tables(ws, df, f, 1, lut, lut2, ca, cb, sy);
+  {
+    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
+    const int nn = df->s[1].num_nodes;
+    for (int k = tid; k < nn; k += kDecThreads) {
+      ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
+    }
+    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) reinterpret_cast<uint4 *>(grp)[k] = gg[k];
+  }
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -1329,12 +1645,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   }
   __syncthreads();
 
-  DecTables tb;
-  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const int bad = decode_stream<WPS, true, USE_GLOBAL>(
+  GrpTables tb;
+  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const int bad = decode_row_lean(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
-      (uint32_t)g.row_block, pay, tb, sh, sym, nullptr, nullptr,
-      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8);
+      (uint32_t)g.row_block, tb, sh, sym, ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8);
   if (bad) {
     if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
     return;
@@ -1473,15 +1788,10 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
                    hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const unsigned gx = (unsigned)((g.cols + 255) / 256);
-  // Fused row kernel when the row's symbols fit the 160 KiB LDS: with the payload
-  // staged in LDS too when that also fits, else with the payload read from L2.
+  // Fused row kernel when the row's symbols and the decode tables fit the 160 KiB
+  // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;
-  int fused = 0;  // 0 = unfused, 1 = staged payload, 2 = payload from global memory
-  if (allow_fused) {
-    if (fused_layout(g.row_block, 8, true).total <= kLdsMax) fused = 1;
-    else if (fused_layout(g.row_block, 8, false).total <= kLdsMax) fused = 2;
-  }
-  const int wps = fused;
+  const int wps = (allow_fused && fused_layout(g.row_block).total <= kLdsMax) ? 1 : 0;
   HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
   // Fork: the serial FRES row-header walk runs on the side stream while this
   // stream decodes the LRES chain; they join before the first FRES row kernel.
@@ -1511,18 +1821,17 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                 d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-    const uint32_t lds = fused_layout(g.row_block, 8, fused == 1).total;
+    const uint32_t lds = fused_layout(g.row_block).total;
     prof_begin(prof, "k_dec_row_fused", stream);
-#define HIMG_FUSED_LAUNCH(G, COLS)                                                              \
+#define HIMG_FUSED_LAUNCH(COLS)                                                                 \
   do {                                                                                          \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<8, G, COLS>),     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<COLS>),           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-    hipLaunchKernelGGL((k_dec_row_fused<8, G, COLS>), dim3(g.rows, batch), dim3(kDecThreads),   \
-                       lds, stream, g, ws, d_packed, in_stride, d_sizes, d_out);                \
+    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3(g.rows, batch), dim3(kDecThreads), lds,    \
+                       stream, g, ws, d_packed, in_stride, d_sizes, d_out);                     \
   } while (0)
-    if (fused == 1) HIMG_FUSED_LAUNCH(false, 0);
-    else if (g.cols == 512) HIMG_FUSED_LAUNCH(true, 512);
-    else HIMG_FUSED_LAUNCH(true, 0);
+    if (g.cols == 512) HIMG_FUSED_LAUNCH(512);
+    else HIMG_FUSED_LAUNCH(0);
 #undef HIMG_FUSED_LAUNCH
     prof_end(prof, stream);
   } else {
