@@ -70,7 +70,7 @@ struct LresTables {
 
 // ---- decoder ---------------------------------------------------------------
 
-constexpr int kLutBits = 11;  // first-level Huffman decode LUT / group table width
+constexpr int kLutBits = 11;  // width of the Huffman decode group table
 constexpr int kDecThreads = 1024;
 
 struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
@@ -92,8 +92,6 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
 struct DecWs {
   DecFrame *frames;          // [f]
   int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
-  uint32_t *lut;             // [f][2][1<<kLutBits]
-  uint2 *lut2;               // [f][2][1<<kLutBits] multi-token groups (kernels_dec.hip next_step)
   uint2 *grp;                // [f][2][1<<kLutBits] group table of the lean decoder (kernels_dec.hip GrpTables)
   uint32_t *row_off;         // [f][rows] payload byte offset of each FRES row
   uint32_t *row_len;         // [f][rows]

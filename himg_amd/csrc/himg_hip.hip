@@ -115,7 +115,7 @@ struct himg_hip_ctx {
   bool enc_valid = false;
 
   // Decoder workspace.
-  DevBuf d_frames, d_nodes, d_lut, d_lut2, d_grp, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
+  DevBuf d_frames, d_nodes, d_grp, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
   Geom dec_geom{};
   DecWs dec_ws{};
   int dec_batch = 0;
@@ -224,7 +224,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (ctx->side) hipStreamDestroy(ctx->side);
   ctx->prof.collect();
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
-                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_lut, &ctx->d_lut2, &ctx->d_grp, &ctx->d_rows,
+                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
   for (DevBuf *b : all) b->release();
@@ -340,8 +340,6 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   const size_t fres = round_up((size_t)g.fres_size + 16, 256);
   if (!ctx->d_frames.reserve(sizeof(DecFrame) * batch) ||
       !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 3 * 4) ||
-      !ctx->d_lut.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
-      !ctx->d_lut2.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
@@ -350,8 +348,6 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
     return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
   w.frames = (DecFrame *)ctx->d_frames.p;
   w.nodes = (int32_t *)ctx->d_nodes.p;
-  w.lut = (uint32_t *)ctx->d_lut.p;
-  w.lut2 = (uint2 *)ctx->d_lut2.p;
   w.grp = (uint2 *)ctx->d_grp.p;
   w.row_off = (uint32_t *)ctx->d_rows.p;
   w.row_len = w.row_off + (size_t)batch * g.rows;

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
   if (lane == 0) df->status = s_status;
   if (s_status) return;
 
-  // First-level LUTs (kLutBits wide, LSB-first codes index them directly), then
-  // the multi-token table derived from them (see next_step).
+  // First-level LUTs (kLutBits wide, LSB-first codes index them directly) in LDS,
+  // then the group tables derived from them.
   for (int s = 0; s < 2; ++s) {
     const int32_t *nodes = s ? nodes1 : nodes0;
     const int nn = df->s[s].num_nodes;
@@ -299,32 +299,6 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
   }
   __syncthreads();
   for (int s = 0; s < 2; ++s) {
-    uint32_t *lut = ws.lut + ((size_t)f * 2 + s) * (1u << kLutBits);
-    uint2 *lut2 = ws.lut2 + ((size_t)f * 2 + s) * (1u << kLutBits);
-    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += 64) {
-      lut[idx] = s_lut[s][idx];
-      // Greedy group of tokens that lie completely inside the kLutBits known bits.
-      uint32_t used = 0, nout = 0, bytes = 0, last = 0, eb_first = 0;
-      for (;;) {
-        const uint32_t e = s_lut[s][(idx >> used) & ((1u << kLutBits) - 1)];
-        const uint32_t len = (e >> 10) & 63u, eb = (e >> 16) & 15u, sym = e & 511u;
-        if ((e & 512u) || len == 0 || used + len > (uint32_t)kLutBits || sym > 260) break;
-        if (eb) {  // zero run with extra bits: only as a step of its own
-          if (nout == 0) { used = len; eb_first = eb; }
-          break;
-        }
-        const uint32_t out = sym == 256 ? 2u : 1u;
-        if (nout + out > 4) break;
-        if (sym < 256) bytes |= sym << (8 * nout);
-        last = used;
-        nout += out;
-        used += len;
-      }
-      uint2 r;
-      r.x = bytes;
-      r.y = (nout || eb_first) ? (used | (nout << 8) | (last << 12) | (eb_first << 16)) : 0u;
-      lut2[idx] = r;
-    }
     // Group table of the lean decoder (GrpTables below).  A group is a greedy
     // sequence of tokens whose CODES lie inside the kLutBits known bits:
     // literals / single zeros / the two-zeros symbol for at most 4 output bytes,
@@ -410,158 +384,37 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
 // Entropy decoding (huffman_dec.cpp:274-418), parallel inside one stream.
 //
 // A whole workgroup (1024 lanes) decodes one Huffman stream (the LRES stream or
-// one FRES block row).  The payload is processed in chunks of 1024 sub-sequences
-// of WPS*32 bits.  Every lane decodes one sub-sequence speculatively from its
-// nominal start; then the workgroup iterates start[t+1] = end[t] until nothing
-// changes.  Lane 0's start is exact, so by induction the fixpoint is the exact
-// token chain (Huffman streams self-synchronise, typically a few rounds).  A
-// prefix scan of the per-lane symbol counts places the output.
+// one FRES block row).  The payload is processed in chunks of 1024 sub-sequences.
+// Every lane decodes one sub-sequence speculatively from its nominal start; then
+// the workgroup iterates start[t+1] = end[t] until nothing changes.  Lane 0's
+// start is exact, so by induction the fixpoint is the exact token chain (Huffman
+// streams self-synchronise, typically within one sub-sequence).  A prefix scan
+// of the per-lane symbol counts places the output, and a last pass writes it.
 //
-// The chunk's payload words are staged in LDS TRANSPOSED ([word-in-subsequence]
-// [lane]) so that the 64 lanes of a wave, which walk 64 different sub-sequences,
-// hit 64 different banks; each lane keeps a 64-bit bit window in registers and
-// refills it one dword at a time.
+// These passes are bound by VALU issue (a CU retires one wave64 VALU
+// instruction per cycle), so the inner loop is kept to a few dozen instructions
+// per step: a 64-bit bit window per lane over the payload in place (L2), ONE
+// table read per step that resolves a whole group of tokens, and no per-token
+// classification.
+//
+// Group table entry (uint2), indexed by the next kLutBits stream bits:
+//   .x  the first 4 output bytes of the group (0 where the output is a zero)
+//   .y  [3:0]   code bits of the whole group   [7:4]   extra bits that follow them
+//       [16:8]  symbols it produces, before the extra-bits value is added
+//       [20:17] code bits of its first token    [23:21] class of the first token:
+//               0 literal / single zero, 1 two zeros, 2..5 zero runs 257..260
+//   .y == 0: the first code is longer than the table; .x = node | depth << 16
+//            is where the tree walk continues.
+// A lane owns the tokens that START in [start, lim): the whole group is taken
+// while pos + kLutBits <= lim (every token of it then starts before lim), the
+// first token alone otherwise.
 // ---------------------------------------------------------------------------
-constexpr int kWinBytes = 32768;  // output window in LDS (generic kernel)
+constexpr int kWinBytes = 32768;  // output window in LDS (streams that go to HBM)
 
-template <int WPS>
-struct PayView {
-  const uint32_t *pay;  // LDS, transposed
-  static constexpr int kRow = kDecThreads + 2;
-  __device__ __forceinline__ uint32_t ld(uint32_t j) const {
-    return pay[(j & (WPS - 1)) * kRow + (j / WPS)];
-  }
+struct GrpTables {
+  const uint2 *grp;           // LDS, 1 << kLutBits entries
+  const short *ca, *cb, *sy;  // LDS tree nodes
 };
-
-// Payload read straight from global memory (L2): word j of the dword-aligned
-// window that starts at stream byte `gb`.  Bytes beyond the stream read as zero.
-struct GlobalView {
-  const uint8_t *p;       // stream base (4-byte aligned)
-  uint32_t gb;            // window start, multiple of 4
-  uint32_t stream_size;   // >= 12; the buffer is readable up to the next multiple of 4
-  // Branch-free: clamp the address to the dword holding the stream's last byte and
-  // mask off the bytes beyond the stream (this sits in the decoder's hot loop).
-  __device__ __forceinline__ uint32_t ld(uint32_t j) const {
-    const uint32_t b = gb + 4u * j;
-    const uint32_t last = (stream_size - 1u) & ~3u;
-    const uint32_t w = *reinterpret_cast<const uint32_t *>(p + (b < last ? b : last));
-    const uint32_t tail = stream_size - last;  // 1..4 valid bytes in the last dword
-    const uint32_t m_last = tail >= 4 ? 0xffffffffu : ((1u << (8 * tail)) - 1u);
-    return b < last ? w : (b == last ? (w & m_last) : 0u);
-  }
-};
-
-// 64-bit bit window over a payload view, with the next word prefetched so that
-// a refill never waits on the load it issues.
-struct BitReader {
-  unsigned long long win;
-  int nb;         // valid bits in win
-  uint32_t next;  // index of the word held in `pre`
-  uint32_t pre;   // prefetched word `next`
-  template <class PV>
-  __device__ __forceinline__ void init(const PV &pv, uint32_t pos) {
-    const uint32_t j = pos >> 5, sh = pos & 31;
-    win = (((unsigned long long)pv.ld(j + 1) << 32) | pv.ld(j)) >> sh;
-    nb = 64 - (int)sh;
-    next = j + 2;
-    pre = pv.ld(next);
-  }
-  __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
-};
-
-struct DecTables {
-  const uint32_t *lut;             // LDS, 1 << kLutBits entries
-  const uint2 *lut2;               // LDS, multi-token groups (see build_lut2)
-  const short *ca, *cb, *sy;       // LDS tree nodes
-};
-
-struct Tok { int sym; int nbits; int count; };
-
-// Token step of the hot loops, fully inline: one branch-free refill (>= 33
-// valid bits, enough for any code), one LUT read that yields symbol, code length
-// and extra-bit count; lanes whose code is longer than kLutBits walk the tree
-// (divergent, rare per lane); a second refill for the extra bits happens only
-// when some lane of the wave needs it.
-template <class PV>
-__device__ __forceinline__ void refill_bf(BitReader &br, const PV &pv) {
-  if (br.nb <= 32) {
-    br.win |= (unsigned long long)br.pre << br.nb;
-    br.nb += 32;
-    ++br.next;
-    br.pre = pv.ld(br.next);
-  }
-}
-
-template <class PV>
-__device__ __forceinline__ Tok next_token(BitReader &br, const PV &pv, const DecTables &t) {
-  refill_bf(br, pv);
-  const uint32_t e = t.lut[(uint32_t)br.win & ((1u << kLutBits) - 1)];
-  int len = (int)(e >> 10) & 63, eb = (int)(e >> 16) & 15;
-  int sym = (int)(e & 511u);
-  if (e & 512u) {
-    int node = (int)(e >> 20);
-    while (t.sy[node] < 0 && len < kMaxDepth) {
-      node = ((br.win >> len) & 1ull) ? t.cb[node] : t.ca[node];
-      ++len;
-    }
-    sym = t.sy[node];
-    eb = rle_extra_bits(sym);
-  }
-  br.consume(len);
-  if (__any(eb > br.nb)) refill_bf(br, pv);
-  // RLE symbols (huffman_common.h:24-28, huffman_dec.cpp:330-354).
-  const int extra = (int)((uint32_t)br.win & ((1u << eb) - 1u));
-  br.consume(eb);
-  const int base = eb == 0 ? 2 : eb == 2 ? 3 : eb == 4 ? 7 : eb == 8 ? 23 : 279;
-  Tok r;
-  r.sym = sym;
-  r.nbits = len + eb;
-  // Symbols above 260 make the reference abort (huffman_dec.cpp:349-352).
-  r.count = sym < 256 ? 1 : (sym <= 260 ? base + extra : -1);
-  return r;
-}
-
-// One decode STEP = one lookup in the multi-token table lut2: either a group of
-// up to 4 output bytes' worth of short tokens without extra bits (literals and
-// the two-zeros symbol), or one zero-run token with its extra bits.  The step is
-// only taken when every token of the group starts before `lim` (tokens are owned
-// by the lane whose range they START in), when it fits in the valid bits and in
-// `room` (symbols left in the block); otherwise -- and for codes longer than
-// kLutBits -- the lane falls back to one exact single-token step.
-struct Step {
-  int nbits;        // bits consumed
-  int count;        // output symbols produced (-1: invalid symbol, reference aborts)
-  int nlit;         // how many of them are explicit bytes in `bytes` (else zeros)
-  uint32_t bytes;
-};
-
-template <class PV>
-__device__ __forceinline__ Step next_step(BitReader &br, const PV &pv, const DecTables &t,
-                                          uint32_t pos, uint32_t lim, unsigned long long room) {
-  refill_bf(br, pv);
-  const uint2 e = t.lut2[(uint32_t)br.win & ((1u << kLutBits) - 1)];
-  const int nb = (int)(e.y & 63u), gn = (int)((e.y >> 8) & 15u), last = (int)((e.y >> 12) & 15u);
-  const int eb = (int)((e.y >> 16) & 15u);
-  const bool fast = nb != 0 && pos + (uint32_t)last < lim && nb + eb <= br.nb &&
-                    (eb != 0 || (unsigned long long)gn <= room);
-  Step r;
-  if (__builtin_expect(!fast, 0)) {
-    const Tok k = next_token(br, pv, t);
-    r.nbits = k.nbits;
-    r.count = k.count;
-    r.nlit = k.sym < 256 ? 1 : 0;
-    r.bytes = (uint32_t)k.sym;
-    return r;
-  }
-  const int extra = (int)((uint32_t)(br.win >> nb) & ((1u << eb) - 1u));
-  br.consume(nb + eb);
-  const int base = eb == 2 ? 3 : eb == 4 ? 7 : eb == 8 ? 23 : 279;
-  r.nbits = nb + eb;
-  r.count = eb ? base + extra : gn;
-  r.nlit = eb ? 0 : gn;
-  r.bytes = e.x;
-  return r;
-}
 
 // Exclusive scan of a 64-bit value over the 1024-thread workgroup.
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v,
@@ -594,291 +447,6 @@ struct StreamShared {            // small LDS state of the stream decoder
   int err;
 };
 
-// ---- building blocks of the stream decoder -----------------------------------
-
-// Stage the payload words that cover one chunk starting at absolute stream bit
-// `abs_bit` (transposed, zero beyond the stream).  Returns the bit offset of
-// `abs_bit` inside the staged words.  Ends with a barrier.
-template <int WPS>
-__device__ __forceinline__ uint32_t stage_chunk(const uint8_t *p, uint32_t stream_size,
-                                                unsigned long long abs_bit, uint32_t *pay) {
-  constexpr int kStageWords = kDecThreads * WPS + 4;
-  const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;  // dword-aligned byte offset
-  for (int j = threadIdx.x; j < kStageWords; j += kDecThreads) {
-    const uint32_t b = gb + 4u * j;
-    uint32_t w = 0;
-    if (b + 4 <= stream_size) {
-      w = *reinterpret_cast<const uint32_t *>(p + b);
-    } else {
-      for (int k = 0; k < 4; ++k)
-        if (b + k < stream_size) w |= (uint32_t)p[b + k] << (8 * k);
-    }
-    pay[(j & (WPS - 1)) * PayView<WPS>::kRow + (j / WPS)] = w;
-  }
-  __syncthreads();
-  return (uint32_t)(abs_bit - 8ull * gb);
-}
-
-// Speculative decode of one chunk to the self-synchronised fixpoint.  On return
-// lane t owns exactly the tokens that START in [start, lim) -- relative to lane
-// 0's start `first`, which the caller asserts (exact) or assumes (speculative).
-template <class PV>
-__device__ __forceinline__ void fixpoint_chunk(const PV &pv, const DecTables &tb,
-                                               StreamShared *sh, uint32_t first, uint32_t my_b0,
-                                               uint32_t lim, uint32_t rel_end, uint32_t *start_io,
-                                               uint32_t *endpos_io, unsigned long long *cnt_io,
-                                               uint32_t *rounds, bool warm = false) {
-  // warm: (*start_io, *endpos_io, *cnt_io) hold a fixpoint reached for another
-  // first-token position; only lanes whose start changes decode again.
-  const int tid = threadIdx.x;
-  uint32_t start = my_b0 < rel_end ? my_b0 : rel_end;
-  if (tid == 0) start = first;
-  uint32_t endpos = start;
-  unsigned long long cnt = 0;
-  bool dirty = true;
-  if (warm) {
-    dirty = (tid == 0) && (first != *start_io);
-    if (!dirty) start = *start_io;
-    endpos = *endpos_io;
-    cnt = *cnt_io;
-  }
-  for (;;) {
-    if (dirty) {
-      uint32_t pos = start;
-      unsigned long long c = 0;
-      if (pos < lim) {
-        BitReader br;
-        br.init(pv, pos);
-        do {
-          const Step t = next_step(br, pv, tb, pos, lim, ~0ull);
-          pos += t.nbits ? t.nbits : 1;
-          c += (unsigned long long)(t.count > 0 ? t.count : 0);
-        } while (pos < lim);
-      }
-      endpos = pos;
-      cnt = c;
-    }
-    sh->nxt[tid + 1] = endpos;
-    __syncthreads();
-    const uint32_t ns = tid == 0 ? first : sh->nxt[tid];
-    dirty = (ns != start);
-    start = ns;
-    ++*rounds;
-    if (!__syncthreads_or(dirty ? 1 : 0)) break;
-  }
-  *start_io = start;
-  *endpos_io = endpos;
-  *cnt_io = cnt;
-}
-
-// Write the symbols of one chunk through 32 KiB LDS windows (zero runs are the
-// window's zero fill; windows are flushed with 16-byte stores).  Lane t decodes
-// the tokens starting in [bp, lim) and places them from output offset `op`.
-template <class PV>
-__device__ __forceinline__ void write_chunk_windows(const PV &pv, const DecTables &tb,
-                                                    StreamShared *sh, uint32_t bp, uint32_t lim,
-                                                    unsigned long long op, unsigned long long O0,
-                                                    unsigned long long O1, uint32_t out_size,
-                                                    unsigned long long endbit_base, uint32_t rel0,
-                                                    uint32_t *win, uint8_t *gout) {
-  const int tid = threadIdx.x;
-  bool done = !(bp < lim) || op >= out_size;
-  BitReader br;
-  if (!done) br.init(pv, bp);
-  for (unsigned long long wb = (O0 / kWinBytes) * kWinBytes; wb < O1; wb += kWinBytes) {
-    for (int k = tid; k < kWinBytes / 4; k += kDecThreads) win[k] = 0;
-    __syncthreads();
-    const unsigned long long we = wb + kWinBytes;
-    while (!done && op < we) {
-      // A group may not straddle the window end: cap `room` at the window.
-      const unsigned long long room = (out_size < we ? out_size : we) - op;
-      const Step t = next_step(br, pv, tb, bp, lim, room);
-      if (t.count < 0 || t.nbits == 0) { sh->err = 1; done = true; break; }
-      if (t.nlit) {
-        uint8_t *o = reinterpret_cast<uint8_t *>(win) + (uint32_t)(op - wb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t b = (t.bytes >> (8 * i)) & 255u;
-          if (i < t.nlit && b) o[i] = (uint8_t)b;
-        }
-      } else if (op + (unsigned long long)t.count > out_size) {
-        sh->err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
-        done = true;
-        break;
-      }
-      op += (unsigned long long)t.count;
-      bp += t.nbits;
-      if (op >= out_size) { sh->endbit = endbit_base + (bp - rel0); done = true; }
-      else if (!(bp < lim)) done = true;
-    }
-    __syncthreads();
-    // Flush [max(wb, O0), min(we, O1)): 16-byte stores inside, bytes at the edges
-    // (another workgroup may own the rest of an edge group).
-    const unsigned long long lo = wb > O0 ? wb : O0, hi = we < O1 ? we : O1;
-    const uint32_t l = (uint32_t)(lo - wb), h = (uint32_t)(hi - wb);
-    const uint32_t la = (l + 15u) & ~15u, ha = h & ~15u;
-    const uint8_t *w8 = reinterpret_cast<const uint8_t *>(win);
-    if (la <= ha && (((uintptr_t)(gout + wb)) & 15) == 0) {
-      for (uint32_t k = l + tid; k < la; k += kDecThreads) gout[wb + k] = w8[k];
-      for (uint32_t k = la / 16 + tid; k < ha / 16; k += kDecThreads) {
-        uint4 q;
-        q.x = win[4 * k]; q.y = win[4 * k + 1]; q.z = win[4 * k + 2]; q.w = win[4 * k + 3];
-        *reinterpret_cast<uint4 *>(gout + wb + 16ull * k) = q;
-      }
-      for (uint32_t k = ha + tid; k < h; k += kDecThreads) gout[wb + k] = w8[k];
-    } else {
-      for (uint32_t k = l + tid; k < h; k += kDecThreads) gout[wb + k] = w8[k];
-    }
-    __syncthreads();
-  }
-}
-
-// Payload view of the chunk that starts at absolute stream bit `abs_bit`: either
-// staged in LDS (transposed) or read in place from global memory.
-template <int WPS>
-__device__ __forceinline__ void make_view(const uint8_t *p, uint32_t stream_size,
-                                          unsigned long long abs_bit, uint32_t *pay,
-                                          PayView<WPS> *pv, uint32_t *rel0) {
-  pv->pay = pay;
-  *rel0 = stage_chunk<WPS>(p, stream_size, abs_bit, pay);
-}
-template <int WPS>
-__device__ __forceinline__ void make_view(const uint8_t *p, uint32_t stream_size,
-                                          unsigned long long abs_bit, uint32_t *pay,
-                                          GlobalView *pv, uint32_t *rel0) {
-  (void)pay;
-  pv->p = p;
-  pv->gb = (uint32_t)(abs_bit >> 5) * 4u;
-  pv->stream_size = stream_size;
-  *rel0 = (uint32_t)(abs_bit - 8ull * pv->gb);
-}
-
-// Decode one whole stream with one workgroup, chunk after chunk (each chunk's
-// first token position is exact because the previous chunk has finished).
-// FUSED: the whole output (out_size bytes) lives in LDS at `lds_out` (pre-zeroed
-// by the caller) and literals are written there directly; otherwise they go
-// through the LDS window to `gout`.  Returns (to every lane) 0 when the stream is
-// accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
-template <int WPS, bool FUSED, bool USE_GLOBAL>
-__device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
-                             uint32_t pay_len, uint32_t out_size, uint32_t *pay,
-                             const DecTables &tb, StreamShared *sh, uint8_t *lds_out,
-                             uint32_t *win, uint8_t *gout, uint32_t *stats) {
-  constexpr int kSubBits = WPS * 32;
-  constexpr int kChunkBits = kDecThreads * kSubBits;
-  const int tid = threadIdx.x;
-  typedef typename std::conditional<USE_GLOBAL, GlobalView, PayView<WPS> >::type PV;
-  if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
-  __syncthreads();
-
-  const unsigned long long P1 = 8ull * pay_len;  // payload end, in bits from pay_off
-  unsigned long long cur = 0;                    // exact bit position of the next token
-  unsigned long long O0 = 0;                     // symbols produced so far
-  uint32_t st_chunks = 0, st_rounds = 0;
-  long long c_stage = 0, c_sync = 0, c_write = 0, c_t0 = clock64();
-
-  while (cur < P1 && O0 < out_size) {
-    PV pv;
-    uint32_t rel0;
-    make_view<WPS>(p, stream_size, 8ull * pay_off + cur, pay, &pv, &rel0);
-    { const long long t = clock64(); c_stage += t - c_t0; c_t0 = t; ++st_chunks; }
-
-    const unsigned long long rem = P1 - cur;
-    const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kChunkBits ? rem : kChunkBits);
-    const uint32_t my_b0 = rel0 + tid * kSubBits;
-    uint32_t lim = rel0 + (tid + 1) * kSubBits;
-    if (lim > rel_end) lim = rel_end;
-
-    uint32_t start, endpos;
-    unsigned long long cnt;
-    fixpoint_chunk(pv, tb, sh, rel0, my_b0, lim, rel_end, &start, &endpos, &cnt, &st_rounds);
-    { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
-
-    unsigned long long tot;
-    const unsigned long long off = block_scan_u64(cnt, sh->sm64, &tot);
-    const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
-
-    if (FUSED) {
-      uint32_t bp = start;
-      unsigned long long op = O0 + off;
-      bool done = !(bp < lim) || op >= out_size;
-      BitReader br;
-      if (!done) br.init(pv, bp);
-      while (!done) {
-        const Step t = next_step(br, pv, tb, bp, lim, (unsigned long long)out_size - op);
-        if (t.count < 0 || t.nbits == 0) { sh->err = 1; break; }
-        if (t.nlit) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t b = (t.bytes >> (8 * i)) & 255u;
-            if (i < t.nlit && b) lds_out[op + i] = (uint8_t)b;
-          }
-        } else if (op + (unsigned long long)t.count > out_size) {
-          sh->err = 1;  // zero run overruns the block (huffman_dec.cpp:353-354,410-411)
-          break;
-        }
-        op += (unsigned long long)t.count;
-        bp += t.nbits;
-        if (op >= out_size) { sh->endbit = cur + (bp - rel0); done = true; }
-        else if (!(bp < lim)) done = true;
-      }
-      __syncthreads();
-    } else {
-      write_chunk_windows(pv, tb, sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win, gout);
-    }
-    { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
-
-    // ---- advance to the next chunk ----
-    if (tid == kDecThreads - 1) sh->nxt[0] = endpos;
-    __syncthreads();
-    const uint32_t last_end = sh->nxt[0];
-    cur += (unsigned long long)(last_end - rel0);
-    O0 += tot;
-    if (last_end == rel0) break;  // no progress (cannot happen on a valid stream)
-    __syncthreads();
-  }
-  __syncthreads();
-
-  // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
-  int bad = sh->err;
-  if (O0 < out_size) bad = 1;  // ran out of payload before the block was full
-  const unsigned long long E = sh->endbit;
-  // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
-  if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
-  if (tid == 0 && stats) {
-    stats[0] = st_chunks; stats[1] = st_rounds; stats[2] = 0;
-    stats[3] = (uint32_t)(c_stage >> 4); stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
-    stats[6] = pay_len; stats[7] = out_size;
-  }
-  return bad;
-}
-
-// ---------------------------------------------------------------------------
-// Lean decode path (fused row kernel, payload read in place from L2).
-//
-// The decode passes are bound by VALU issue, so their inner loops are kept to a
-// handful of instructions per step: one 64-bit bit window with a two-deep word
-// prefetch, ONE table read per step, and no per-token classification.
-//
-// Group table entry (uint2), indexed by the next kLutBits stream bits:
-//   .x  the first 4 output bytes of the group (0 where the output is a zero)
-//   .y  [3:0]   code bits of the whole group   [7:4]   extra bits that follow them
-//       [16:8]  symbols it produces, before the extra-bits value is added
-//       [20:17] code bits of its first token    [23:21] class of the first token:
-//               0 literal / single zero, 1 two zeros, 2..5 zero runs 257..260
-//   .y == 0: the first code is longer than the table; .x = node | depth << 16
-//            is where the tree walk continues.
-// A lane owns the tokens that START in [start, lim): the whole group is taken
-// while pos + kLutBits <= lim (every token of it then starts before lim), the
-// first token alone otherwise.
-// ---------------------------------------------------------------------------
-struct GrpTables {
-  const uint2 *grp;           // LDS, 1 << kLutBits entries
-  const short *ca, *cb, *sy;  // LDS tree nodes
-};
-
-struct __attribute__((packed)) PackedU32 { uint32_t v; };
-
 // Bit window over the stream's dwords in global memory.  Word indices are
 // clamped to the dword that holds the stream's last byte: bits past the end of
 // the stream repeat that dword, which only a token that overruns the payload can
@@ -893,6 +461,15 @@ struct GReader {
                        // touched by the next one, so its latency hides behind ~3 steps.
                        // (It must land in `pre` untouched -- any move or mask of the
                        // loaded register makes the compiler wait for it on the spot.)
+  // Window over the stream `p` (4-byte aligned, stream_size bytes) whose bit 0 is
+  // the dword holding absolute stream bit abs_bit; returns abs_bit's offset in it.
+  __device__ __forceinline__ uint32_t attach(const uint8_t *p, uint32_t stream_size,
+                                             unsigned long long abs_bit) {
+    const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;
+    w = reinterpret_cast<const uint32_t *>(p + gb);
+    jmax = ((stream_size - 1u) >> 2) - (gb >> 2);
+    return (uint32_t)(abs_bit - 8ull * gb);
+  }
   __device__ __forceinline__ uint32_t ld(uint32_t j) const { return w[j < jmax ? j : jmax]; }
   __device__ __forceinline__ void init(uint32_t pos) {
     const uint32_t j = pos >> 5, sh = pos & 31;
@@ -989,10 +566,46 @@ __device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint
   *count = c;
 }
 
-// Write pass of one lane: the tokens that start in [bp, lim) go to lds_out
-// (pre-zeroed) from offset op.  The group's bytes are OR-ed in with two aligned
-// ds_or (the bytes past the group are zeros, so neighbours are never disturbed).
-// The caller guarantees that all of the lane's symbols lie inside the block.
+// Speculative decode of one chunk to the self-synchronised fixpoint.  On return
+// lane t owns exactly the tokens that START in [*start, lim) -- given that lane
+// 0's start `first` is exact (asserted or assumed by the caller).
+// Cold: *start = nominal start, the lane decodes in round 1 iff `active`.
+// Warm: (*start, *endpos, *cnt) hold a fixpoint reached for another `first`; only
+// lanes whose start changes decode again.
+// Lanes whose range lies beyond the payload (`active` false) own nothing and stay
+// out of it: passing the chain's end along them would cost one round per lane.
+__device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, StreamShared *sh,
+                                              uint32_t first, bool active, uint32_t lim,
+                                              uint32_t *start_io, uint32_t *endpos_io,
+                                              uint32_t *cnt_io, uint32_t *rounds, bool warm) {
+  const int tid = threadIdx.x;
+  uint32_t start = *start_io, endpos = *endpos_io, cnt = *cnt_io;
+  bool dirty = active;
+  if (tid == 0 && !warm) start = first;
+  if (warm) {
+    dirty = (tid == 0) && (first != start);
+    if (dirty) start = first;
+  }
+  for (;;) {
+    if (dirty) lean_count(rd, tb, start, lim, &endpos, &cnt);
+    sh->nxt[tid + 1] = endpos;
+    __syncthreads();
+    const uint32_t ns = tid == 0 ? first : sh->nxt[tid];
+    dirty = active && (ns != start);
+    if (active) start = ns;
+    ++*rounds;
+    if (!__syncthreads_or(dirty ? 1 : 0)) break;
+  }
+  *start_io = start;
+  *endpos_io = endpos;
+  *cnt_io = cnt;
+}
+
+// Write pass of one lane straight into LDS: the tokens that start in [bp, lim)
+// go to lds_out (pre-zeroed) from offset op.  The group's bytes are OR-ed in with
+// two aligned ds_or (the bytes past the group are zeros, so neighbours are never
+// disturbed).  The caller guarantees that all of the lane's symbols lie strictly
+// inside the block.
 __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint32_t bp,
                                            uint32_t lim, uint32_t op, uint8_t *lds_out) {
   bool bad = false;
@@ -1037,29 +650,90 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
   }
 }
 
-// Fused decode of one FRES block row into LDS with the lean passes.  Same
-// contract as decode_stream<.., FUSED = true, USE_GLOBAL = true>.  The row is
-// normally ONE chunk: the sub-sequence length is chosen so that the 1024 lanes
-// cover the whole payload.
-__device__ int decode_row_lean(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
-                               uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
-                               StreamShared *sh, uint8_t *lds_out, uint32_t *stats) {
+// Write pass to HBM through 32 KiB LDS windows (zero runs are the window's zero
+// fill; windows are flushed with 16-byte stores).  Lane t decodes the tokens that
+// start in [bp, lim) and places them from output offset op; `exact` marks the lane
+// in whose range the block completes.  win holds kWinBytes / 4 + 1 words.
+__device__ __forceinline__ void lean_write_windows(GReader &rd, const GrpTables &tb,
+                                                   StreamShared *sh, uint32_t bp, uint32_t lim,
+                                                   unsigned long long op, bool exact,
+                                                   unsigned long long O0, unsigned long long O1,
+                                                   uint32_t out_size,
+                                                   unsigned long long endbit_base, uint32_t rel0,
+                                                   uint32_t *win, uint8_t *gout) {
+  const int tid = threadIdx.x;
+  bool done = !(bp < lim) || op >= out_size;
+  bool bad = false;
+  if (!done) rd.init(bp);
+  const int limk = (int)lim - kLutBits;
+  for (unsigned long long wb = (O0 / kWinBytes) * kWinBytes; wb < O1; wb += kWinBytes) {
+    for (int k = tid; k < kWinBytes / 4 + 1; k += kDecThreads) win[k] = 0;
+    __syncthreads();
+    const unsigned long long we = wb + kWinBytes;
+    while (!done && op < we) {
+      // The explicit bytes of a group may not straddle the window end.
+      const bool single = exact || (int)bp > limk || op + 4 > we;
+      uint32_t nbits, cnt, by;
+      lean_step<true>(rd, tb, single, &nbits, &cnt, &by, &bad);
+      if (exact && (bad || op + cnt > out_size)) { bad = true; break; }
+      const uint32_t o = (uint32_t)(op - wb);
+      const unsigned long long v = (unsigned long long)by << (8u * (o & 3u));
+      atomicOr(&win[o >> 2], (uint32_t)v);
+      atomicOr(&win[(o >> 2) + 1], (uint32_t)(v >> 32));
+      op += cnt;
+      bp += nbits;
+      if (exact && op >= out_size) { sh->endbit = endbit_base + (bp - rel0); done = true; }
+      else if (!(bp < lim)) done = true;
+    }
+    if (bad) { sh->err = 1; done = true; }
+    __syncthreads();
+    // Flush [max(wb, O0), min(we, O1)): 16-byte stores inside, bytes at the edges
+    // (another workgroup may own the rest of an edge group).
+    const unsigned long long lo = wb > O0 ? wb : O0, hi = we < O1 ? we : O1;
+    const uint32_t l = (uint32_t)(lo - wb), h = (uint32_t)(hi - wb);
+    const uint32_t la = (l + 15u) & ~15u, ha = h & ~15u;
+    const uint8_t *w8 = reinterpret_cast<const uint8_t *>(win);
+    if (la <= ha && (((uintptr_t)(gout + wb)) & 15) == 0) {
+      for (uint32_t k = l + tid; k < la; k += kDecThreads) gout[wb + k] = w8[k];
+      for (uint32_t k = la / 16 + tid; k < ha / 16; k += kDecThreads) {
+        uint4 q;
+        q.x = win[4 * k]; q.y = win[4 * k + 1]; q.z = win[4 * k + 2]; q.w = win[4 * k + 3];
+        *reinterpret_cast<uint4 *>(gout + wb + 16ull * k) = q;
+      }
+      for (uint32_t k = ha + tid; k < h; k += kDecThreads) gout[wb + k] = w8[k];
+    } else {
+      for (uint32_t k = l + tid; k < h; k += kDecThreads) gout[wb + k] = w8[k];
+    }
+    __syncthreads();
+  }
+}
+
+// Decode one whole stream with one workgroup, chunk after chunk (each chunk's
+// first token position is exact because the previous chunk has finished).  The
+// sub-sequence length is chosen so that the 1024 lanes cover the remaining payload
+// (one chunk, normally).
+// FUSED: the whole output (out_size bytes) lives in LDS at `lds_out` (pre-zeroed
+// by the caller) and the bytes are OR-ed in there; otherwise they go through the
+// LDS window `win` to `gout`.  Returns (to every lane) 0 when the stream is
+// accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
+template <bool FUSED>
+__device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
+                             uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
+                             StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
+                             uint32_t *stats) {
   const int tid = threadIdx.x;
   if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
   __syncthreads();
 
-  const unsigned long long P1 = 8ull * pay_len;
-  unsigned long long cur = 0, O0 = 0;
+  const unsigned long long P1 = 8ull * pay_len;  // payload end, in bits from pay_off
+  unsigned long long cur = 0;                    // exact bit position of the next token
+  unsigned long long O0 = 0;                     // symbols produced so far
   uint32_t st_chunks = 0, st_rounds = 0;
   long long c_sync = 0, c_write = 0, c_t0 = clock64();
 
   while (cur < P1 && O0 < out_size) {
-    const unsigned long long abs_bit = 8ull * pay_off + cur;
-    const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;
-    const uint32_t rel0 = (uint32_t)(abs_bit - 8ull * gb);
     GReader rd;
-    rd.w = reinterpret_cast<const uint32_t *>(p + gb);
-    rd.jmax = ((stream_size - 1u) >> 2) - (gb >> 2);
+    const uint32_t rel0 = rd.attach(p, stream_size, 8ull * pay_off + cur);
     ++st_chunks;
 
     const unsigned long long rem = P1 - cur;
@@ -1071,49 +745,49 @@ __device__ int decode_row_lean(const uint8_t *p, uint32_t stream_size, uint32_t 
     const uint32_t my_b0 = rel0 + (uint32_t)tid * sub;
     uint32_t lim = my_b0 + sub;
     if (lim > rel_end) lim = rel_end;
+    const bool active = my_b0 < rel_end;
+    const int last_active = (int)((rel_end - rel0 - 1u) / sub);
 
-    // Speculative decode to the self-synchronised fixpoint (see fixpoint_chunk).
-    uint32_t start = my_b0 < rel_end ? my_b0 : rel_end;
-    uint32_t endpos = start, cnt = 0;
-    bool dirty = true;
-    for (;;) {
-      if (dirty) lean_count(rd, tb, start, lim, &endpos, &cnt);
-      sh->nxt[tid + 1] = endpos;
-      __syncthreads();
-      const uint32_t ns = tid == 0 ? rel0 : sh->nxt[tid];
-      dirty = (ns != start);
-      start = ns;
-      ++st_rounds;
-      if (!__syncthreads_or(dirty ? 1 : 0)) break;
-    }
+    uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0;
+    lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false);
     { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
 
     unsigned long long tot;
     const unsigned long long off = block_scan_u64(cnt, sh->sm64, &tot);
     const unsigned long long opl = O0 + off;
-    uint32_t end_bp = ~0u;
-    if (opl + cnt < out_size) {
-      if (!lean_write(rd, tb, start, lim, (uint32_t)opl, lds_out)) sh->err = 1;
-    } else if (opl < out_size) {
-      if (!exact_write(rd, tb, start, lim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
+    // The lane in whose range the block completes takes the exact path.
+    const bool inside = opl + cnt < out_size, exact = !inside && opl < out_size;
+    if (FUSED) {
+      uint32_t end_bp = ~0u;
+      if (inside) {
+        if (!lean_write(rd, tb, start, lim, (uint32_t)opl, lds_out)) sh->err = 1;
+      } else if (exact) {
+        if (!exact_write(rd, tb, start, lim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
+      }
+      if (end_bp != ~0u) sh->endbit = cur + (end_bp - rel0);
+      __syncthreads();
+    } else {
+      const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
+      lean_write_windows(rd, tb, sh, start, lim, opl, exact, O0, O1, out_size, cur, rel0, win, gout);
     }
-    if (end_bp != ~0u) sh->endbit = cur + (end_bp - rel0);
-    __syncthreads();
     { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
 
-    if (tid == kDecThreads - 1) sh->nxt[0] = endpos;
+    // ---- advance to the next chunk ----
+    if (tid == last_active) sh->nxt[0] = endpos;
     __syncthreads();
     const uint32_t last_end = sh->nxt[0];
     cur += (unsigned long long)(last_end - rel0);
     O0 += tot;
-    if (last_end == rel0) break;
+    if (last_end == rel0) break;  // no progress (cannot happen on a valid stream)
     __syncthreads();
   }
   __syncthreads();
 
+  // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
   int bad = sh->err;
-  if (O0 < out_size) bad = 1;
+  if (O0 < out_size) bad = 1;  // ran out of payload before the block was full
   const unsigned long long E = sh->endbit;
+  // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
   if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
   if (tid == 0 && stats) {
     stats[0] = st_chunks; stats[1] = st_rounds; stats[2] = 0;
@@ -1123,17 +797,17 @@ __device__ int decode_row_lean(const uint8_t *p, uint32_t stream_size, uint32_t 
   return bad;
 }
 
+// Tree nodes and group table of stream `strm` of frame f -> LDS.
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
-                                                uint32_t *lut, uint2 *lut2, short *ca, short *cb,
-                                                short *sy) {
+                                                uint2 *grp, short *ca, short *cb, short *sy) {
   const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
   const int nn = df->s[strm].num_nodes;
   for (int k = threadIdx.x; k < nn; k += kDecThreads) {
     ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
   }
-  const uint32_t *gl = ws.lut + ((size_t)f * 2 + strm) * (1u << kLutBits);
-  const uint2 *gl2 = ws.lut2 + ((size_t)f * 2 + strm) * (1u << kLutBits);
-  for (int k = threadIdx.x; k < (1 << kLutBits); k += kDecThreads) { lut[k] = gl[k]; lut2[k] = gl2[k]; }
+  const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + strm) * (1u << kLutBits));
+  for (int k = threadIdx.x; k < (1 << kLutBits) / 2; k += kDecThreads)
+    reinterpret_cast<uint4 *>(grp)[k] = gg[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -1144,10 +818,8 @@ __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame 
 __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, const uint8_t *packed,
                                                           size_t in_stride, const uint32_t *sizes,
                                                           int first_block, int lres_fallback_only) {
-  __shared__ uint32_t pay[8 * (kDecThreads + 2)];
-  __shared__ uint32_t win[kWinBytes / 4];
-  __shared__ uint32_t lut[1 << kLutBits];
-  __shared__ uint2 lut2[1 << kLutBits];
+  __shared__ uint32_t win[kWinBytes / 4 + 1];
+  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
 
@@ -1171,13 +843,12 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
   }
-  load_dec_tables(ws, df, f, strm, lut, lut2, ca, cb, sy);
+  load_dec_tables(ws, df, f, strm, grp, ca, cb, sy);
   __syncthreads();
-  DecTables tb;
-  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const int bad = decode_stream<8, false, false>(p, sizes[f], pay_off, pay_len, out_size, pay, tb, &sh,
-                                          nullptr, win, out,
-                                          ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
+  GrpTables tb;
+  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
+                                       out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
   if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
 }
 
@@ -1201,15 +872,13 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
 // If an end did change (a mis-speculation ran through a whole 32 KiB chunk) the
 // frame falls back to the serial workgroup-per-stream path (k_dec_huff).
 // ---------------------------------------------------------------------------
-constexpr int kLresWps = 8;
-constexpr int kLresChunkBits = kDecThreads * kLresWps * 32;
+constexpr int kLresSubBits = 256;   // bits per lane
+constexpr int kLresChunkBits = kDecThreads * kLresSubBits;
 
 template <bool FIX>
 __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, const uint8_t *packed,
                                                             size_t in_stride, const uint32_t *sizes) {
-  __shared__ uint32_t pay[kLresWps * (kDecThreads + 2)];
-  __shared__ uint32_t lut[1 << kLutBits];
-  __shared__ uint2 lut2[1 << kLutBits];
+  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -1228,40 +897,33 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     if (tid == 0) ws.fix_end[slot] = ws.spec_end[slot];
     return;
   }
-  load_dec_tables(ws, df, f, 0, lut, lut2, ca, cb, sy);
-  DecTables tb;
-  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  load_dec_tables(ws, df, f, 0, grp, ca, cb, sy);
+  GrpTables tb;
+  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
+  const unsigned long long rem = P1 - cur;
+  const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
+  const uint32_t my_b0 = rel0 + tid * kLresSubBits;
+  uint32_t lim = my_b0 + kLresSubBits;
+  if (lim > rel_end) lim = rel_end;
+  const bool active = my_b0 < rel_end;
+  const int last_active = (int)((rel_end - rel0 - 1u) / kLresSubBits);
+  __syncthreads();
   if (FIX) {
     // Cheap test first: lane 0 re-decodes its own sub-sequence from the true start
-    // T (payload read in place, nothing staged).  If it ends where its speculative
-    // chain ended, no other lane changes and the chunk is done.
-    __syncthreads();
+    // T.  If it ends where its speculative chain ended, no other lane changes and
+    // the chunk is done.
     if (tid == 0) {
       const unsigned long long T = ws.spec_end[slot - 1];
       sh.flag = 0;
-      if (T >= cur && T < cur + kLresWps * 32) {
-        GlobalView gv;
-        uint32_t grel0;
-        make_view<kLresWps>(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur, nullptr,
-                            &gv, &grel0);
-        unsigned long long lim_abs = cur + kLresWps * 32;
-        if (lim_abs > P1) lim_abs = P1;
-        uint32_t pos = grel0 + (uint32_t)(T - cur);
-        const uint32_t lim = grel0 + (uint32_t)(lim_abs - cur);
-        unsigned long long c = 0;
-        if (pos < lim) {
-          BitReader br;
-          br.init(gv, pos);
-          do {
-            const Step t = next_step(br, gv, tb, pos, lim, ~0ull);
-            pos += t.nbits ? t.nbits : 1;
-            c += (unsigned long long)(t.count > 0 ? t.count : 0);
-          } while (pos < lim);
-        }
-        if (pos - grel0 == ws.spec_endpos[slot * kDecThreads]) {
+      if (T >= cur && T < cur + kLresSubBits) {
+        uint32_t pos, c;
+        lean_count(rd, tb, rel0 + (uint32_t)(T - cur), lim, &pos, &c);
+        if (pos - rel0 == ws.spec_endpos[slot * kDecThreads]) {
           const unsigned long long oldc = ws.spec_cnt[slot * kDecThreads];
           ws.spec_start[slot * kDecThreads] = (uint32_t)(T - cur);
-          ws.spec_cnt[slot * kDecThreads] = (uint32_t)(c < 0xffffffffull ? c : 0xffffffffull);
+          ws.spec_cnt[slot * kDecThreads] = c;
           ws.spec_tot[slot] = ws.spec_tot[slot] - oldc + c;
           ws.fix_end[slot] = ws.spec_end[slot];
           sh.flag = 1;
@@ -1273,20 +935,11 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     __syncthreads();
     if (sh.flag) return;
   }
-  const PayView<kLresWps> pv = {pay};
-  const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
-                                              8ull * pay_off + cur, pay);
-  const unsigned long long rem = P1 - cur;
-  const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
-  const uint32_t my_b0 = rel0 + tid * (kLresWps * 32);
-  uint32_t lim = rel0 + (tid + 1) * (kLresWps * 32);
-  if (lim > rel_end) lim = rel_end;
-  uint32_t start = 0, endpos = 0, rounds = 0, first = rel0;
-  unsigned long long cnt = 0, tot;
+  uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0, first = rel0;
   if (FIX) {
     const unsigned long long T = ws.spec_end[slot - 1];
     // A token is at most 46 bits, so the true first token lies in lane 0's range.
-    if (T < cur || T >= cur + kLresWps * 32) {
+    if (T < cur || T >= cur + kLresSubBits) {
       if (tid == 0) ws.fix_end[slot] = ~0ull;  // forces the serial path
       return;
     }
@@ -1295,13 +948,13 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     endpos = rel0 + ws.spec_endpos[slot * kDecThreads + tid];
     cnt = ws.spec_cnt[slot * kDecThreads + tid];
   }
-  fixpoint_chunk(pv, tb, &sh, first, my_b0, lim, rel_end, &start, &endpos, &cnt, &rounds,
-                           FIX);
+  lean_fixpoint(rd, tb, &sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX);
+  unsigned long long tot;
   block_scan_u64(cnt, sh.sm64, &tot);
   ws.spec_start[slot * kDecThreads + tid] = start - rel0;
   ws.spec_endpos[slot * kDecThreads + tid] = endpos - rel0;
-  ws.spec_cnt[slot * kDecThreads + tid] = (uint32_t)(cnt < 0xffffffffull ? cnt : 0xffffffffull);
-  if (tid == kDecThreads - 1) { end_out[slot] = cur + (endpos - rel0); ws.spec_tot[slot] = tot; }
+  ws.spec_cnt[slot * kDecThreads + tid] = cnt;
+  if (tid == last_active) { end_out[slot] = cur + (endpos - rel0); ws.spec_tot[slot] = tot; }
   if (tid == 0) {
     uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1)) * 8;
     atomicAdd(&st[FIX ? 2 : 0], 1u);
@@ -1337,10 +990,8 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_verify(Geom g, DecWs ws) {
 
 __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, const uint8_t *packed,
                                                             size_t in_stride, const uint32_t *sizes) {
-  __shared__ uint32_t pay[kLresWps * (kDecThreads + 2)];
-  __shared__ uint32_t win[kWinBytes / 4];
-  __shared__ uint32_t lut[1 << kLutBits];
-  __shared__ uint2 lut2[1 << kLutBits];
+  __shared__ uint32_t win[kWinBytes / 4 + 1];
+  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -1354,24 +1005,26 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const size_t slot = (size_t)f * ws.lres_chunks + k;
   const unsigned long long O0 = ws.ver_base[slot];
   if (O0 >= out_size) return;
-  load_dec_tables(ws, df, f, 0, lut, lut2, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, grp, ca, cb, sy);
   if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
-  DecTables tb;
-  tb.lut = lut; tb.lut2 = lut2; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const PayView<kLresWps> pv = {pay};
-  const uint32_t rel0 = stage_chunk<kLresWps>(packed + (size_t)f * in_stride, sizes[f],
-                                              8ull * pay_off + cur, pay);
+  GrpTables tb;
+  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
   const unsigned long long rem = P1 - cur;
   const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
-  uint32_t lim = rel0 + (tid + 1) * (kLresWps * 32);
+  uint32_t lim = rel0 + (tid + 1) * kLresSubBits;
   if (lim > rel_end) lim = rel_end;
   const uint32_t start = rel0 + ws.spec_start[slot * kDecThreads + tid];
   const unsigned long long cnt = ws.spec_cnt[slot * kDecThreads + tid];
+  __syncthreads();
   unsigned long long tot;
   const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
   const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
-  write_chunk_windows(pv, tb, &sh, start, lim, O0 + off, O0, O1, out_size, cur, rel0, win,
-                                ws.lres_sym + (size_t)f * ws.lres_stride);
+  const unsigned long long opl = O0 + off;
+  const bool exact = !(opl + cnt < out_size) && opl < out_size;
+  lean_write_windows(rd, tb, &sh, start, lim, opl, exact, O0, O1, out_size, cur, rel0, win,
+                     ws.lres_sym + (size_t)f * ws.lres_stride);
   __syncthreads();
   if (tid == 0) {
     if (sh.err) atomicMax(&df->status, fmt_err(4, 1));
@@ -1571,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // ---------------------------------------------------------------------------
 // k_dec_row_fused: one 1024-lane workgroup per FRES block row, when the row's
 // symbols fit in LDS (row_block <= ~128 KiB, i.e. width <= 4096 for RGBA).
-//   1. entropy-decode the row into LDS (decode_stream<FUSED>);
+//   1. entropy-decode the row into LDS (decode_stream<true>);
 //   2. lane = tile: gather, dequantise, inverse WHT, + low-res, clamp; results
 //      overwrite the tile's own 64 symbol slots per channel (in place);
 //   3. lane = (tile, pixel row): colour inverse and two 16-byte stores, so a wave
@@ -1622,15 +1275,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  {
-    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
-    const int nn = df->s[1].num_nodes;
-    for (int k = tid; k < nn; k += kDecThreads) {
-      ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
-    }
-    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
-    for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) reinterpret_cast<uint4 *>(grp)[k] = gg[k];
-  }
+  load_dec_tables(ws, df, f, 1, grp, ca, cb, sy);
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -1647,9 +1292,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 
   GrpTables tb;
   tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const int bad = decode_row_lean(
+  const int bad = decode_stream<true>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
-      (uint32_t)g.row_block, tb, sh, sym, ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8);
+      (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
+      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8);
   if (bad) {
     if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
     return;

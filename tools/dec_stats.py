@@ -17,3 +17,8 @@ print("LRES:", dict(zip(names, st[0].tolist())))
 fr = st[1:].astype(np.float64)
 for i, n in enumerate(names):
     print("FRES %-14s mean %.1f min %.0f max %.0f" % (n, fr[:, i].mean(), fr[:, i].min(), fr[:, i].max()))
+if len(sys.argv) > 2:
+    np.save(sys.argv[2], st)
+    r = st[1:, 1]
+    print("rounds histogram:", np.bincount(np.minimum(r, 60) // 5))
+    print("rows with most rounds:", np.argsort(-r.astype(int))[:16].tolist(), np.sort(r)[::-1][:16].tolist())
