@@ -72,6 +72,8 @@ struct LresTables {
 
 constexpr int kLutBits = 11;  // width of the Huffman decode group table
 constexpr int kDecThreads = 1024;
+constexpr int kSubEntries = 1024;  // second-level decode table (codes longer than kLutBits)
+constexpr int kSubMaxBits = 6;     // widest second-level sub-table
 
 struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
   uint32_t payload_off;      // byte offset (in the packed stream) after the aligned tree
@@ -92,12 +94,14 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
 struct DecWs {
   DecFrame *frames;          // [f]
   int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
-  uint2 *grp;                // [f][2][1<<kLutBits] group table of the lean decoder (kernels_dec.hip GrpTables)
+  uint2 *grp;                // [f][2][1<<kLutBits] group table (kernels_dec.hip GrpTables)
+  uint32_t *sub;             // [f][2][kSubEntries] second-level entries for codes longer than kLutBits
   uint32_t *row_off;         // [f][rows] payload byte offset of each FRES row
   uint32_t *row_len;         // [f][rows]
   uint8_t *lres_sym;         size_t lres_stride;
   uint8_t *fres_sym;         size_t fres_stride;
   uint8_t *low;              size_t plane_stride;
+  uint32_t *parse_stats;     // [f][4] k_dec_parse phase cycles / 16
   uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
   // Parallel LRES decode (k_lres_spec / verify / write).
   int lres_chunks;           // chunk slots per frame (upper bound from lres_size)

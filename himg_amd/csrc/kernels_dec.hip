@@ -38,6 +38,7 @@ constexpr int kStGeom = 1, kStUnsupported = 3, kStFormat = 4;
 __device__ __host__ constexpr int fmt_err(int stage, int huff) { return kStFormat | (stage << 4) | (huff << 8); }
 constexpr int kMaxDepth = 32;   // deepest code the decoder walks (the reference encoder keeps codes in uint32_t)
 constexpr int kMaxNodes = 2 * kNumSym - 1;
+constexpr int kMaxSlow = 128;   // kLutBits-bit prefixes that get a second-level sub-table
 
 __device__ __forceinline__ int clamp255d(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
@@ -157,147 +158,245 @@ __device__ __forceinline__ uint32_t lut_node(int node, int bits) {
 }
 
 // ---------------------------------------------------------------------------
-// k_dec_parse: one wavefront per frame; lane 0 walks the container, the whole
-// wave fills the two first-level decode LUTs.
+// k_dec_parse: one 256-thread workgroup per frame.
+//   1. thread 0 walks the chunk headers only (decoder.cpp:144-290): RIFF, FRMT,
+//      LMAP, LRES, QCFG, FMAP, FRES -- a chain of dependent global reads;
+//   2. the workgroup stages the small bodies (mapping tables, QCFG, the two
+//      serialised trees) in LDS;
+//   3. wave 0 recovers the LRES tree while wave 1 recovers the FRES tree (the two
+//      serial bit walks run concurrently); wave 2 parses the tables;
+//   4. the verdict is the FIRST failure in the reference's order of checks;
+//   5. all four waves build the decode tables.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_t *packed,
-                                                  size_t in_stride, const uint32_t *sizes) {
+constexpr int kParseThreads = 256;
+__global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, const uint8_t *packed,
+                                                             size_t in_stride, const uint32_t *sizes) {
   __shared__ TreeAux aux[2][kMaxNodes + 1];
   __shared__ uint32_t s_lut[2][1 << kLutBits];
-  __shared__ uint32_t s_buf[(kTreeStride + 16) / 4];  // staged chunk bytes (tree / mapping table)
-  __shared__ uint32_t s_idx, s_sz;                     // chunk body offset / size found by lane 0
-  __shared__ TreeStack s_stack;
+  __shared__ uint32_t s_sub[2][kSubEntries];
+  __shared__ uint16_t s_heap[2 << kLutBits], s_symd[kMaxNodes + 1];
+  __shared__ uint32_t s_nslow[2], s_slow_m[2][kMaxSlow], s_slow_off[2][kMaxSlow];
+  // Staged chunk bodies: 0 LMAP, 1 LRES tree, 2 QCFG, 3 FMAP, 4 FRES tree.
+  __shared__ uint32_t s_buf[5][(kTreeStride + 16) / 4];
+  __shared__ uint32_t s_off[5], s_sz[5];
+  __shared__ TreeStack s_stack[2];
+  // Verdict per check, in the reference's order (0 = passed / not reached).
+  enum { cHead = 0, cLmap, cLresFind, cLresTree, cQcfg, cFmapFind, cFmap, cFresFind, cFresTree, cLeaf0, cLeaf1, cCount };
+  __shared__ int s_chk[cCount];
   __shared__ int s_status;
-  const int f = blockIdx.x, lane = threadIdx.x;
+  const int f = blockIdx.x, lane = threadIdx.x;   // lane = thread index in the workgroup
+  const long long c_in = clock64();
   const uint8_t *p = packed + (size_t)f * in_stride;
   const uint32_t n = sizes[f];
   DecFrame *df = ws.frames + f;
   int32_t *nodes0 = ws.nodes + ((size_t)f * 2 + 0) * (kMaxNodes + 1) * 3;
   int32_t *nodes1 = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
-  uint8_t *s_bytes = reinterpret_cast<uint8_t *>(s_buf);
 
-  // The container walk is serial (lane 0); the bodies it needs to read byte by
-  // byte (mapping tables, serialised trees) are first staged in LDS by the whole
-  // wave, because a dependent global load costs ~1 us and an LDS read ~50 ns.
-  auto stage = [&]() {   // copies min(s_sz, capacity) bytes from p + s_idx; all lanes
-    __syncthreads();
-    const uint32_t cnt = s_status ? 0u : (s_sz < (uint32_t)kTreeStride ? s_sz : (uint32_t)kTreeStride);
-    for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16; k += 64)
-      s_bytes[k] = k < cnt ? p[s_idx + k] : (uint8_t)0;
-    __syncthreads();
-  };
-  if (lane == 0) { s_status = 0; s_idx = 0; s_sz = 0; }
-  uint32_t idx = 12, sz = 0;   // lane 0's cursor
+  if (lane < cCount) s_chk[lane] = 0;
+  if (lane < 5) { s_off[lane] = 0; s_sz[lane] = 0; }
+  __syncthreads();
 
-  if (lane == 0) {   // ---- A: RIFF, FRMT, locate LMAP (decoder.cpp:144-212)
-    int st = 0;
+  if (lane == 0) {   // ---- 1: chunk headers, in file order
+    uint32_t idx = 12, sz = 0;
     do {
       if (n < 12 || rd32(p) != 0x46464952u /*RIFF*/ || rd32(p + 4) + 8u != n ||
-          rd32(p + 8) != 0x474d4948u /*HIMG*/) { st = fmt_err(1, 0); break; }
-      if (!find_chunk(p, n, &idx, 0x544d5246u /*FRMT*/, &sz) || sz < 11 || p[idx] != 1) { st = fmt_err(2, 0); break; }
+          rd32(p + 8) != 0x474d4948u /*HIMG*/) { s_chk[cHead] = fmt_err(1, 0); break; }
+      if (!find_chunk(p, n, &idx, 0x544d5246u /*FRMT*/, &sz) || sz < 11 || p[idx] != 1) { s_chk[cHead] = fmt_err(2, 0); break; }
       const uint32_t w = rd32(p + idx + 1), h = rd32(p + idx + 5);
       const int c = p[idx + 9];
       df->ycbcr = (p[idx + 10] != 0 && c >= 3) ? 1 : 0;
-      if ((int)w != g.W || (int)h != g.H || c != g.C) { st = kStGeom; break; }
+      if ((int)w != g.W || (int)h != g.H || c != g.C) { s_chk[cHead] = kStGeom; break; }
       idx += sz;
-      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz)) { st = fmt_err(3, 0); break; }
-      s_idx = idx; s_sz = sz;
-    } while (0);
-    s_status = st;
-  }
-  stage();
-  if (lane == 0 && !s_status) {   // ---- B: LMAP body, locate LRES (decoder.cpp:202-232)
-    int st = 0;
-    do {
-      if (sz > (uint32_t)kTreeStride || !parse_map_lds(s_bytes, sz, df->lmap)) { st = fmt_err(3, 0); break; }
+      if (!find_chunk(p, n, &idx, 0x50414d4cu /*LMAP*/, &sz)) { s_chk[cHead] = fmt_err(3, 0); break; }
+      s_off[0] = idx; s_sz[0] = sz;
       idx += sz;
-      if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { st = fmt_err(4, 0); break; }
+      if (!find_chunk(p, n, &idx, 0x5345524cu /*LRES*/, &sz)) { s_chk[cLresFind] = fmt_err(4, 0); break; }
       df->s[0].chunk_end = idx + sz;
-      s_idx = idx; s_sz = sz;
-    } while (0);
-    s_status = st;
-  }
-  stage();
-  if (lane == 0 && !s_status) {   // ---- C: LRES tree, QCFG, locate FMAP (decoder.cpp:250-272)
-    int st = 0;
-    do {
-      uint32_t tb = 0;
-      st = recover_tree(s_buf, sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes0, aux[0],
-                        &df->s[0].num_nodes, &tb, &s_stack);
-      if (st) { if (st == kStFormat) st = fmt_err(4, 1); break; }
-      df->s[0].root = 0;
-      df->s[0].payload_off = idx + tb;
-      // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
-      if (df->s[0].payload_off >= df->s[0].chunk_end) { st = fmt_err(4, 1); break; }
+      s_off[1] = idx; s_sz[1] = sz;
       idx += sz;
-      if (!find_chunk(p, n, &idx, 0x47464351u /*QCFG*/, &sz) || sz != (df->ycbcr ? 64u : 32u)) { st = fmt_err(5, 0); break; }
-      for (int i = 0; i < 32; ++i) {   // quantize.cpp:190-213
-        df->shift[0][2 * i] = p[idx + i] >> 4; df->shift[0][2 * i + 1] = p[idx + i] & 15;
-        const uint8_t x = df->ycbcr ? p[idx + 32 + i] : 0;
-        df->shift[1][2 * i] = x >> 4; df->shift[1][2 * i + 1] = x & 15;
-      }
+      if (!find_chunk(p, n, &idx, 0x47464351u /*QCFG*/, &sz) || sz != (df->ycbcr ? 64u : 32u)) { s_chk[cQcfg] = fmt_err(5, 0); break; }
+      s_off[2] = idx; s_sz[2] = sz;
       idx += sz;
-      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz)) { st = fmt_err(6, 0); break; }
-      s_idx = idx; s_sz = sz;
-    } while (0);
-    s_status = st;
-  }
-  stage();
-  if (lane == 0 && !s_status) {   // ---- D: FMAP body, locate FRES (decoder.cpp:262-290)
-    int st = 0;
-    do {
-      if (sz > (uint32_t)kTreeStride || !parse_map_lds(s_bytes, sz, df->fmap)) { st = fmt_err(6, 0); break; }
+      if (!find_chunk(p, n, &idx, 0x50414d46u /*FMAP*/, &sz)) { s_chk[cFmapFind] = fmt_err(6, 0); break; }
+      s_off[3] = idx; s_sz[3] = sz;
       idx += sz;
-      if (!find_chunk(p, n, &idx, 0x53455246u /*FRES*/, &sz)) { st = fmt_err(7, 0); break; }
+      if (!find_chunk(p, n, &idx, 0x53455246u /*FRES*/, &sz)) { s_chk[cFresFind] = fmt_err(7, 0); break; }
       df->s[1].chunk_end = idx + sz;
       // Trap T2: the decoder derives use_blocks from the COMPRESSED size
       // (huffman_dec.cpp:215-219); UncompressBlock refuses when it is false (:265).
-      if (!((uint32_t)g.row_block < sz)) { st = fmt_err(7, 1); break; }
-      s_idx = idx; s_sz = sz;
+      if (!((uint32_t)g.row_block < sz)) { s_chk[cFresFind] = fmt_err(7, 1); break; }
+      s_off[4] = idx; s_sz[4] = sz;
     } while (0);
-    s_status = st;
-  }
-  stage();
-  if (lane == 0 && !s_status) {   // ---- E: FRES tree
-    int st = 0;
-    do {
-      uint32_t tb = 0;
-      st = recover_tree(s_buf, sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes1, aux[1],
-                        &df->s[1].num_nodes, &tb, &s_stack);
-      if (st) { if (st == kStFormat) st = fmt_err(7, 1); break; }
-      df->s[1].root = 0;
-      df->s[1].payload_off = idx + tb;
-      if (df->s[1].payload_off >= df->s[1].chunk_end) { st = fmt_err(7, 1); break; }
-      // A tree that is a single leaf decodes without consuming code bits in the
-      // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
-      // the encoder's 1-bit codes; such streams are rejected here.
-      if (nodes0[2] >= 0) { st = fmt_err(4, 1); break; }
-      if (nodes1[2] >= 0) { st = fmt_err(7, 1); break; }
-    } while (0);
-    s_status = st;
   }
   __syncthreads();
-  if (lane == 0) df->status = s_status;
-  if (s_status) return;
 
-  // First-level LUTs (kLutBits wide, LSB-first codes index them directly) in LDS,
-  // then the group tables derived from them.
-  for (int s = 0; s < 2; ++s) {
-    const int32_t *nodes = s ? nodes1 : nodes0;
-    const int nn = df->s[s].num_nodes;
-    for (int k = lane; k < nn; k += 64) {
-      const int depth = aux[s][k].depth;
-      const uint32_t code = aux[s][k].code;
-      const int sym = nodes[3 * k + 2];
-      if (sym >= 0 && depth <= kLutBits) {
-        for (uint32_t i = 0; i < (1u << (kLutBits - depth)); ++i)
-          s_lut[s][(i << depth) | code] = lut_leaf(sym, depth) | ((uint32_t)k << 20);
-      } else if (sym < 0 && depth == kLutBits) {
-        s_lut[s][code] = lut_node(k, depth);
+  // ---- 2: stage the bodies (a dependent global load costs ~1 us, an LDS read ~50 ns)
+  for (int b = 0; b < 5; ++b) {
+    uint8_t *dst = reinterpret_cast<uint8_t *>(s_buf[b]);
+    const uint32_t cnt = s_sz[b] < (uint32_t)kTreeStride ? s_sz[b] : (uint32_t)kTreeStride;
+    for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16; k += kParseThreads)
+      dst[k] = k < cnt ? p[s_off[b] + k] : (uint8_t)0;
+  }
+  __syncthreads();
+
+  // ---- 3: the serial walks, one per wave
+  if (lane == 0 && s_off[1]) {         // LRES tree (decoder.cpp:232, huffman_dec.cpp:152-229)
+    uint32_t tb = 0;
+    const uint32_t sz = s_sz[1];
+    int st = recover_tree(s_buf[1], sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes0, aux[0],
+                          &df->s[0].num_nodes, &tb, &s_stack[0]);
+    if (st == kStFormat) st = fmt_err(4, 1);
+    if (!st) {
+      df->s[0].root = 0;
+      df->s[0].payload_off = s_off[1] + tb;
+      // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
+      if (df->s[0].payload_off >= df->s[0].chunk_end) st = fmt_err(4, 1);
+    }
+    s_chk[cLresTree] = st;
+    // A tree that is a single leaf decodes without consuming code bits in the
+    // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
+    // the encoder's 1-bit codes; such streams are rejected.
+    if (!st && df->s[0].num_nodes == 1) s_chk[cLeaf0] = fmt_err(4, 1);
+  }
+  if (lane == 64 && s_off[4]) {        // FRES tree (decoder.cpp:290)
+    uint32_t tb = 0;
+    const uint32_t sz = s_sz[4];
+    int st = recover_tree(s_buf[4], sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes1, aux[1],
+                          &df->s[1].num_nodes, &tb, &s_stack[1]);
+    if (st == kStFormat) st = fmt_err(7, 1);
+    if (!st) {
+      df->s[1].root = 0;
+      df->s[1].payload_off = s_off[4] + tb;
+      if (df->s[1].payload_off >= df->s[1].chunk_end) st = fmt_err(7, 1);
+    }
+    s_chk[cFresTree] = st;
+    if (!st && df->s[1].num_nodes == 1) s_chk[cLeaf1] = fmt_err(7, 1);
+  }
+  if (lane == 128) {                   // mapping tables and QCFG
+    if (s_off[0]) {
+      if (s_sz[0] > (uint32_t)kTreeStride ||
+          !parse_map_lds(reinterpret_cast<const uint8_t *>(s_buf[0]), s_sz[0], df->lmap)) s_chk[cLmap] = fmt_err(3, 0);
+    }
+    if (s_off[2]) {
+      const uint8_t *q = reinterpret_cast<const uint8_t *>(s_buf[2]);
+      for (int i = 0; i < 32; ++i) {   // quantize.cpp:190-213
+        df->shift[0][2 * i] = q[i] >> 4; df->shift[0][2 * i + 1] = q[i] & 15;
+        const uint8_t x = df->ycbcr ? q[32 + i] : 0;
+        df->shift[1][2 * i] = x >> 4; df->shift[1][2 * i + 1] = x & 15;
       }
+    }
+    if (s_off[3]) {
+      if (s_sz[3] > (uint32_t)kTreeStride ||
+          !parse_map_lds(reinterpret_cast<const uint8_t *>(s_buf[3]), s_sz[3], df->fmap)) s_chk[cFmap] = fmt_err(6, 0);
     }
   }
   __syncthreads();
+  if (lane == 0) {   // ---- 4: first failure in the reference's order
+    int st = 0;
+    for (int k = 0; k < cCount && !st; ++k) st = s_chk[k];
+    s_status = st;
+    df->status = st;
+  }
+  __syncthreads();
+  if (s_status) return;
+  const long long c_serial = clock64();
+
+  // First-level LUTs (kLutBits wide, LSB-first codes index them directly) in LDS,
+  // then the group tables derived from them.  Every node of depth <= kLutBits is
+  // first entered in an implicit heap (index (1 << depth) | code); an entry then
+  // finds its leaf with at most kLutBits independent reads instead of every leaf
+  // replicating itself (a depth-1 leaf would write half the table on one lane).
+  for (int s = 0; s < 2; ++s) {
+    const int32_t *nodes = s ? nodes1 : nodes0;
+    const int nn = df->s[s].num_nodes;
+    for (int k = lane; k < (2 << kLutBits); k += kParseThreads) s_heap[k] = 0;
+    __syncthreads();
+    for (int k = lane; k < nn; k += kParseThreads) {
+      const int depth = aux[s][k].depth;
+      if (depth > kLutBits) continue;
+      const int sym = nodes[3 * k + 2];
+      // leaf: k + 1; branch (only looked at on the last level): 0x8000 | k
+      s_heap[(1u << depth) | aux[s][k].code] = (uint16_t)(sym >= 0 ? k + 1 : (0x8000 | k));
+      s_symd[k] = (uint16_t)(sym >= 0 ? sym : 0x8000);
+    }
+    __syncthreads();
+    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += kParseThreads) {
+      uint32_t e = 0;
+      // depth 0: a tree that is one leaf (rejected above, kept consistent anyway)
+      uint32_t h = s_heap[1];
+      if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], 0) | ((h - 1) << 20);
+      for (int d = 1; d <= kLutBits && !e; ++d) {
+        h = s_heap[(1u << d) | (idx & ((1u << d) - 1u))];
+        if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], d) | ((h - 1) << 20);
+        else if (h && d == kLutBits) e = lut_node(h & 0x7fffu, d);
+      }
+      s_lut[s][idx] = e;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const long long c_lut = clock64();
+  // Second-level tables for codes longer than kLutBits.  Few kLutBits-bit prefixes
+  // lead to such codes; each gets a sub-table indexed by the next m bits (m = the
+  // deepest leaf below it, at most kSubMaxBits; deeper leaves continue from a
+  // branch node).  The flagged first-level entry keeps its slot in bits [8:0].
+  for (int s = 0; s < 2; ++s) {
+    const int32_t *nodes = s ? nodes1 : nodes0;
+    const int nn = df->s[s].num_nodes;
+    if (lane == 0) s_nslow[s] = 0;
+    for (int k = lane; k < kSubEntries; k += kParseThreads) s_sub[s][k] = 0;
+    __syncthreads();
+    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += kParseThreads) {
+      const uint32_t e = s_lut[s][idx];
+      if (e & 512u) {
+        const uint32_t slot = atomicAdd(&s_nslow[s], 1u);
+        s_lut[s][idx] = e | (slot < (uint32_t)kMaxSlow ? slot : 511u);
+        if (slot < (uint32_t)kMaxSlow) s_slow_m[s][slot] = 0;
+      }
+    }
+    __syncthreads();
+    for (int k = lane; k < nn; k += kParseThreads) {
+      const int depth = aux[s][k].depth;
+      if (nodes[3 * k + 2] >= 0 && depth > kLutBits) {
+        const uint32_t slot = s_lut[s][aux[s][k].code & ((1u << kLutBits) - 1)] & 511u;
+        if (slot < (uint32_t)kMaxSlow) atomicMax(&s_slow_m[s][slot], (uint32_t)(depth - kLutBits));
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      const uint32_t n = s_nslow[s] < (uint32_t)kMaxSlow ? s_nslow[s] : (uint32_t)kMaxSlow;
+      uint32_t off = 0;
+      for (uint32_t q = 0; q < n; ++q) {
+        uint32_t m = s_slow_m[s][q] < (uint32_t)kSubMaxBits ? s_slow_m[s][q] : (uint32_t)kSubMaxBits;
+        if (off + (1u << m) > (uint32_t)kSubEntries) m = 0;   // no room: plain tree walk
+        s_slow_m[s][q] = m;
+        s_slow_off[s][q] = off;
+        if (m) off += 1u << m;
+      }
+    }
+    __syncthreads();
+    for (int k = lane; k < nn; k += kParseThreads) {
+      const int depth = aux[s][k].depth;
+      if (depth <= kLutBits) continue;
+      const uint32_t code = aux[s][k].code;
+      const uint32_t slot = s_lut[s][code & ((1u << kLutBits) - 1)] & 511u;
+      if (slot >= (uint32_t)kMaxSlow) continue;
+      const uint32_t m = s_slow_m[s][slot], off = s_slow_off[s][slot];
+      const uint32_t d = (uint32_t)(depth - kLutBits), rel = code >> kLutBits;
+      const int sym = nodes[3 * k + 2];
+      if (m == 0 || d > m) continue;
+      if (sym >= 0) {
+        for (uint32_t i = 0; i < (1u << (m - d)); ++i)
+          s_sub[s][off + ((i << d) | rel)] = lut_leaf(sym, depth) | ((uint32_t)k << 20);
+      } else if (d == m) {
+        s_sub[s][off + rel] = lut_node(k, depth);
+      }
+    }
+    __syncthreads();
+    uint32_t *sub = ws.sub + ((size_t)f * 2 + s) * kSubEntries;
+    for (int k = lane; k < kSubEntries; k += kParseThreads) sub[k] = s_sub[s][k];
+  }
+  const long long c_sub = clock64();
   for (int s = 0; s < 2; ++s) {
     // Group table of the lean decoder (GrpTables below).  A group is a greedy
     // sequence of tokens whose CODES lie inside the kLutBits known bits:
@@ -305,7 +404,7 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
     // optionally closed by ONE zero-run token (its zeros need no explicit bytes;
     // its extra bits are read from the stream at decode time).
     uint2 *grp = ws.grp + ((size_t)f * 2 + s) * (1u << kLutBits);
-    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += 64) {
+    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += kParseThreads) {
       uint32_t used = 0, nout = 0, bytes = 0, g_eb = 0, s_tb = 0, s_class = 0, ntok = 0;
       const uint32_t e0 = s_lut[s][idx];
       for (;;) {
@@ -333,13 +432,23 @@ __global__ __launch_bounds__(64) void k_dec_parse(Geom g, DecWs ws, const uint8_
         r.x = bytes;
         r.y = used | (g_eb << 4) | (nout << 8) | (s_tb << 17) | (s_class << 21);
       } else {
-        // The first code is longer than the table: .x says where the tree walk
-        // continues (node | depth << 16).
-        r.x = (e0 >> 20) | (((e0 >> 10) & 63u) << 16);
+        // The first code is longer than the table: .x says where to continue --
+        // bit 31 set: sub-table (offset << 8 | index bits); else the tree walk
+        // from node | depth << 16.
+        const uint32_t slot = e0 & 511u;
+        if ((e0 & 512u) && slot < (uint32_t)kMaxSlow && s_slow_m[s][slot])
+          r.x = 0x80000000u | (s_slow_off[s][slot] << 8) | s_slow_m[s][slot];
+        else
+          r.x = (e0 >> 20) | (((e0 >> 10) & 63u) << 16);
         r.y = 0;
       }
       grp[idx] = r;
     }
+  }
+  if (lane == 0) {   // phase cycles / 16 for tools/dec_stats.py (after the memset of stats)
+    uint32_t *st = ws.parse_stats + (size_t)f * 4;
+    st[0] = (uint32_t)((c_serial - c_in) >> 4); st[1] = (uint32_t)((c_lut - c_serial) >> 4);
+    st[2] = (uint32_t)((c_sub - c_lut) >> 4); st[3] = (uint32_t)((clock64() - c_sub) >> 4);
   }
 }
 
@@ -413,6 +522,7 @@ constexpr int kWinBytes = 32768;  // output window in LDS (streams that go to HB
 
 struct GrpTables {
   const uint2 *grp;           // LDS, 1 << kLutBits entries
+  const uint32_t *sub;        // LDS, second-level entries (codes longer than kLutBits)
   const short *ca, *cb, *sy;  // LDS tree nodes
 };
 
@@ -512,16 +622,30 @@ __device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool 
   else y = reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
   uint32_t tb = y & 15u, eb = (y >> 4) & 15u, cb = (y >> 8) & 511u, pre = 0, by = bx;
   if (single) {
-    const uint32_t c = (y >> 21) & 7u;
-    tb = (y >> 17) & 15u;
-    eb = class_eb(c);
-    cb = class_base(c);
-    by &= 255u;
+    // (The empty asm has "side effects", which makes the compiler keep a real
+    // branch around this block instead of predicating it into every step: lanes
+    // are `single` in their last few steps only.)
+    asm volatile("" ::: "memory");
+    {
+      const uint32_t c = (y >> 21) & 7u;
+      tb = (y >> 17) & 15u;
+      eb = class_eb(c);
+      cb = class_base(c);
+      by &= 255u;
+    }
   }
   if (__builtin_expect(tb == 0, 0)) {
-    // Code longer than the table: walk the tree (huffman_dec.cpp:291-328).
+    // Code longer than the table (huffman_dec.cpp:291-328): the second-level
+    // table resolves it with one more read; whatever is deeper still walks the
+    // tree from the node found there.
     const uint32_t ex = WANT_BYTES ? bx : t.grp[idx].x;
-    int node = (int)(ex & 0xffffu), len = (int)(ex >> 16);
+    int node = (int)(ex & 0xffffu), len = (int)((ex >> 16) & 0x7fffu);
+    if (ex >> 31) {
+      const uint32_t e2 = t.sub[((ex >> 8) & 0xffffu) +
+                                __builtin_amdgcn_ubfe((uint32_t)(rd.win >> kLutBits), 0, ex & 255u)];
+      node = (int)(e2 >> 20);
+      len = (int)((e2 >> 10) & 63u);
+    }
     while (t.sy[node] < 0 && len < kMaxDepth) {
       node = ((rd.win >> len) & 1ull) ? t.cb[node] : t.ca[node];
       ++len;
@@ -577,8 +701,10 @@ __device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint
 __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, StreamShared *sh,
                                               uint32_t first, bool active, uint32_t lim,
                                               uint32_t *start_io, uint32_t *endpos_io,
-                                              uint32_t *cnt_io, uint32_t *rounds, bool warm) {
+                                              uint32_t *cnt_io, uint32_t *rounds, bool warm,
+                                              long long *c_first = nullptr) {
   const int tid = threadIdx.x;
+  const long long t_in = clock64();
   uint32_t start = *start_io, endpos = *endpos_io, cnt = *cnt_io;
   bool dirty = active;
   if (tid == 0 && !warm) start = first;
@@ -590,6 +716,7 @@ __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, 
     if (dirty) lean_count(rd, tb, start, lim, &endpos, &cnt);
     sh->nxt[tid + 1] = endpos;
     __syncthreads();
+    if (c_first && *c_first == 0) *c_first = clock64() - t_in;
     const uint32_t ns = tid == 0 ? first : sh->nxt[tid];
     dirty = active && (ns != start);
     if (active) start = ns;
@@ -729,7 +856,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   unsigned long long cur = 0;                    // exact bit position of the next token
   unsigned long long O0 = 0;                     // symbols produced so far
   uint32_t st_chunks = 0, st_rounds = 0;
-  long long c_sync = 0, c_write = 0, c_t0 = clock64();
+  long long c_sync = 0, c_write = 0, c_r1 = 0, c_t0 = clock64();
 
   while (cur < P1 && O0 < out_size) {
     GReader rd;
@@ -749,7 +876,9 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
     const int last_active = (int)((rel_end - rel0 - 1u) / sub);
 
     uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0;
-    lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false);
+    long long c_first = 0;
+    lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false, &c_first);
+    c_r1 += c_first;
     { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
 
     unsigned long long tot;
@@ -791,7 +920,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
   if (tid == 0 && stats) {
     stats[0] = st_chunks; stats[1] = st_rounds; stats[2] = 0;
-    stats[3] = 0; stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
+    stats[3] = (uint32_t)(c_r1 >> 4); stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
     stats[6] = pay_len; stats[7] = out_size;
   }
   return bad;
@@ -799,7 +928,8 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
 
 // Tree nodes and group table of stream `strm` of frame f -> LDS.
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
-                                                uint2 *grp, short *ca, short *cb, short *sy) {
+                                                uint2 *grp, uint32_t *sub, short *ca, short *cb,
+                                                short *sy) {
   const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
   const int nn = df->s[strm].num_nodes;
   for (int k = threadIdx.x; k < nn; k += kDecThreads) {
@@ -808,6 +938,8 @@ __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame 
   const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + strm) * (1u << kLutBits));
   for (int k = threadIdx.x; k < (1 << kLutBits) / 2; k += kDecThreads)
     reinterpret_cast<uint4 *>(grp)[k] = gg[k];
+  const uint32_t *gs = ws.sub + ((size_t)f * 2 + strm) * kSubEntries;
+  for (int k = threadIdx.x; k < kSubEntries; k += kDecThreads) sub[k] = gs[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -820,6 +952,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
                                                           int first_block, int lres_fallback_only) {
   __shared__ uint32_t win[kWinBytes / 4 + 1];
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
 
@@ -843,10 +976,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
   }
-  load_dec_tables(ws, df, f, strm, grp, ca, cb, sy);
+  load_dec_tables(ws, df, f, strm, grp, sub, ca, cb, sy);
   __syncthreads();
   GrpTables tb;
-  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
                                        out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
   if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
@@ -879,6 +1012,7 @@ template <bool FIX>
 __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, const uint8_t *packed,
                                                             size_t in_stride, const uint32_t *sizes) {
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -897,9 +1031,9 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     if (tid == 0) ws.fix_end[slot] = ws.spec_end[slot];
     return;
   }
-  load_dec_tables(ws, df, f, 0, grp, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
   GrpTables tb;
-  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
   const unsigned long long rem = P1 - cur;
@@ -992,6 +1126,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
                                                             size_t in_stride, const uint32_t *sizes) {
   __shared__ uint32_t win[kWinBytes / 4 + 1];
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
@@ -1005,10 +1140,10 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const size_t slot = (size_t)f * ws.lres_chunks + k;
   const unsigned long long O0 = ws.ver_base[slot];
   if (O0 >= out_size) return;
-  load_dec_tables(ws, df, f, 0, grp, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
   if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
   GrpTables tb;
-  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
   const unsigned long long rem = P1 - cur;
@@ -1232,14 +1367,15 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // The symbols never touch HBM: traffic is the packed row in, the pixels out.
 // ---------------------------------------------------------------------------
 struct FusedLayout {
-  uint32_t sym, grp, ca, cb, sy, sh, unmap, shift, total;
+  uint32_t sym, grp, sub, ca, cb, sy, sh, unmap, shift, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int row_block) {
   FusedLayout L;
   uint32_t o = 0;
   auto carve = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
+  L.grp = carve((1u << kLutBits) * 8u);   // at offset 0: the hot loop indexes it
+  L.sub = carve(kSubEntries * 4u);
   L.sym = carve((uint32_t)row_block);
-  L.grp = carve((1u << kLutBits) * 8u);
   L.ca = carve((kMaxNodes + 1) * 2u);
   L.cb = carve((kMaxNodes + 1) * 2u);
   L.sy = carve((kMaxNodes + 1) * 2u);
@@ -1264,6 +1400,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const FusedLayout L = fused_layout(g.row_block);
   uint8_t *sym = smem + L.sym;
   uint2 *grp = reinterpret_cast<uint2 *>(smem + L.grp);
+  uint32_t *sub = reinterpret_cast<uint32_t *>(smem + L.sub);
   short *ca = reinterpret_cast<short *>(smem + L.ca);
   short *cb = reinterpret_cast<short *>(smem + L.cb);
   short *sy = reinterpret_cast<short *>(smem + L.sy);
@@ -1275,7 +1412,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  load_dec_tables(ws, df, f, 1, grp, ca, cb, sy);
+  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -1291,7 +1428,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   __syncthreads();
 
   GrpTables tb;
-  tb.grp = grp; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<true>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
       (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
@@ -1438,7 +1575,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;
   const int wps = (allow_fused && fused_layout(g.row_block).total <= kLdsMax) ? 1 : 0;
-  HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
+  HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
   // Fork: the serial FRES row-header walk runs on the side stream while this
   // stream decodes the LRES chain; they join before the first FRES row kernel.
   // (side == nullptr: run it in line.)

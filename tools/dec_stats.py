@@ -12,8 +12,10 @@ packed = eng.encode(img, 50)
 eng.decode(packed)
 rows = h // 8
 st = eng.debug_read("dec_stats", 0, (rows + 1) * 32, np.uint32, decoder=True).reshape(rows + 1, 8)
-names = ["chunks", "rounds", "clk_tile/16 (lres: fix chunks)", "clk_stage/16 (lres: fix rounds)", "clk_sync/16", "clk_write/16", "pay_len", "clk_store/16"]
+names = ["chunks", "rounds", "clk_tile/16 (lres: fix chunks)", "clk_round1/16 (lres: fix rounds)", "clk_sync/16", "clk_write/16", "pay_len", "clk_store/16"]
 print("LRES:", dict(zip(names, st[0].tolist())))
+ps = eng.debug_read("parse_stats", 0, 16, np.uint32, decoder=True)
+print("k_dec_parse cycles: serial %d, lut %d, sub %d, grp %d" % tuple((ps.astype(np.int64) * 16).tolist()))
 fr = st[1:].astype(np.float64)
 for i, n in enumerate(names):
     print("FRES %-14s mean %.1f min %.0f max %.0f" % (n, fr[:, i].mean(), fr[:, i].min(), fr[:, i].max()))
