@@ -828,9 +828,14 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   if (lane == 0) {
     int err = 0;
     uint32_t nb = 0;  // bits written
-    auto put = [&](uint32_t v, int n) {
-      for (int i = 0; i < n; ++i, ++nb)
-        if ((v >> i) & 1u) bits[nb >> 5] |= 1u << (nb & 31);
+    unsigned long long acc = 0;  // bits not yet stored (fewer than 32), LSB first
+    auto put = [&](uint32_t v, int n) {  // n <= 10
+      acc |= (unsigned long long)v << (nb & 31);
+      nb += n;
+      if (((nb - n) & 31) + n >= 32) {
+        bits[(nb >> 5) - 1] = (uint32_t)acc;
+        acc >>= 32;
+      }
     };
     int sp = 0;
     if (num == 1) {  // single symbol: one leaf, code 0, length 1 (huffman_enc.cpp:231-237)
@@ -856,6 +861,7 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
         stk_node[sp] = ca[n]; stk_code[sp] = code;  stk_bits[sp] = (uint8_t)min(nbits + 1, 255); ++sp;
       }
     }
+    if (nb & 31) bits[nb >> 5] = (uint32_t)acc;
     s_num = (int)((nb + 7) >> 3);
     ws.tree_nbytes[(size_t)f * 2 + strm] = (nb + 7) >> 3;
     if (err) atomicMax(&ws.status[f], 3);  // code longer than 32 bits: outside the built scope
