@@ -95,6 +95,14 @@ def cpu_baseline(frame, quality, budget_s):
     dec(packed, 1)
     t_dec1 = time.perf_counter() - t0
     e, d = t_enc / n_enc, t_dec / n_dec
+    # Node-level encode: one independent single-threaded encoder per worker thread on
+    # the same frame (ctypes releases the GIL); bounded to 32 workers (~250 MB each).
+    from concurrent.futures import ThreadPoolExecutor
+    nw = max(1, min(32, cores))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(nw) as pool:
+        list(pool.map(lambda _: enc(frame, quality, True), range(nw)))
+    t_node = time.perf_counter() - t0
     return {
         "value": round(mpx / (e + d), 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
         "sample": "%dx%d RGBA %s q=%d: %d encodes on 1 thread (%.3f s each) + %d decodes on %d threads "
@@ -103,7 +111,56 @@ def cpu_baseline(frame, quality, budget_s):
         "encode_mpx_s_1thread": round(mpx / e, 3),
         "decode_mpx_s_allthreads": round(mpx / d, 3),
         "decode_mpx_s_1thread": round(mpx / t_dec1, 3),
+        "encode_mpx_s_node": round(mpx * nw / t_node, 3), "encode_node_workers": nw,
     }
+
+
+def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, d_st_d, d_pix, h_sizes,
+                   frame0, W, H, Q, cap):
+    """SURVEY.md 8(d) side figures (rank 0, N=1; none of them is `value`):
+    an on-box copy ceiling for the HBM roofline, single-frame latency, and the
+    host-buffer API whose time includes PCIe both ways."""
+    out = {}
+    # HBM ceiling seen by a plain device-to-device copy (read + write bytes).
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(10):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    out["hbm_copy_ceiling_GBs"] = round(2.0 * n * 10 / (time.perf_counter() - t) / 1e9, 1)
+    del a, b
+    # Single-frame latency through the device-resident API (one frame per launch).
+    def lat(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+    out["single_frame_latency_ms"] = {
+        "encode": round(lat(lambda: eng.encode_device(d_frames[:1], 1, W, H, 4, 4, Q, True, d_out[:1], cap,
+                                                      d_sizes[:1], d_st_e[:1], 0)), 3),
+        "decode": round(lat(lambda: eng.decode_device(d_out[:1], cap, h_sizes[:1], 1, W, H, 4, d_pix[:1],
+                                                      d_st_d[:1], 0)), 3)}
+    # Host-buffer API (himg_hip_encode / himg_hip_decode): H2D + kernels + D2H.
+    packed = eng.encode(frame0, Q, True)
+    eng.decode(packed)
+    t = time.perf_counter()
+    for _ in range(3):
+        packed = eng.encode(frame0, Q, True)
+    te = (time.perf_counter() - t) / 3
+    t = time.perf_counter()
+    for _ in range(3):
+        eng.decode(packed)
+    td = (time.perf_counter() - t) / 3
+    out["host_api_incl_pcie_mpx_s"] = {"encode": round(W * H / te / 1e6, 1), "decode": round(W * H / td / 1e6, 1),
+                                       "encode_decode": round(W * H / (te + td) / 1e6, 1)}
+    return out
 
 
 GOLDEN_16384 = {"packed_size": 275620945, "stream_fnv": "5bdcdb7a140df481"}
@@ -324,7 +381,7 @@ def main():
         # (encode), packed read + W*H*4 written (decode); one launch processes B frames.
         alg_bytes_side = B * W * H * 4.0 + packed_total
         alg_bytes_launch = alg_bytes_side * G / B   # one launch processes G = B/streams frames
-        enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_lres_summary",
+        enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_tile_fwd_pk", "k_lres_summary",
                       "k_tok_hist", "k_tree", "k_sizes", "k_emit", "k_padfix", "memset"}
         stages = {k: {"ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
         dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None
@@ -341,11 +398,20 @@ def main():
                 key = dom.strip("()").split("<")[0]
                 if key in per_frame:
                     traffic = per_frame[key] * G
-            roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom in enc_stages else "decode",
+            # VALU-issue utilisation of that kernel from the committed PMC summary
+            # (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration)): these kernels are
+            # instruction-bound, the HBM fraction is an upper bound on what is left.
+            valu_busy = None
+            ppath = os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")
+            if os.path.exists(ppath) and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
+                for k, v in json.load(open(ppath)).items():
+                    if k.split("<")[0] == dom.strip("()").split("<")[0] and v.get("dur_us"):
+                        valu_busy = round(v.get("SQ_INSTS_VALU", 0) * 4 / (1024 * v["dur_us"] * 1e-6 * 2.4e9), 3)
+            roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom.strip("()").split("<")[0] in enc_stages else "decode",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": alg_bytes_launch, "frames_per_launch": G,
-                        "kernel_ms": round(stages[dom]["ms"], 4)}
+                        "kernel_ms": round(stages[dom]["ms"], 4), "valu_busy_frac_pmc": valu_busy}
         out = {
             "metric": "Mpixels/s encode+decode, 4K RGBA q=50", "value": round(value, 2),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -366,6 +432,9 @@ def main():
             "roofline": roofline,
             "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
         }
+        if world == 1:
+            out["extras"] = measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e,
+                                           d_st_d, d_pix, h_sizes, frames[0], W, H, Q, cap)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], Q, args.cpu_seconds)
         print(json.dumps(out), flush=True)

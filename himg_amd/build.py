@@ -67,6 +67,29 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+CLIDIR = os.path.join(ROOT, "himg_amd", "cli")
+BINDIR = os.path.join(ROOT, "himg_amd", "bin")
+
+
+def build_cli(verbose=False):
+    """chimg / dhimg (reference-style command line tools) against the in-tree library."""
+    lib = build_lib(verbose=verbose)
+    os.makedirs(BINDIR, exist_ok=True)
+    out = []
+    for name in ("chimg", "dhimg"):
+        src = os.path.join(CLIDIR, name + ".cpp")
+        exe = os.path.join(BINDIR, name)
+        if _stale(exe, [src, os.path.join(CLIDIR, "pnm_io.h"), lib]):
+            cmd = ["g++", "-std=c++11", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + CLIDIR, src,
+                   "-L" + LIBDIR, "-lhimg_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../lib",
+                   "-o", exe]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        out.append(exe)
+    return out
+
+
 def build_oracle(verbose=False):
     """Build the CPU checker (tests / smoke / cpu_baseline only)."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")] + ([] if verbose else ["-s"]),

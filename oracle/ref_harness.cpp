@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 
 #include "decoder.h"
@@ -20,12 +21,26 @@
 
 namespace {
 // The library prints progress lines to std::cout from inside Encode/Decode
-// (encoder.cpp:219,334; decoder.cpp:96-135).  Swallow them.
+// (encoder.cpp:219,334; decoder.cpp:96-135).  Swallow them.  Calls may come from
+// several threads at once (bench.py times one encoder per core), so the stream
+// buffer is swapped under a reference count, not per call.
+struct NullBuf : std::streambuf {
+  int overflow(int c) override { return c; }
+  std::streamsize xsputn(const char *, std::streamsize n) override { return n; }
+};
 struct QuietCout {
-  std::ostringstream sink;
-  std::streambuf *old;
-  QuietCout() : old(std::cout.rdbuf(sink.rdbuf())) {}
-  ~QuietCout() { std::cout.rdbuf(old); }
+  static std::mutex &mu() { static std::mutex m; return m; }
+  static int &users() { static int n = 0; return n; }
+  static std::streambuf *&saved() { static std::streambuf *p = nullptr; return p; }
+  static NullBuf &sink() { static NullBuf b; return b; }
+  QuietCout() {
+    std::lock_guard<std::mutex> g(mu());
+    if (users()++ == 0) saved() = std::cout.rdbuf(&sink());
+  }
+  ~QuietCout() {
+    std::lock_guard<std::mutex> g(mu());
+    if (--users() == 0) std::cout.rdbuf(saved());
+  }
 };
 }  // namespace
 

@@ -1,0 +1,122 @@
+"""chimg / dhimg command line tools: the reference's command
+line, messages and exit codes (src/chimg.cpp:36-169, src/dhimg.cpp:17-72) on top of
+the drop-in Encoder / Decoder classes, with Netpbm instead of FreeImage for file I/O."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import himg_amd
+from himg_amd import build as hb
+
+import oracle_lib as ol
+
+
+@pytest.fixture(scope="module")
+def tools():
+    chimg, dhimg = hb.build_cli()
+    return chimg, dhimg
+
+
+def _run(*cmd):
+    return subprocess.run(list(cmd), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _write_pnm(path, img):
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    with open(path, "wb") as f:
+        if c == 1:
+            f.write(b"P5\n# a comment\n%d %d\n255\n" % (w, h))
+        elif c == 3:
+            f.write(b"P6\n%d %d\n255\n" % (w, h))
+        else:
+            f.write(b"P7\nWIDTH %d\nHEIGHT %d\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA\nENDHDR\n" % (w, h))
+        f.write(np.ascontiguousarray(img, np.uint8).tobytes())
+
+
+def _read_pnm(path):
+    data = open(path, "rb").read()
+    if data[:2] in (b"P5", b"P6"):
+        c = 1 if data[:2] == b"P5" else 3
+        # magic, width, height, maxval, then exactly one whitespace byte before the samples
+        pos, toks = 0, []
+        while len(toks) < 4:
+            while data[pos:pos + 1].isspace():
+                pos += 1
+            end = pos
+            while not data[end:end + 1].isspace():
+                end += 1
+            toks.append(data[pos:end])
+            pos = end
+        w, h = int(toks[1]), int(toks[2])
+        return np.frombuffer(data[pos + 1: pos + 1 + w * h * c], np.uint8).reshape(h, w, c)
+    head, rest = data.split(b"ENDHDR\n", 1)
+    kv = dict(l.split(None, 1) for l in head.decode().splitlines()[1:] if l.strip())
+    w, h, c = int(kv["WIDTH"]), int(kv["HEIGHT"]), int(kv["DEPTH"])
+    return np.frombuffer(rest[: w * h * c], np.uint8).reshape(h, w, c)
+
+
+def _freeimage_order(img):
+    """Top-down RGB(A) -> FreeImage's bottom-up BGR(A) (what the reference chimg hands to the codec)."""
+    img = img if img.ndim == 3 else img[:, :, None]
+    out = img[::-1].copy()
+    if img.shape[2] >= 3:
+        out[:, :, [0, 2]] = out[:, :, [2, 0]]
+    return np.ascontiguousarray(out)
+
+
+def test_usage_and_argument_errors(tools, tmp_path):
+    chimg, dhimg = tools
+    r = _run(chimg)
+    assert r.returncode == 0 and r.stdout.startswith("Usage: %s [options] image outfile\nOptions:\n" % chimg)
+    assert " -q <quality> Set the quality (0-100)\n -rgb         Use RGB color space (instead of YCbCr)\n" in r.stdout
+    r = _run(chimg, "-q", "101", "a", "b")
+    assert r.returncode == 0 and r.stdout.startswith("Invalid quality level: 101\nUsage:")
+    r = _run(chimg, "-q", "x7", "a", "b")
+    assert r.returncode == 0 and r.stdout.startswith("Invalid integer expression: x7\nUsage:")
+    r = _run(chimg, "-zz", "a", "b")
+    assert r.returncode == 0 and r.stdout.startswith("Invalid option: -zz\nUsage:")
+    r = _run(dhimg, "only-one")
+    assert r.returncode == 0 and r.stdout == "Usage: %s image outfile\n" % dhimg
+    r = _run(dhimg, str(tmp_path / "missing.himg"), str(tmp_path / "o.ppm"))
+    assert r.returncode == 255 and r.stdout == "Unable to read file %s\n" % (tmp_path / "missing.himg")
+    # input files chimg cannot use (exit -1, message on stderr like the reference)
+    r = _run(chimg, str(tmp_path / "missing.ppm"), str(tmp_path / "o.himg"))
+    assert r.returncode == 255 and r.stderr == "Unable to load %s\n" % (tmp_path / "missing.ppm")
+    bad = tmp_path / "bad.ppm"
+    bad.write_bytes(b"GIF89a....")
+    r = _run(chimg, str(bad), str(tmp_path / "o.himg"))
+    assert r.returncode == 255 and r.stderr == "Unknown file format for %s\n" % bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,flags", [(3, []), (4, ["-q", "70"]), (1, ["-q", "90"]), (3, ["-rgb", "-q", "30"])])
+def test_cli_round_trip_matches_the_oracle(tools, tmp_path, channels, flags):
+    chimg, dhimg = tools
+    w, h = 256, 128
+    rgba = himg_amd.synth("randtile", 11 + channels, w, h)
+    img = rgba[:, :, 0] if channels == 1 else rgba[:, :, :channels]
+    src = str(tmp_path / "in.pnm")
+    _write_pnm(src, img)
+    packed_path, out_path = str(tmp_path / "o.himg"), str(tmp_path / "o.pnm")
+    r = _run(chimg, *flags, src, packed_path)
+    q = int(flags[flags.index("-q") + 1]) if "-q" in flags else 50
+    want = ol.oracle_encode(_freeimage_order(img), q, "-rgb" not in flags, channels=channels, stride=channels)
+    assert r.returncode == 0, r.stderr
+    # the library's two lines (encoder.cpp:219,334), then the tool's own
+    assert r.stdout.splitlines()[-1] == "Compressed size: %d" % len(want)
+    assert r.stdout.startswith("Low resolution data: ")
+    got = np.fromfile(packed_path, np.uint8)
+    assert np.array_equal(got, want)
+
+    r = _run(dhimg, packed_path, out_path)
+    rc, pix = ol.oracle_decode(want)
+    if rc != 0:   # the reference refuses its own stream (trap T2)
+        assert r.returncode == 255 and r.stdout.splitlines()[-1] == "Unable to decode image."
+        return
+    assert r.returncode == 0, r.stdout
+    assert r.stdout.splitlines()[0] == "File size: %d" % len(want)
+    back = _read_pnm(out_path)
+    assert np.array_equal(_freeimage_order(back), pix.reshape(h, w, channels))
