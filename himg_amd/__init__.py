@@ -68,6 +68,10 @@ def lib():
     L.himg_hip_max_packed_size.restype = sz
     L.himg_hip_encode.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, P(vp), P(sz)]
     L.himg_hip_decode.argtypes = [vp, vp, sz, P(vp), P(i32), P(i32), P(i32)]
+    L.himg_hip_encode_to.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, P(sz)]
+    L.himg_hip_decode_to.argtypes = [vp, vp, sz, vp, sz, P(i32), P(i32), P(i32)]
+    L.himg_hip_fetch_last.argtypes = [vp, vp, sz, P(sz)]
+    L.himg_hip_peek.argtypes = [vp, sz, P(i32), P(i32), P(i32)]
     L.himg_hip_free.argtypes = [vp]
     L.himg_hip_free.restype = None
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
@@ -154,29 +158,36 @@ class Engine:
 
     # host-buffer API ---------------------------------------------------------
     def encode(self, img, quality=50, use_ycbcr=True, channels=None, pixel_stride=None):
+        """himg_hip_encode_to + himg_hip_fetch_last: the stream is fetched into an
+        array of exactly its size (no intermediate copies)."""
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape[:2]
         ch = channels if channels is not None else (img.shape[2] if img.ndim == 3 else 1)
         stride = pixel_stride if pixel_stride is not None else (img.shape[2] if img.ndim == 3 else 1)
-        out, n = C.c_void_p(), C.c_size_t()
-        rc = lib().himg_hip_encode(self._ctx, img.ctypes.data, w, h, stride, ch, quality,
-                                   1 if use_ycbcr else 0, C.byref(out), C.byref(n))
-        self._check(rc, "encode")
-        buf = C.string_at(out, n.value)
-        lib().himg_hip_free(out)
-        return np.frombuffer(buf, np.uint8).copy()
+        n = C.c_size_t()
+        rc = lib().himg_hip_encode_to(self._ctx, img.ctypes.data, w, h, stride, ch, quality,
+                                      1 if use_ycbcr else 0, None, 0, C.byref(n))
+        if rc != HIMG_ERR_CAPACITY or n.value == 0:
+            self._check(rc if rc != HIMG_OK else HIMG_ERR_ARG, "encode")
+        out = np.empty(n.value, np.uint8)
+        self._check(lib().himg_hip_fetch_last(self._ctx, out.ctypes.data, out.nbytes, C.byref(n)), "encode")
+        return out
 
-    def decode(self, packed):
+    def decode(self, packed, out=None):
+        """himg_hip_peek + himg_hip_decode_to straight into `out` (reused when it has
+        the right size) or a new array."""
         packed = np.ascontiguousarray(np.frombuffer(packed, np.uint8) if isinstance(packed, (bytes, bytearray)) else packed)
-        out = C.c_void_p()
         w, h, c = C.c_int(), C.c_int(), C.c_int()
-        rc = lib().himg_hip_decode(self._ctx, packed.ctypes.data, packed.nbytes, C.byref(out),
-                                   C.byref(w), C.byref(h), C.byref(c))
+        dst, cap = None, 0
+        if lib().himg_hip_peek(packed.ctypes.data, packed.nbytes, C.byref(w), C.byref(h), C.byref(c)) == HIMG_OK:
+            n = w.value * h.value * c.value
+            if out is None or out.nbytes != n or not out.flags["C_CONTIGUOUS"] or out.dtype != np.uint8:
+                out = np.empty(n, np.uint8)
+            dst, cap = out.ctypes.data, out.nbytes
+        rc = lib().himg_hip_decode_to(self._ctx, packed.ctypes.data, packed.nbytes, dst, cap,
+                                      C.byref(w), C.byref(h), C.byref(c))
         self._check(rc, "decode")
-        n = w.value * h.value * c.value
-        buf = C.string_at(out, n)
-        lib().himg_hip_free(out)
-        return np.frombuffer(buf, np.uint8).reshape(h.value, w.value, c.value).copy()
+        return out.reshape(h.value, w.value, c.value)
 
     # device-resident API -------------------------------------------------------
     def encode_device(self, d_frames, batch, width, height, pixel_stride, channels, quality,

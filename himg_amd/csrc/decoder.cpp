@@ -8,23 +8,30 @@
 namespace himg {
 
 Decoder::Decoder(int max_threads)
-    : m_ctx(nullptr), m_max_threads(max_threads), m_width(0), m_height(0), m_num_channels(0) {}
+    : m_ctx(nullptr), m_max_threads(max_threads), m_unpacked_size(0), m_capacity(0), m_width(0),
+      m_height(0), m_num_channels(0) {}
 
 Decoder::~Decoder() {
   if (m_ctx) himg_hip_destroy(m_ctx);
 }
 
 bool Decoder::Decode(const uint8_t *packed_data, int packed_size) {
-  m_unpacked_data.clear();
+  m_unpacked_size = 0;
   if (!m_ctx && himg_hip_create(0, &m_ctx) != HIMG_OK) {
     std::cout << "Error: no usable MI355X device (the HIMG engine has no CPU fallback).\n";
     return false;
   }
-  uint8_t *out = nullptr;
+  const size_t size = packed_size < 0 ? 0 : static_cast<size_t>(packed_size);
   int w = 0, h = 0, c = 0;
-  const int rc = himg_hip_decode(m_ctx, packed_data,
-                                 packed_size < 0 ? 0 : static_cast<size_t>(packed_size), &out, &w,
-                                 &h, &c);
+  // Size the (reused) output buffer from the header, then decode straight into it.
+  if (himg_hip_peek(packed_data, size, &w, &h, &c) == HIMG_OK) {
+    const size_t need = static_cast<size_t>(w) * h * c;
+    if (need > m_capacity) {
+      m_unpacked_data.reset(new uint8_t[need]);
+      m_capacity = need;
+    }
+  }
+  const int rc = himg_hip_decode_to(m_ctx, packed_data, size, m_unpacked_data.get(), m_capacity, &w, &h, &c);
   if (rc != HIMG_OK) {
     // For HIMG_ERR_FORMAT the message is the reference's own text
     // (decoder.cpp:96-135,232,287,345), newline-terminated.
@@ -36,8 +43,7 @@ bool Decoder::Decode(const uint8_t *packed_data, int packed_size) {
   m_width = w;
   m_height = h;
   m_num_channels = c;
-  m_unpacked_data.assign(out, out + static_cast<size_t>(w) * h * c);
-  himg_hip_free(out);
+  m_unpacked_size = static_cast<size_t>(w) * h * c;
   return true;
 }
 

@@ -106,6 +106,7 @@ struct himg_hip_ctx {
   // Fixed table: LUT of the full-res companding search (FullResMapper is the
   // same for every quality, mapper.cpp:213-223), 32769 entries.
   DevBuf fmap_lut;
+  size_t host_bytes = 0;   // bytes of the last host-API result still resident in h_out
 
   // Encoder workspace.
   DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist;
@@ -486,12 +487,13 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
 // ---------------------------------------------------------------------------
 // Host-buffer API.
 // ---------------------------------------------------------------------------
-extern "C" int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
-                               int pixel_stride, int num_channels, int quality, int use_ycbcr,
-                               uint8_t **out, size_t *out_size) {
-  if (!ctx || !data || !out || !out_size) return HIMG_ERR_ARG;
-  *out = nullptr;
-  *out_size = 0;
+// ---- host-buffer API ---------------------------------------------------------
+// The stream / the pixels of the last host call stay resident in ctx->h_out; the
+// entry points differ only in where they copy them to.
+
+static int encode_core(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
+                       int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                       uint32_t *n_out) {
   Geom g;
   if (!make_geom(width, height, pixel_stride, num_channels, use_ycbcr, &g))
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
@@ -500,6 +502,7 @@ extern "C" int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width
   if (!ctx->h_in.reserve(round_up((size_t)g.frame_bytes, 256)) || !ctx->h_out.reserve(cap) ||
       !ctx->h_sizes.reserve(256) || !ctx->h_status.reserve(256))
     return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+  ctx->host_bytes = 0;
   HIP_TRY(ctx, hipMemcpy(ctx->h_in.p, data, (size_t)g.frame_bytes, hipMemcpyHostToDevice));
   int rc = himg_hip_encode_device(ctx, ctx->h_in.p, 1, width, height, pixel_stride, num_channels,
                                   quality, use_ycbcr, ctx->h_out.p, cap, (uint32_t *)ctx->h_sizes.p,
@@ -510,6 +513,20 @@ extern "C" int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width
   HIP_TRY(ctx, hipMemcpy(&n, ctx->h_sizes.p, 4, hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(&st, ctx->h_status.p, 4, hipMemcpyDeviceToHost));
   if (st) return fail(ctx, status_to_code(st), "device encode reported an error");
+  ctx->host_bytes = n;
+  *n_out = n;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
+                               int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                               uint8_t **out, size_t *out_size) {
+  if (!ctx || !data || !out || !out_size) return HIMG_ERR_ARG;
+  *out = nullptr;
+  *out_size = 0;
+  uint32_t n = 0;
+  const int rc = encode_core(ctx, data, width, height, pixel_stride, num_channels, quality, use_ycbcr, &n);
+  if (rc) return rc;
   uint8_t *buf = (uint8_t *)std::malloc(n ? n : 1);
   if (!buf) return fail(ctx, HIMG_ERR_ARG, "out of host memory");
   HIP_TRY(ctx, hipMemcpy(buf, ctx->h_out.p, n, hipMemcpyDeviceToHost));
@@ -518,45 +535,81 @@ extern "C" int himg_hip_encode(himg_hip_ctx *ctx, const uint8_t *data, int width
   return HIMG_OK;
 }
 
-extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size,
-                               uint8_t **out, int *width, int *height, int *num_channels) {
-  if (!ctx || !packed || !out || !width || !height || !num_channels) return HIMG_ERR_ARG;
-  *out = nullptr;
-  // Geometry comes from the FRMT chunk; the host only needs it to size the
-  // launch, every check is repeated on the device (k_dec_parse).
-  // decoder.cpp:144-200
+extern "C" int himg_hip_encode_to(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
+                                  int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                                  uint8_t *dst, size_t dst_cap, size_t *out_size) {
+  if (!ctx || !data || !out_size) return HIMG_ERR_ARG;
+  *out_size = 0;
+  uint32_t n = 0;
+  const int rc = encode_core(ctx, data, width, height, pixel_stride, num_channels, quality, use_ycbcr, &n);
+  if (rc) return rc;
+  *out_size = n;
+  if (!dst || dst_cap < n) return fail(ctx, HIMG_ERR_CAPACITY, "output buffer too small");
+  HIP_TRY(ctx, hipMemcpy(dst, ctx->h_out.p, n, hipMemcpyDeviceToHost));
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_fetch_last(himg_hip_ctx *ctx, uint8_t *dst, size_t dst_cap, size_t *size) {
+  if (!ctx || !size) return HIMG_ERR_ARG;
+  *size = ctx->host_bytes;
+  if (!ctx->host_bytes) return fail(ctx, HIMG_ERR_ARG, "no result to fetch");
+  if (!dst || dst_cap < ctx->host_bytes) return fail(ctx, HIMG_ERR_CAPACITY, "output buffer too small");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(dst, ctx->h_out.p, ctx->host_bytes, hipMemcpyDeviceToHost));
+  return HIMG_OK;
+}
+
+// Geometry from the FRMT chunk (decoder.cpp:144-200).  Returns nullptr or the
+// reference's message for the failing check.
+static const char *parse_header(const uint8_t *packed, size_t packed_size, int *W, int *H, int *C) {
   if (packed_size < 12 || packed_size > 0x7fffffffu || memcmp(packed, "RIFF", 4) != 0 ||
       memcmp(packed + 8, "HIMG", 4) != 0)
-    return fail(ctx, HIMG_ERR_FORMAT, "Not a RIFF HIMG file.\n");
+    return "Not a RIFF HIMG file.\n";
   size_t idx = 12;
-  int W = 0, H = 0, C = 0;
   for (;;) {
-    if (idx + 8 > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.\n");
+    if (idx + 8 > packed_size) return "Error decoding header.\n";
     const uint32_t sz = packed[idx + 4] | (packed[idx + 5] << 8) | (packed[idx + 6] << 16) |
                         ((uint32_t)packed[idx + 7] << 24);
     const bool frmt = memcmp(packed + idx, "FRMT", 4) == 0;
     idx += 8;
-    if (idx + sz > packed_size) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.\n");
+    if (idx + sz > packed_size) return "Error decoding header.\n";
     if (frmt) {
-      if (sz < 11 || packed[idx] != 1) return fail(ctx, HIMG_ERR_FORMAT, "Error decoding header.\n");
-      W = (int)(packed[idx + 1] | (packed[idx + 2] << 8) | (packed[idx + 3] << 16) | ((uint32_t)packed[idx + 4] << 24));
-      H = (int)(packed[idx + 5] | (packed[idx + 6] << 8) | (packed[idx + 7] << 16) | ((uint32_t)packed[idx + 8] << 24));
-      C = packed[idx + 9];
-      break;
+      if (sz < 11 || packed[idx] != 1) return "Error decoding header.\n";
+      *W = (int)(packed[idx + 1] | (packed[idx + 2] << 8) | (packed[idx + 3] << 16) | ((uint32_t)packed[idx + 4] << 24));
+      *H = (int)(packed[idx + 5] | (packed[idx + 6] << 8) | (packed[idx + 7] << 16) | ((uint32_t)packed[idx + 8] << 24));
+      *C = packed[idx + 9];
+      return nullptr;
     }
     idx += sz;
   }
+}
+
+extern "C" int himg_hip_peek(const uint8_t *packed, size_t packed_size, int *width, int *height,
+                             int *num_channels) {
+  if (!packed || !width || !height || !num_channels) return HIMG_ERR_ARG;
+  int W = 0, H = 0, C = 0;
+  if (parse_header(packed, packed_size, &W, &H, &C)) return HIMG_ERR_FORMAT;
+  *width = W; *height = H; *num_channels = C;
+  return HIMG_OK;
+}
+
+static int decode_core(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size, int *W, int *H,
+                       int *C) {
+  // The host only needs the geometry to size the launch; every check is repeated
+  // on the device (k_dec_parse).
+  if (const char *msg = parse_header(packed, packed_size, W, H, C)) return fail(ctx, HIMG_ERR_FORMAT, msg);
   Geom g;
-  if (!make_geom(W, H, C, C, 1, &g)) return fail(ctx, HIMG_ERR_UNSUPPORTED, "unsupported geometry");
+  if (!make_geom(*W, *H, *C, *C, 1, &g)) return fail(ctx, HIMG_ERR_UNSUPPORTED, "unsupported geometry");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t in_cap = round_up(packed_size + 16, 256);
-  const size_t out_bytes = (size_t)W * H * C;
+  const size_t out_bytes = (size_t)*W * *H * *C;
   if (!ctx->h_in.reserve(in_cap) || !ctx->h_out.reserve(round_up(out_bytes, 256)) ||
       !ctx->h_status.reserve(256))
     return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+  ctx->host_bytes = 0;
   HIP_TRY(ctx, hipMemcpy(ctx->h_in.p, packed, packed_size, hipMemcpyHostToDevice));
   const uint32_t sz32 = (uint32_t)packed_size;
-  int rc = himg_hip_decode_device(ctx, ctx->h_in.p, in_cap, &sz32, 1, W, H, C, ctx->h_out.p,
+  int rc = himg_hip_decode_device(ctx, ctx->h_in.p, in_cap, &sz32, 1, *W, *H, *C, ctx->h_out.p,
                                   (int32_t *)ctx->h_status.p, nullptr);
   if (rc) return rc;
   int32_t st = 0;
@@ -569,11 +622,36 @@ extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t 
     }
     return fail(ctx, code, "device decode reported an error");
   }
+  ctx->host_bytes = out_bytes;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size,
+                               uint8_t **out, int *width, int *height, int *num_channels) {
+  if (!ctx || !packed || !out || !width || !height || !num_channels) return HIMG_ERR_ARG;
+  *out = nullptr;
+  int W = 0, H = 0, C = 0;
+  const int rc = decode_core(ctx, packed, packed_size, &W, &H, &C);
+  if (rc) return rc;
+  const size_t out_bytes = ctx->host_bytes;
   uint8_t *buf = (uint8_t *)std::malloc(out_bytes ? out_bytes : 1);
   if (!buf) return fail(ctx, HIMG_ERR_ARG, "out of host memory");
   HIP_TRY(ctx, hipMemcpy(buf, ctx->h_out.p, out_bytes, hipMemcpyDeviceToHost));
   *out = buf;
   *width = W; *height = H; *num_channels = C;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_to(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size,
+                                  uint8_t *dst, size_t dst_cap, int *width, int *height,
+                                  int *num_channels) {
+  if (!ctx || !packed || !width || !height || !num_channels) return HIMG_ERR_ARG;
+  int W = 0, H = 0, C = 0;
+  const int rc = decode_core(ctx, packed, packed_size, &W, &H, &C);
+  if (rc) return rc;
+  *width = W; *height = H; *num_channels = C;
+  if (!dst || dst_cap < ctx->host_bytes) return fail(ctx, HIMG_ERR_CAPACITY, "output buffer too small");
+  HIP_TRY(ctx, hipMemcpy(dst, ctx->h_out.p, ctx->host_bytes, hipMemcpyDeviceToHost));
   return HIMG_OK;
 }
 

@@ -6,8 +6,9 @@
 #ifndef DECODER_H_
 #define DECODER_H_
 
+#include <cstddef>
 #include <cstdint>
-#include <vector>
+#include <memory>
 
 struct himg_hip_ctx;
 
@@ -28,8 +29,8 @@ class Decoder {
   // the streams the reference rejects.  Reusable across calls.
   bool Decode(const uint8_t *packed_data, int packed_size);
 
-  const uint8_t *unpacked_data() const { return m_unpacked_data.data(); }
-  int unpacked_size() const { return static_cast<int>(m_unpacked_data.size()); }
+  const uint8_t *unpacked_data() const { return m_unpacked_data.get(); }
+  int unpacked_size() const { return static_cast<int>(m_unpacked_size); }
 
   int width() const { return m_width; }
   int height() const { return m_height; }
@@ -38,7 +39,10 @@ class Decoder {
  private:
   himg_hip_ctx *m_ctx;
   int m_max_threads;
-  std::vector<uint8_t> m_unpacked_data;
+  // Kept (and its pages kept mapped) across Decode calls: the copy from the GPU
+  // then runs at PCIe speed instead of page-faulting through a fresh allocation.
+  std::unique_ptr<uint8_t[]> m_unpacked_data;
+  size_t m_unpacked_size, m_capacity;
   int m_width;
   int m_height;
   int m_num_channels;

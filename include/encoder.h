@@ -8,8 +8,9 @@
 #ifndef ENCODER_H_
 #define ENCODER_H_
 
+#include <cstddef>
 #include <cstdint>
-#include <vector>
+#include <memory>
 
 struct himg_hip_ctx;
 
@@ -36,13 +37,14 @@ class Encoder {
               int quality,
               bool use_ycbcr);
 
-  const uint8_t *packed_data() const { return m_packed_data.data(); }
+  const uint8_t *packed_data() const { return m_packed_data.get(); }
 
-  int packed_size() const { return static_cast<int>(m_packed_data.size()); }
+  int packed_size() const { return static_cast<int>(m_packed_size); }
 
  private:
   himg_hip_ctx *m_ctx;
-  std::vector<uint8_t> m_packed_data;
+  std::unique_ptr<uint8_t[]> m_packed_data;  // uninitialised storage, exactly the stream
+  size_t m_packed_size;
 };
 
 }  // namespace himg

@@ -68,6 +68,22 @@ int himg_hip_decode(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size
 
 void himg_hip_free(void *p);
 
+/* The same two operations into caller-owned host memory.  A caller that reuses
+ * its buffers (the reference's benchmark decodes 30x with one Decoder,
+ * benchmark.cpp:122-125) avoids a fresh 64 MiB allocation per call, whose page
+ * faults cost several times the PCIe transfer.  HIMG_ERR_CAPACITY (with the
+ * required size in *out_size / the geometry in *width...) when dst is too small
+ * or NULL; the result then stays resident and himg_hip_fetch_last copies it
+ * without repeating the work.  himg_hip_peek reads only the FRMT chunk (no GPU). */
+int himg_hip_encode_to(himg_hip_ctx *ctx, const uint8_t *data, int width, int height,
+                       int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                       uint8_t *dst, size_t dst_cap, size_t *out_size);
+int himg_hip_decode_to(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_size, uint8_t *dst,
+                       size_t dst_cap, int *width, int *height, int *num_channels);
+int himg_hip_fetch_last(himg_hip_ctx *ctx, uint8_t *dst, size_t dst_cap, size_t *size);
+int himg_hip_peek(const uint8_t *packed, size_t packed_size, int *width, int *height,
+                  int *num_channels);
+
 /* ---- device-resident batched API (roofline measurements, pipelines) ----- */
 
 /* Encode `batch` frames that already live in HBM.

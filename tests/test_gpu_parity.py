@@ -210,3 +210,38 @@ def test_engine_is_reusable_and_fresh_per_call(engine):
     e2 = engine.encode(a, 50)
     _eq(e1, e2, "repeat encode")
     _eq(e1, ol.oracle_encode(a, 50), "oracle")
+
+
+def test_host_buffer_variants(engine):
+    """himg_hip_encode_to / himg_hip_fetch_last / himg_hip_decode_to: caller-owned
+    buffers, HIMG_ERR_CAPACITY with the needed size, results identical to the
+    allocating entry points."""
+    import ctypes as C
+    L = himg_amd.lib()
+    img = himg_amd.synth("randtile", 3, 320, 200)
+    want = ol.oracle_encode(img, 50, True)
+    ctx = engine._ctx
+    n = C.c_size_t()
+    small = np.empty(16, np.uint8)
+    rc = L.himg_hip_encode_to(ctx, img.ctypes.data, 320, 200, 4, 4, 50, 1, small.ctypes.data, small.nbytes, C.byref(n))
+    assert rc == himg_amd.HIMG_ERR_CAPACITY and n.value == len(want)
+    buf = np.empty(n.value + 7, np.uint8)
+    assert L.himg_hip_fetch_last(ctx, buf.ctypes.data, buf.nbytes, C.byref(n)) == 0
+    _eq(buf[: n.value], want, "fetched stream")
+    big = np.empty(himg_amd.max_packed_size(320, 200, 4), np.uint8)
+    assert L.himg_hip_encode_to(ctx, img.ctypes.data, 320, 200, 4, 4, 50, 1, big.ctypes.data, big.nbytes, C.byref(n)) == 0
+    _eq(big[: n.value], want, "stream in the caller's buffer")
+    _eq(engine.encode(img, 50, True), want, "Engine.encode")
+
+    rc0, pix = ol.oracle_decode(want)
+    assert rc0 == 0
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = L.himg_hip_decode_to(ctx, want.ctypes.data, want.nbytes, None, 0, C.byref(w), C.byref(h), C.byref(c))
+    assert rc == himg_amd.HIMG_ERR_CAPACITY and (w.value, h.value, c.value) == (320, 200, 4)
+    out = np.empty(320 * 200 * 4, np.uint8)
+    assert L.himg_hip_fetch_last(ctx, out.ctypes.data, out.nbytes, C.byref(n)) == 0 and n.value == out.nbytes
+    _eq(out, pix.ravel(), "fetched pixels")
+    reuse = np.zeros((200, 320, 4), np.uint8)
+    got = engine.decode(want, out=reuse)
+    assert got.ctypes.data == reuse.ctypes.data   # decoded in place, no new allocation
+    _eq(got.ravel(), pix.ravel(), "pixels in the caller's buffer")

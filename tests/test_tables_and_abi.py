@@ -150,3 +150,25 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(himg_amd.HimgError):
         himg_amd.Engine(0)
+
+
+def test_peek_reads_the_geometry_without_a_gpu():
+    """himg_hip_peek parses the FRMT chunk only (decoder.cpp:144-200): no device needed."""
+    import ctypes as C
+    L = himg_amd.lib()
+    gdir = os.path.join(ROOT, "tests", "golden")
+    seen = 0
+    for fn in sorted(os.listdir(gdir)):
+        if not fn.endswith(".himg"):
+            continue
+        data = np.fromfile(os.path.join(gdir, fn), np.uint8)
+        w, h, c = C.c_int(), C.c_int(), C.c_int()
+        assert L.himg_hip_peek(data.ctypes.data, data.nbytes, C.byref(w), C.byref(h), C.byref(c)) == 0
+        assert (w.value, h.value) == (64, 64) and c.value in (1, 3, 4)
+        seen += 1
+        # truncated before the FRMT body / not a RIFF file
+        assert L.himg_hip_peek(data.ctypes.data, 20, C.byref(w), C.byref(h), C.byref(c)) == himg_amd.HIMG_ERR_FORMAT
+        bad = data.copy()
+        bad[0] ^= 1
+        assert L.himg_hip_peek(bad.ctypes.data, bad.nbytes, C.byref(w), C.byref(h), C.byref(c)) == himg_amd.HIMG_ERR_FORMAT
+    assert seen >= 5
