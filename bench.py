@@ -166,7 +166,7 @@ def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, 
     return out
 
 
-GOLDEN_16384 = {"packed_size": 275620945, "stream_fnv": "5bdcdb7a140df481"}
+GOLDEN_16384 = {"packed_size": 275620945, "stream_fnv": "5bdcdb7a140df481", "decoded_fnv": "08fb9dc8e25c2fae"}
 
 
 def bench_rows(args, rank, local_rank, world, dev):
@@ -224,13 +224,38 @@ def bench_rows(args, rank, local_rank, world, dev):
         step()
     barrier()
     dt = time.perf_counter() - t0
+
+    # Row-sharded decode of the same stream (not part of `value`): every rank
+    # decodes LRES + its own block rows, pixels stay sharded; the gathered image is
+    # hashed once against the golden outside the timed region.
+    d_packed = torch.from_numpy(out).to(dev) if rank == 0 else None
+    ok, pix = sharded.decode_sharded(eng, d_packed, W, H, 4, gather=True, device=dev)
+    dec_verified = "n/a"
+    if rank == 0:
+        assert ok, "sharded decode rejected the stream"
+        if want is None:
+            assert himg_amd.fnv1a64(pix) == GOLDEN_16384["decoded_fnv"], "pixels differ from the reference"
+            dec_verified = "golden"
+        else:
+            rc, ref = ol.oracle_decode(want)
+            assert rc == 0 and np.array_equal(pix.ravel(), ref.ravel()), "pixels differ from the oracle"
+            dec_verified = "oracle"
+    del pix
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        sharded.decode_sharded(eng, d_packed, W, H, 4, gather=False, device=dev)
+    barrier()
+    dt_dec = time.perf_counter() - t1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_dec], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.cpu()[0])
+        dt, dt_dec = float(t.cpu()[0]), float(t.cpu()[1])
     if rank == 0:
         value = W * H * args.steps / dt / 1e6
         print(json.dumps({
+            "decode_mpx_s": round(W * H * args.steps / dt_dec / 1e6, 2),
+            "decode_note": "row-sharded decode incl. broadcast of the stream; pixels stay sharded; bit_exact " + dec_verified,
             "metric": "Mpixels/s encode, one RGBA frame row-sharded over the GPUs, q=%d" % Q,
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -76,6 +76,7 @@ def lib():
     L.himg_hip_free.restype = None
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
     L.himg_hip_decode_device.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_decode_rows_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_shard_stats.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_shard_row_bits.argtypes = [vp, vp, vp, vp]
     L.himg_hip_shard_emit.argtypes = [vp, vp, vp, sz, vp, vp]
@@ -205,6 +206,14 @@ class Engine:
                                           batch, width, height, channels, _ptr(d_out),
                                           _ptr(d_status), C.c_void_p(stream))
         self._check(rc, "decode_device")
+
+    def decode_rows_device(self, d_packed, packed_size, width, height, channels, row0, row1,
+                           d_out_rows, d_status, stream=0):
+        """Block rows [row0, row1) of one frame (row-sharded decode, himg_amd/sharded.py)."""
+        rc = lib().himg_hip_decode_rows_device(self._ctx, _ptr(d_packed), int(packed_size), width,
+                                               height, channels, row0, row1, _ptr(d_out_rows),
+                                               _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "decode_rows_device")
 
     # row-sharded encode (see himg_amd/sharded.py) --------------------------------------
     def shard_stats(self, d_frame_base, width, height, pixel_stride, channels, quality, use_ycbcr,

@@ -128,7 +128,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
-                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1);
 
 // Row-sharded encode of one frame (multi-GPU): phases between the collectives.
 void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,

@@ -479,7 +479,36 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, h_sizes, (size_t)batch * 4, hipMemcpyHostToDevice, s));
   launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
                 (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof,
-                ctx->allow_fused, ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join);
+                ctx->allow_fused, ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, 0,
+                g.rows);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                           int width, int height, int num_channels, int row0,
+                                           int row1, void *d_out_rows, int32_t *d_status,
+                                           void *stream) {
+  if (!ctx || !d_packed || !d_out_rows || !d_status) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
+  if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))
+    return fail(ctx, HIMG_ERR_ARG, "buffers must be 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, 1);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, &packed_size, 4, hipMemcpyHostToDevice, s));
+  // The kernels address pixel rows of the whole frame; hand them a virtual frame
+  // base so that block row row0 lands at the start of d_out_rows.
+  uint8_t *base = (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C;
+  launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
+                (const uint32_t *)ctx->d_sizes.p, base, d_status, s, &ctx->prof, ctx->allow_fused,
+                ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, row0, row1);
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }

@@ -1254,10 +1254,10 @@ __device__ __forceinline__ void iwht8(int &x0, int &x1, int &x2, int &x3, int &x
   x6 = (int16_t)((b4 - b5) >> 3); x7 = (int16_t)((b0 - b1) >> 3);
 }
 
-__global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames) {
+__global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames, int v0) {
   __shared__ int16_t s_unmap[256];   // indexed by the code byte
   __shared__ uint8_t s_shift[2][64];
-  const int v = blockIdx.y, f = blockIdx.z;
+  const int v = blockIdx.y + v0, f = blockIdx.z;
   const DecFrame *df = ws.frames + f;
   if (df->status) return;
   for (int k = threadIdx.x; k < 256; k += 256) {
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
                                                                const uint8_t *packed,
                                                                size_t in_stride,
                                                                const uint32_t *sizes,
-                                                               uint8_t *out_frames) {
+                                                               uint8_t *out_frames, int r0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const FusedLayout L = fused_layout(g.row_block);
   uint8_t *sym = smem + L.sym;
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
   uint8_t *s_shift = smem + L.shift;
 
-  const int r = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int r = blockIdx.x + r0, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
@@ -1569,7 +1569,10 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
-                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1) {
+  // Block rows [r0, r1) only (row-sharded decode: every rank decodes the small
+  // LRES stream and walks all row headers, then its own FRES rows).
+  const int nrows = r1 - r0;
   const unsigned gx = (unsigned)((g.cols + 255) / 256);
   // Fused row kernel when the row's symbols and the decode tables fit the 160 KiB
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
@@ -1610,19 +1613,24 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   do {                                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<COLS>),           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3(g.rows, batch), dim3(kDecThreads), lds,    \
-                       stream, g, ws, d_packed, in_stride, d_sizes, d_out);                     \
+    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3(nrows, batch), dim3(kDecThreads), lds,     \
+                       stream, g, ws, d_packed, in_stride, d_sizes, d_out, r0);                 \
   } while (0)
-    if (g.cols == 512) HIMG_FUSED_LAUNCH(512);
-    else HIMG_FUSED_LAUNCH(0);
+    if (nrows > 0) {
+      if (g.cols == 512) HIMG_FUSED_LAUNCH(512);
+      else HIMG_FUSED_LAUNCH(0);
+    }
 #undef HIMG_FUSED_LAUNCH
     prof_end(prof, stream);
   } else {
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-    HIMG_LAUNCH(k_dec_huff, dim3(g.rows + 1, batch), dim3(kDecThreads), g, ws, d_packed,
-                in_stride, d_sizes, 0, 1);
+    HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
+                d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
+    if (nrows > 0)
+      HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
+                  d_sizes, 1 + r0, 1);
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
-    HIMG_LAUNCH(k_tile_inv, dim3(gx, g.rows, batch), dim3(256), g, ws, d_out);
+    if (nrows > 0) HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
   }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
 }

@@ -196,3 +196,82 @@ class EngineBackend:
         if int(status[0]) != 0:
             raise himg_amd.HimgError(-int(status[0]), "sharded assemble failed")
         return out[: int(size[0])].cpu().numpy()
+
+
+# ---------------------------------------------------------------------------
+# Row-sharded DECODE of one frame.
+# ---------------------------------------------------------------------------
+
+def decode_sharded(engine, packed, width, height, channels=4, group=None, gather=True, device=None,
+                   comm_device=None, stream=0):
+    """Decode one frame with its block rows sharded over the ranks of `group`.
+
+    `packed` (uint8 numpy array or tensor) is the whole stream on rank 0; it is
+    broadcast (the only exchange before the kernels -- the stream is ~4x smaller
+    than the pixels).  Every rank decodes the LRES stream and its own block rows
+    (reference decoder.cpp:292-326 hands block rows to worker threads the same
+    way).  Returns (ok, pixels): `ok` is the AND over the ranks (a stream the
+    reference rejects is rejected); with gather=True rank 0 gets the whole
+    H x W x C image (None elsewhere), otherwise every rank gets its own pixel rows.
+    `engine` provides decode_rows_device (himg_amd.Engine); `comm_device` is where
+    the process group can move tensors (CUDA for nccl/RCCL, "cpu" for gloo).
+    """
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    comm = torch.device(comm_device) if comm_device is not None else dev
+    rows = (height + 7) // 8
+    parts = shard_rows(rows, world)
+    r0, r1 = parts[rank]
+
+    def bcast(t):
+        if world > 1:
+            c = t.to(comm)
+            dist.broadcast(c, src=0, group=group)
+            if c is not t:
+                t.copy_(c)
+
+    # The stream, padded to a multiple of 16 bytes, on every rank.
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        n[0] = int(packed.numel() if torch.is_tensor(packed) else len(packed))
+    bcast(n)
+    size = int(n.item())
+    d_packed = torch.zeros((size + 15) // 16 * 16, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
+        d_packed[:size] = src.to(dev)
+    bcast(d_packed)
+
+    y0, y1 = min(8 * r0, height), min(8 * r1, height)
+    d_rows = torch.empty((max(y1 - y0, 1), width, channels), dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
+    engine.decode_rows_device(d_packed, size, width, height, channels, r0, r1, d_rows, d_status, stream)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    bad = (d_status != 0).to(torch.int32).to(comm)
+    if world > 1:
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    ok = int(bad.item()) == 0
+    d_rows = d_rows[: y1 - y0]
+    if not gather:
+        return ok, (d_rows if ok else None)
+    if world == 1:
+        return ok, (d_rows.cpu().numpy() if ok else None)
+    # Gather the pixel rows on rank 0 (padded to the largest shard).
+    max_rows = max(min(8 * b, height) - min(8 * a, height) for a, b in parts)
+    pad = torch.zeros((max_rows, width, channels), dtype=torch.uint8, device=comm)
+    pad[: y1 - y0] = d_rows.to(comm)
+    lst = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, lst, dst=0, group=group)
+    if rank != 0 or not ok:
+        return ok, None
+    out = torch.empty((height, width, channels), dtype=torch.uint8, device=comm)
+    for t, (a, b) in zip(lst, parts):
+        ya, yb = min(8 * a, height), min(8 * b, height)
+        out[ya:yb] = t[: yb - ya]
+    return ok, out.cpu().numpy()

@@ -154,6 +154,22 @@ int himg_hip_shard_assemble(himg_hip_ctx *ctx, const uint8_t *d_low_full,
                             void *d_out, size_t out_cap, uint32_t *d_size, int32_t *d_status,
                             void *stream);
 
+/* ---- row-sharded decode of ONE frame over several GPUs -------------------- */
+/*
+ * Block rows are independently coded (reference decoder.cpp:298-309 hands them
+ * to worker threads), so one large frame decodes by block rows too.  Every rank
+ * holds the packed stream, parses the container, walks the row headers and
+ * decodes the small LRES stream (1/64 of the data); it then decodes only block
+ * rows [row0, row1) into d_out_rows = pixel rows [8*row0, min(8*row1, height)),
+ * tightly packed.  There is no data-path collective: the verdict is the OR of the
+ * ranks' d_status (a stream the reference rejects is rejected by the rank that
+ * meets the failing check; container-level failures are seen by every rank).
+ * packed_size bytes at d_packed, readable up to the next multiple of 4.
+ */
+int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                int width, int height, int num_channels, int row0, int row1,
+                                void *d_out_rows, int32_t *d_status, void *stream);
+
 /* ---- introspection for parity tests and bench.py ------------------------ */
 
 /* Intermediate device buffers of the LAST encode/decode on this context

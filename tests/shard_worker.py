@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import himg_amd  # noqa: E402
 from himg_amd import sharded  # noqa: E402
+import oracle_lib as ol  # noqa: E402
 
 
 def riff_chunks(stream):
@@ -98,9 +99,45 @@ class StubBackend:
         return np.concatenate([head, rel_full.numpy()])
 
 
+class StubDecodeEngine:
+    """decode_rows_device answered by the oracle (CPU tensors): block rows
+    [r0, r1) of the decoded frame, or a non-zero status when the reference rejects
+    the stream."""
+
+    def decode_rows_device(self, d_packed, size, w, h, c, r0, r1, d_rows, d_status, stream=0):
+        rc, pix = ol.oracle_decode(d_packed[:size].numpy())
+        if rc != 0:
+            d_status[0] = 4
+            return
+        y0, y1 = min(8 * r0, h), min(8 * r1, h)
+        if y1 > y0:
+            d_rows[: y1 - y0] = torch.from_numpy(pix.reshape(h, w, c)[y0:y1].copy())
+
+
+def main_decode(mode, kind, seed, W, H, q, outfile):
+    """Row-sharded decode: rank 0 owns the stream; the assembled pixels (or the
+    word REJECTED) go to outfile."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    packed = ol.oracle_encode(himg_amd.synth(kind, seed, W, H), q, True) if rank == 0 else None
+    if mode == "dstub":
+        ok, pix = sharded.decode_sharded(StubDecodeEngine(), packed, W, H, 4, device="cpu", comm_device="cpu")
+    else:
+        ok, pix = sharded.decode_sharded(himg_amd.Engine(0), packed, W, H, 4, device="cuda:0", comm_device="cpu")
+    if rank == 0:
+        if ok:
+            np.asarray(pix, np.uint8).tofile(outfile)
+        else:
+            open(outfile, "w").write("REJECTED")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     mode, kind, seed, W, H, q, outfile = sys.argv[1:8]
     seed, W, H, q = int(seed), int(W), int(H), int(q)
+    if mode in ("dstub", "dgpu"):
+        return main_decode(mode, kind, seed, W, H, q, outfile)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     img = himg_amd.synth(kind, seed, W, H)

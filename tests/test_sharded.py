@@ -127,3 +127,61 @@ def test_sharded_encode_two_processes(tmp_path):
     _run_ranks(2, ["gpu", "randtile", 2, 512, 1024, 50, out])
     want = ol.oracle_encode(himg_amd.synth("randtile", 2, 512, 1024), 50, True)
     assert np.array_equal(np.fromfile(out, np.uint8), want)
+
+
+# ---- row-sharded decode ---------------------------------------------------------
+
+@pytest.mark.parametrize("world,kind,w,h,q", [(2, "randtile", 256, 512, 90), (3, "gradn", 128, 520, 50),
+                                               (2, "grad", 512, 512, 50)])
+def test_sharded_decode_orchestration_gloo_cpu(tmp_path, world, kind, w, h, q):
+    """world_size > 1 over gloo on CPU: broadcast of the stream, per-rank row
+    ranges, status reduction and the gather; the device phase is answered by the
+    oracle.  The `grad` case is a stream the reference rejects (trap T2)."""
+    out = tmp_path / "out.bin"
+    _run_ranks(world, ["dstub", kind, 4, w, h, q, out])
+    rc, pix = ol.oracle_decode(ol.oracle_encode(himg_amd.synth(kind, 4, w, h), q, True))
+    if rc != 0:
+        assert open(out).read() == "REJECTED"
+    else:
+        assert np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,q,parts", [
+    ("randtile", 256, 512, 90, 2), ("randtile", 4096, 256, 50, 2), ("gradn", 256, 261, 90, 3),
+    ("randtile", 8192, 128, 50, 2), ("rand", 512, 1024, 50, 4)])
+def test_sharded_decode_simulated_ranks(kind, w, h, q, parts):
+    """Every rank simulated in one process: each decodes only its block rows
+    (fused row kernel, generic path for 8192-wide rows, ragged height) and the
+    concatenation equals the oracle's pixels."""
+    import torch
+    packed = ol.oracle_encode(himg_amd.synth(kind, 2, w, h), q, True)
+    rc, pix = ol.oracle_decode(packed)
+    assert rc == 0
+    pix = pix.reshape(h, w, 4)
+    d_packed = torch.zeros((packed.size + 15) // 16 * 16, dtype=torch.uint8, device="cuda:0")
+    d_packed[: packed.size] = torch.from_numpy(packed).to("cuda:0")
+    rows = (h + 7) // 8
+    for (r0, r1) in sharded.shard_rows(rows, parts):
+        eng = himg_amd.Engine(0)
+        y0, y1 = min(8 * r0, h), min(8 * r1, h)
+        d_rows = torch.full((max(y1 - y0, 1), w, 4), 77, dtype=torch.uint8, device="cuda:0")
+        st = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        eng.decode_rows_device(d_packed, packed.size, w, h, 4, r0, r1, d_rows, st)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 0
+        if y1 > y0:
+            assert np.array_equal(d_rows[: y1 - y0].cpu().numpy(), pix[y0:y1]), (r0, r1)
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_sharded_decode_two_processes(tmp_path):
+    """Two ranks, two processes, real collectives (gloo with CPU staging: one GPU on
+    the test box), real kernels on both ranks; and a stream both ranks reject."""
+    out = tmp_path / "out.bin"
+    _run_ranks(2, ["dgpu", "randtile", 2, 512, 1024, 70, out])
+    rc, pix = ol.oracle_decode(ol.oracle_encode(himg_amd.synth("randtile", 2, 512, 1024), 70, True))
+    assert rc == 0 and np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
+    _run_ranks(2, ["dgpu", "grad", 0, 512, 512, 50, out])
+    assert open(out).read() == "REJECTED"
