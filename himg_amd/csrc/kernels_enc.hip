@@ -640,6 +640,37 @@ __device__ __forceinline__ void walk16(const uint32_t w[4], uint32_t mask, int n
   }
 }
 
+// The same walk with the common case folded: a non-zero symbol preceded by at
+// most kPairRuns - 1 zeros is handed to fp as ONE table entry (run token and
+// literal merged, see k_emit / k_tok_hist); everything else goes token by token
+// to f.  pair_tab[r * 256 + sym]; an entry of 0 means "not merged".
+constexpr int kPairRuns = 7;
+template <class FP, class F>
+__device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask, int nvalid,
+                                             int run_in, bool flush, const uint32_t *pair_tab,
+                                             FP &&fp, F &&f) {
+  int prev = -1;
+  uint32_t m = mask;
+  while (m) {
+    const int k = __ffs(m) - 1;
+    m &= m - 1;
+    const int run = k - prev - 1 + (prev < 0 ? run_in : 0);
+    const int sym = symbol_at(w, k);
+    prev = k;
+    const uint32_t pair = run < kPairRuns ? pair_tab[run * 256 + sym] : 0u;
+    if (__builtin_expect(pair != 0, 1)) {
+      fp(pair);
+    } else {
+      if (run) emit_run(run, f);
+      f(sym, 0, 0);
+    }
+  }
+  if (flush) {
+    const int run = nvalid - 1 - prev + (prev < 0 ? run_in : 0);
+    if (run) emit_run(run, f);
+  }
+}
+
 // Zero-run summary of one thread's chunk.  Chunks with fewer than 16 valid
 // symbols only occur at the very end of a span; an empty chunk is the identity.
 __device__ __forceinline__ ZR summarize16(uint32_t mask, int nvalid) {
@@ -724,12 +755,18 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
 }
 
 // k_tok_hist: token histogram of one span (huffman_enc.cpp:98-144).
+// A non-zero symbol preceded by fewer than kPairRuns zeros -- almost every token
+// pair -- is counted with ONE LDS atomic in a 2-D histogram [run][symbol] (which
+// also spreads the hot symbols over more addresses); the pairs are folded into
+// the 261 token bins at the end.  Longer runs are counted token by token.
 __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
+  __shared__ uint32_t hist2[kPairRuns][256];
   __shared__ ZR sm[4];
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
   for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
+  for (int k = threadIdx.x; k < kPairRuns * 256; k += 256) (&hist2[0][0])[k] = 0;
   ZR carry;
   carry.tz = span_carry_in(g, ws, sp, f);
   carry.az = 0;
@@ -746,7 +783,41 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
     carry = total;
     carry.az = 0;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
-    walk16(w, mask, nvalid, ex.tz, flush, [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); });
+    auto one = [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); };
+    int prev = -1;
+    uint32_t m = mask;
+    while (m) {
+      const int k = __ffs(m) - 1;
+      m &= m - 1;
+      const int run = k - prev - 1 + (prev < 0 ? ex.tz : 0);
+      const int sym = symbol_at(w, k);
+      prev = k;
+      if (__builtin_expect(run < kPairRuns, 1)) {
+        atomicAdd(&hist2[run][sym], 1u);
+      } else {
+        emit_run(run, one);
+        atomicAdd(&hist[sym], 1u);
+      }
+    }
+    if (flush) {
+      const int run = nvalid - 1 - prev + (prev < 0 ? ex.tz : 0);
+      if (run) emit_run(run, one);
+    }
+  }
+  __syncthreads();
+  // Fold the pairs: the literal of every pair, and its run token (huffman_enc.cpp:
+  // 111-141: one zero = literal 0, two = 256, three to six = 257).
+  {
+    const int sym = threadIdx.x;   // 256 threads = 256 literal values
+    uint32_t lit = 0, r1 = hist2[1][sym], r2 = hist2[2][sym], r3 = 0;
+#pragma unroll
+    for (int r = 0; r < kPairRuns; ++r) lit += hist2[r][sym];
+#pragma unroll
+    for (int r = 3; r < kPairRuns; ++r) r3 += hist2[r][sym];
+    if (lit) atomicAdd(&hist[sym], lit);
+    if (r1) atomicAdd(&hist[0], r1);
+    if (r2) atomicAdd(&hist[256], r2);
+    if (r3) atomicAdd(&hist[257], r3);
   }
   __syncthreads();
   uint32_t *sh = (s.is_lres ? ws.span_hist_l + ((size_t)f * g.lres_spans + sp) * kHistStride
@@ -992,8 +1063,17 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
 // with neighbours: FRES rows are byte aligned, so edge dwords are written with
 // byte stores (single owner per byte); LRES spans meet at arbitrary bit
 // positions, so their edge dwords are OR-ed into the pre-zeroed LRES region.
+//
+// The kernel is latency-bound and lives on occupancy (PMC: 76 % VALU-busy at 6
+// workgroups per CU; 4 workgroups cost +60 %), so the staging buffer is NOT
+// sized for the worst case of an iteration (4096 symbols x 46 bits = 24 KiB) but
+// for 4 KiB: a circular buffer indexed by the span-relative bit position.  An
+// iteration whose bits exceed it (never seen on image data: it takes > 8 bits
+// per SYMBOL) is emitted in several windows, each lane skipping the tokens
+// outside the current window.
 // ---------------------------------------------------------------------------
-constexpr int kStageWords = 6144;  // >= (31 + (4096+32)*46) / 32
+constexpr int kStageWords = 1024;                                   // power of two
+constexpr uint32_t kWindowBits = (uint32_t)(kStageWords - 4) * 32u; // + carry word + 46-bit spill
 
 // Wave-level inclusive scans (no barrier); lane 63 holds the wave total.
 __device__ __forceinline__ ZR wave_scan_zr(ZR v) {
@@ -1020,13 +1100,17 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
 // Three barriers per 4096-symbol iteration: (A) after the waves publish their
 // zero-run totals, (B) after they publish their bit totals, (C) after the bits
 // have been OR-ed into the staging buffer.  The exchange slots are double
-// buffered by iteration parity, and the staging buffer is circular: the partial
-// last word stays where it is and every thread flushes AND re-zeroes its own
-// words, so neither needs a barrier of its own.
+// buffered by iteration parity; every thread flushes AND re-zeroes its own words
+// of the circular buffer, and the next ORs only come after the next iteration's
+// barriers, so the flush needs no barrier of its own.
 __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
                                               const uint32_t *sizes, int sp0) {
   __shared__ uint32_t stage[kStageWords];
   __shared__ unsigned long long s_cl[kHistStride];  // code | length << 32
+  // Merged token pairs: a zero run of r <= 6 zeros followed by the literal `sym`
+  // (the common case by far) costs ONE lookup and ONE put: bits | length << 24,
+  // 0 where the pair is longer than 24 bits (then the tokens go one by one).
+  __shared__ uint32_t s_pair[kPairRuns][256];
   __shared__ ZR sm_zr[2][4];
   __shared__ uint32_t sm_u[2][4];
 
@@ -1044,10 +1128,24 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   for (int k = tid; k < kHistStride; k += 256)
     s_cl[k] = (unsigned long long)(uint32_t)ws.codes[tab + k] | ((unsigned long long)ws.lens[tab + k] << 32);
   for (int k = tid; k < kStageWords; k += 256) stage[k] = 0;
+  __syncthreads();
+  for (int k = tid; k < kPairRuns * 256; k += 256) {
+    const int r = k >> 8, sym = k & 255;
+    // run token of r zeros (huffman_enc.cpp:111-141): none, literal 0, 256, or 257 + (r - 3)
+    const int rs = r == 1 ? 0 : r == 2 ? 256 : 257;
+    const unsigned long long cr = r ? s_cl[rs] : 0ull, cs = s_cl[sym];
+    const int lr = (int)(cr >> 32), eb = r >= 3 ? 2 : 0, ls = (int)(cs >> 32);
+    const unsigned long long bits = (uint32_t)cr | ((unsigned long long)(r >= 3 ? r - 3 : 0) << lr) |
+                                    ((unsigned long long)(uint32_t)cs << (lr + eb));
+    const int n = lr + eb + ls;
+    s_pair[r][sym] = (sym != 0 && ls > 0 && (r == 0 || lr > 0) && n <= 24) ? ((uint32_t)bits | ((uint32_t)n << 24)) : 0u;
+  }
   int run_carry = span_carry_in(g, ws, sp, f);  // zeros pending in front of this iteration
-  unsigned long long gword = B0 >> 5;           // global dword of stage[woff]
-  uint32_t carry_bits = (uint32_t)(B0 & 31);    // bits of stage[woff] already taken
-  uint32_t woff = 0;                            // staging word of the current partial word
+  // Positions are bits relative to the dword that holds the span's first bit;
+  // word k of the span is global dword gw0 + k and staging slot k % kStageWords.
+  const unsigned long long gw0 = B0 >> 5;
+  uint32_t sbit = (uint32_t)(B0 & 31);  // position of the next token
+  uint32_t fw = 0;                      // words already flushed
   __syncthreads();
 
   auto store_word = [&](unsigned long long gw, uint32_t val) {
@@ -1097,8 +1195,9 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
 
     // (B) bit offset of every lane.
     uint32_t mybits = 0;
-    walk16(w, mask, nvalid, run_in, flush,
-           [&](int sym, int eb, int) { mybits += (uint32_t)(s_cl[sym] >> 32) + eb; });
+    walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0],
+                 [&](uint32_t pair) { mybits += pair >> 24; },
+                 [&](int sym, int eb, int) { mybits += (uint32_t)(s_cl[sym] >> 32) + eb; });
     const uint32_t bincl = wave_scan_u32(mybits);
     if (lane == 63) sm_u[par][wave] = bincl;
     __syncthreads();
@@ -1108,48 +1207,73 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
       if (k < wave) bpre += sm_u[par][k];
       iter_bits += sm_u[par][k];
     }
+    const uint32_t my_pos = sbit + bpre + bincl - mybits;  // where this lane's first token starts
+    const uint32_t iter_end = sbit + iter_bits;
 
-    // Append this thread's tokens at its bit offset inside the circular staging buffer.
-    uint32_t pos = carry_bits + bpre + bincl - mybits;
-    uint32_t widx = woff + (pos >> 5);
-    if (widx >= (uint32_t)kStageWords) widx -= kStageWords;
-    uint32_t accb = pos & 31;
-    unsigned long long acc = 0;
-    auto put = [&](uint32_t v, int n) {  // n <= 32
-      acc |= (unsigned long long)v << accb;
-      accb += n;
-      if (accb >= 32) {
-        atomicOr(&stage[widx], (uint32_t)acc);
-        widx = widx + 1 == (uint32_t)kStageWords ? 0u : widx + 1;
-        acc >>= 32;
-        accb -= 32;
+    // Append the tokens to the circular staging buffer, window by window (one
+    // window unless the iteration overflows the buffer).
+    uint32_t wlo = sbit;
+    for (;;) {
+      const uint32_t whi = iter_end - wlo <= kWindowBits ? iter_end : wlo + kWindowBits;
+      const bool whole = wlo == sbit && whi == iter_end;
+      uint32_t widx = 0, accb = 0;
+      unsigned long long acc = 0;
+      auto put = [&](uint32_t v, int n) {  // n <= 32
+        acc |= (unsigned long long)v << accb;
+        accb += n;
+        if (accb >= 32) {
+          atomicOr(&stage[widx], (uint32_t)acc);
+          widx = (widx + 1) & (kStageWords - 1);
+          acc >>= 32;
+          accb -= 32;
+        }
+      };
+      if (whole) {
+        widx = (my_pos >> 5) & (kStageWords - 1);
+        accb = my_pos & 31;
+        walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0],
+                     [&](uint32_t pair) { put(pair & 0xffffffu, (int)(pair >> 24)); },
+                     [&](int sym, int eb, int ev) {
+                       const unsigned long long cl = s_cl[sym];
+                       put((uint32_t)cl, (int)(cl >> 32));
+                       if (eb) put((uint32_t)ev, eb);
+                     });
+      } else {
+        // Only the tokens that START inside [wlo, whi); they are contiguous.
+        uint32_t q = my_pos;
+        bool started = false;
+        walk16(w, mask, nvalid, run_in, flush, [&](int sym, int eb, int ev) {
+          const unsigned long long cl = s_cl[sym];
+          const int len = (int)(cl >> 32);
+          if (q >= wlo && q < whi) {
+            if (!started) { widx = (q >> 5) & (kStageWords - 1); accb = q & 31; started = true; }
+            put((uint32_t)cl, len);
+            if (eb) put((uint32_t)ev, eb);
+          }
+          q += (uint32_t)(len + eb);
+        });
       }
-    };
-    walk16(w, mask, nvalid, run_in, flush, [&](int sym, int eb, int ev) {
-      const unsigned long long cl = s_cl[sym];
-      put((uint32_t)cl, (int)(cl >> 32));
-      if (eb) put((uint32_t)ev, eb);
-    });
-    if (accb && acc) atomicOr(&stage[widx], (uint32_t)acc);
-    __syncthreads();   // (C)
+      if (accb && acc) atomicOr(&stage[widx], (uint32_t)acc);
+      __syncthreads();   // (C)
 
-    // Flush the complete words; each thread re-zeroes what it flushed.
-    const uint32_t end_bits = carry_bits + iter_bits;
-    const uint32_t nfull = end_bits >> 5;
-    for (uint32_t k = tid; k < nfull; k += 256) {
-      uint32_t i = woff + k;
-      if (i >= (uint32_t)kStageWords) i -= kStageWords;
-      store_word(gword + k, stage[i]);
-      stage[i] = 0;
+      // Flush the words that are complete below whi; each thread re-zeroes what it
+      // flushed.  (Bits of a token that spills past whi stay staged.)
+      const uint32_t nw = whi >> 5;
+      for (uint32_t k = fw + tid; k < nw; k += 256) {
+        const uint32_t slot = k & (kStageWords - 1);
+        store_word(gw0 + k, stage[slot]);
+        stage[slot] = 0;
+      }
+      fw = nw;
+      wlo = whi;
+      if (wlo >= iter_end) break;
+      __syncthreads();   // the next window's ORs must not meet this flush
     }
-    gword += nfull;
-    woff += nfull;
-    if (woff >= (uint32_t)kStageWords) woff -= kStageWords;
-    carry_bits = end_bits & 31;
+    sbit = iter_end;
     w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
   }
   __syncthreads();
-  if (tid == 0 && carry_bits) store_word(gword, stage[woff]);
+  if (tid == 0 && (sbit & 31)) store_word(gw0 + (sbit >> 5), stage[(sbit >> 5) & (kStageWords - 1)]);
 }
 
 // ---------------------------------------------------------------------------

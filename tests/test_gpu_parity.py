@@ -245,3 +245,27 @@ def test_host_buffer_variants(engine):
     got = engine.decode(want, out=reuse)
     assert got.ctypes.data == reuse.ctypes.data   # decoded in place, no new allocation
     _eq(got.ravel(), pix.ravel(), "pixels in the caller's buffer")
+
+
+def test_emit_staging_overflow_windows(engine):
+    """k_emit stages an iteration's bits (4096 symbols) in a 4 KiB circular buffer
+    and falls back to several windows when they do not fit (> 32 640 bits).  A
+    frame of two-valued tiles with one band of random tiles gives that band's
+    low-res deltas rare, 11..19-bit codes over 8192 consecutive LRES symbols."""
+    rng = np.random.default_rng(5)
+    w, h, band = 1024, 4096, 512
+    a = rng.integers(0, 2, (h // 8, w // 8, 4), dtype=np.uint8) * 16 + 120
+    a[: band // 8] = rng.integers(0, 256, (band // 8, w // 8, 4), dtype=np.uint8)
+    img = np.ascontiguousarray(np.repeat(np.repeat(a, 8, axis=0), 8, axis=1))
+    want, tr = ol.oracle_encode(img, 50, True, trace=True)
+    sym = np.array(tr["lres_sym"]).ravel()
+    lens = np.array(tr["lres_len"]).astype(np.int64)
+    cost = lens[sym] * (sym != 0)   # literal bits only: a lower bound of the iteration's bits
+    worst = max(int(cost[i:i + 4096].sum()) for s0 in range(0, sym.size, 16384)
+                for i in range(s0, min(s0 + 16384, sym.size), 4096))
+    assert worst > 1020 * 32, "the input no longer overflows the staging window"
+    assert lens.max() > 11   # codes longer than the decoder's first-level table, too
+    _eq(engine.encode(img, 50, True), want, "stream")
+    rc, pix = ol.oracle_decode(want)
+    assert rc == 0
+    _eq(engine.decode(want).ravel(), pix.ravel(), "pixels")
