@@ -645,10 +645,11 @@ __device__ __forceinline__ void walk16(const uint32_t w[4], uint32_t mask, int n
 // literal merged, see k_emit / k_tok_hist); everything else goes token by token
 // to f.  pair_tab[r * 256 + sym]; an entry of 0 means "not merged".
 constexpr int kPairRuns = 7;
+constexpr int kRunTab = 279;   // run_tab[r]: the token of a run of r zeros (r < 279: symbols 0, 256..259)
 template <class FP, class F>
 __device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask, int nvalid,
                                              int run_in, bool flush, const uint32_t *pair_tab,
-                                             FP &&fp, F &&f) {
+                                             const uint32_t *run_tab, FP &&fp, F &&f) {
   int prev = -1;
   uint32_t m = mask;
   while (m) {
@@ -661,7 +662,11 @@ __device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask,
     if (__builtin_expect(pair != 0, 1)) {
       fp(pair);
     } else {
-      if (run) emit_run(run, f);
+      // Medium path: the run token (code + extra bits) from a table indexed by the
+      // run length, then the literal -- no classification branches.
+      const uint32_t rt = (run_tab && run < kRunTab) ? run_tab[run] : 0u;
+      if (rt) fp(rt);
+      else if (run) emit_run(run, f);
       f(sym, 0, 0);
     }
   }
@@ -762,11 +767,13 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
 __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
   __shared__ uint32_t hist2[kPairRuns][256];
+  __shared__ uint32_t hrun[kRunTab + 1];   // runs of kPairRuns..278 zeros, by exact length
   __shared__ ZR sm[4];
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
   for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
   for (int k = threadIdx.x; k < kPairRuns * 256; k += 256) (&hist2[0][0])[k] = 0;
+  for (int k = threadIdx.x; k < kRunTab + 1; k += 256) hrun[k] = 0;
   ZR carry;
   carry.tz = span_carry_in(g, ws, sp, f);
   carry.az = 0;
@@ -795,7 +802,8 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
       if (__builtin_expect(run < kPairRuns, 1)) {
         atomicAdd(&hist2[run][sym], 1u);
       } else {
-        emit_run(run, one);
+        if (run < kRunTab) atomicAdd(&hrun[run], 1u);
+        else emit_run(run, one);
         atomicAdd(&hist[sym], 1u);
       }
     }
@@ -818,6 +826,10 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
     if (r1) atomicAdd(&hist[0], r1);
     if (r2) atomicAdd(&hist[256], r2);
     if (r3) atomicAdd(&hist[257], r3);
+  }
+  for (int r = kPairRuns + (int)threadIdx.x; r < kRunTab; r += 256) {   // 7..22 -> 258, 23..278 -> 259
+    const uint32_t c = hrun[r];
+    if (c) atomicAdd(&hist[r <= 22 ? 258 : 259], c);
   }
   __syncthreads();
   uint32_t *sh = (s.is_lres ? ws.span_hist_l + ((size_t)f * g.lres_spans + sp) * kHistStride
@@ -1111,6 +1123,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   // (the common case by far) costs ONE lookup and ONE put: bits | length << 24,
   // 0 where the pair is longer than 24 bits (then the tokens go one by one).
   __shared__ uint32_t s_pair[kPairRuns][256];
+  __shared__ uint32_t s_run[kRunTab];   // run token of r zeros: bits | length << 24 (0: not representable)
   __shared__ ZR sm_zr[2][4];
   __shared__ uint32_t sm_u[2][4];
 
@@ -1139,6 +1152,15 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
                                     ((unsigned long long)(uint32_t)cs << (lr + eb));
     const int n = lr + eb + ls;
     s_pair[r][sym] = (sym != 0 && ls > 0 && (r == 0 || lr > 0) && n <= 24) ? ((uint32_t)bits | ((uint32_t)n << 24)) : 0u;
+  }
+  for (int r = tid; r < kRunTab; r += 256) {
+    const int rs = r == 1 ? 0 : r == 2 ? 256 : r <= 6 ? 257 : r <= 22 ? 258 : 259;
+    const int eb = r <= 2 ? 0 : r <= 6 ? 2 : r <= 22 ? 4 : 8;
+    const int ev = r <= 2 ? 0 : r <= 6 ? r - 3 : r <= 22 ? r - 7 : r - 23;
+    const unsigned long long cl = s_cl[rs];
+    const int len = (int)(cl >> 32);
+    s_run[r] = (r > 0 && len > 0 && len + eb <= 24)
+                   ? ((uint32_t)cl | ((uint32_t)ev << len) | ((uint32_t)(len + eb) << 24)) : 0u;
   }
   int run_carry = span_carry_in(g, ws, sp, f);  // zeros pending in front of this iteration
   // Positions are bits relative to the dword that holds the span's first bit;
@@ -1195,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
 
     // (B) bit offset of every lane.
     uint32_t mybits = 0;
-    walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0],
+    walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
                  [&](uint32_t pair) { mybits += pair >> 24; },
                  [&](int sym, int eb, int) { mybits += (uint32_t)(s_cl[sym] >> 32) + eb; });
     const uint32_t bincl = wave_scan_u32(mybits);
@@ -1231,7 +1253,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
       if (whole) {
         widx = (my_pos >> 5) & (kStageWords - 1);
         accb = my_pos & 31;
-        walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0],
+        walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
                      [&](uint32_t pair) { put(pair & 0xffffffu, (int)(pair >> 24)); },
                      [&](int sym, int eb, int ev) {
                        const unsigned long long cl = s_cl[sym];
