@@ -101,6 +101,10 @@ struct DecWs {
   uint8_t *lres_sym;         size_t lres_stride;
   uint8_t *fres_sym;         size_t fres_stride;
   uint8_t *low;              size_t plane_stride;
+  // k_row_count -> k_dec_row_fused: per FRES row and lane the first owned token
+  // (bits from the chunk start) and the exclusive prefix of the symbol counts.
+  uint32_t *lane_start;      // [f][rows][kDecThreads]
+  uint32_t *lane_off;        // [f][rows][kDecThreads + 4]: offsets, then total, chain end (bits), valid flag
   uint32_t *parse_stats;     // [f][4] k_dec_parse phase cycles / 16
   uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
   // Parallel LRES decode (k_lres_spec / verify / write).

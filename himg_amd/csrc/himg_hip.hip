@@ -116,7 +116,7 @@ struct himg_hip_ctx {
   bool enc_valid = false;
 
   // Decoder workspace.
-  DevBuf d_frames, d_nodes, d_grp, d_sub, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
+  DevBuf d_frames, d_nodes, d_grp, d_sub, d_lane, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
   Geom dec_geom{};
   DecWs dec_ws{};
   int dec_batch = 0;
@@ -225,7 +225,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (ctx->side) hipStreamDestroy(ctx->side);
   ctx->prof.collect();
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
-                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_sub, &ctx->d_rows,
+                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
   for (DevBuf *b : all) b->release();
@@ -343,6 +343,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
       !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 3 * 4) ||
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 4) ||
+      !ctx->d_lane.reserve((size_t)batch * g.rows * (2 * kDecThreads + 4) * 4) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
       !ctx->d_sizes.reserve((size_t)batch * 4) ||
@@ -352,6 +353,8 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.nodes = (int32_t *)ctx->d_nodes.p;
   w.grp = (uint2 *)ctx->d_grp.p;
   w.sub = (uint32_t *)ctx->d_sub.p;
+  w.lane_start = (uint32_t *)ctx->d_lane.p;
+  w.lane_off = w.lane_start + (size_t)batch * g.rows * kDecThreads;
   w.row_off = (uint32_t *)ctx->d_rows.p;
   w.row_len = w.row_off + (size_t)batch * g.rows;
   w.lres_sym = (uint8_t *)ctx->d_lres.p; w.lres_stride = lres;
