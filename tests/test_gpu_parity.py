@@ -269,3 +269,43 @@ def test_emit_staging_overflow_windows(engine):
     rc, pix = ol.oracle_decode(want)
     assert rc == 0
     _eq(engine.decode(want).ravel(), pix.ravel(), "pixels")
+
+
+def _chunks(stream):
+    import struct
+    b, out, i = bytes(stream), {}, 12
+    while i + 8 <= len(b):
+        sz = struct.unpack("<I", b[i + 4:i + 8])[0]
+        out[b[i:i + 4].decode()] = (i + 8, sz)
+        i += 8 + sz
+    return out
+
+
+@pytest.mark.parametrize("kind,w,h,q", [("randtile", 256, 128, 90), ("gradn", 512, 512, 50), ("rand", 128, 64, 50)])
+def test_bit_flips_in_the_payload_decode_like_the_reference(engine, unfused_engine, kind, w, h, q):
+    """Streams no encoder produced: one flipped bit in the LRES / FRES payload (or,
+    sometimes, in the serialised tree).  The container stays valid, so the
+    reference's behaviour is defined: it either rejects the stream or decodes
+    different pixels -- and the GPU decoder (fused and generic path) must do exactly
+    the same, bit for bit."""
+    img = himg_amd.synth(kind, 3, w, h)
+    good = ol.oracle_encode(img, q, True)
+    assert ol.oracle_decode(good)[0] == 0
+    ch = _chunks(good)
+    rng = np.random.default_rng(1)
+    accepted = rejected = 0
+    for t in range(120):
+        bad = good.copy()
+        off, sz = ch["FRES" if t % 3 else "LRES"]
+        lo = off + (0 if t % 10 == 0 else min(400, sz // 2))
+        bad[int(rng.integers(lo, off + sz))] ^= 1 << int(rng.integers(0, 8))
+        rc, pix = ol.oracle_decode(bad)
+        for eng in (engine, unfused_engine) if t % 4 == 0 else (engine,):
+            if rc == 0:
+                _eq(eng.decode(bad).ravel(), pix.ravel(), "pixels of mutation %d" % t)
+            else:
+                with pytest.raises(himg_amd.HimgError):
+                    eng.decode(bad)
+        accepted += rc == 0
+        rejected += rc != 0
+    assert accepted > 10 and rejected > 10   # the mutations exercise both outcomes
