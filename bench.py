@@ -58,6 +58,8 @@ def parse_args():
                          "metric); rows: ONE frame (default 16384x16384, BASELINE config 4) sharded by "
                          "block rows with RCCL all-reduce / all-gather / gather (encode only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements (copy ceiling, latency, host API): profile runs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     return ap.parse_args()
 
@@ -430,7 +432,7 @@ def main():
             # (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration)): these kernels are
             # instruction-bound, the HBM fraction is an upper bound on what is left.
             valu_busy = None
-            ppath = os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")
+            ppath = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
             if os.path.exists(ppath) and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
                 for k, v in json.load(open(ppath)).items():
                     if k.split("<")[0] == dom.strip("()").split("<")[0] and v.get("dur_us"):
@@ -460,7 +462,7 @@ def main():
             "roofline": roofline,
             "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out["extras"] = measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e,
                                            d_st_d, d_pix, h_sizes, frames[0], W, H, Q, cap)
         if world == 1 and not args.no_cpu_baseline:

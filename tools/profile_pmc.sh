@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {
   local name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- \
-      python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} \
+      python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} \
       > "$ROOT/$OUT/$name.log" 2>&1
   echo "$name exit=$?"
 }
