@@ -45,8 +45,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=12, help="frames per GPU per step")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--batch", type=int, default=24, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams (one engine context each) the batch is split over, so the short "
                          "serial kernels of one group overlap the wide kernels of the other")
     ap.add_argument("--width", type=int, default=None, help="default 4096 (frames) / 16384 (rows)")
