@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
 // ---------------------------------------------------------------------------
 constexpr int kStageWords = 1024;                                   // power of two
 constexpr uint32_t kWindowBits = (uint32_t)(kStageWords - 4) * 32u; // + carry word + 46-bit spill
+constexpr int kPrivWords = 8;   // lane-private words per iteration (16 symbols: 256 bits cover all but 16+-bit codes)
 
 // Wave-level inclusive scans (no barrier); lane 63 holds the wave total.
 __device__ __forceinline__ ZR wave_scan_zr(ZR v) {
@@ -1124,6 +1125,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   // 0 where the pair is longer than 24 bits (then the tokens go one by one).
   __shared__ uint32_t s_pair[kPairRuns][256];
   __shared__ uint32_t s_run[kRunTab];   // run token of r zeros: bits | length << 24 (0: not representable)
+  __shared__ uint32_t s_priv[kPrivWords * 256];   // [word][lane]: the bits a lane assembled this iteration
   __shared__ ZR sm_zr[2][4];
   __shared__ uint32_t sm_u[2][4];
 
@@ -1215,14 +1217,42 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     run_carry = tot.tz;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
 
-    // (B) bit offset of every lane.
-    uint32_t mybits = 0;
-    walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
-                 [&](uint32_t pair) { mybits += pair >> 24; },
-                 [&](int sym, int eb, int) { mybits += (uint32_t)(s_cl[sym] >> 32) + eb; });
+    // (B) ONE walk over the tokens: the lane assembles its bits from bit 0 into
+    // lane-private LDS words (plain stores, transposed so that lanes never share a
+    // bank) and thereby learns its bit count; after the offset scan the words are
+    // shifted into the shared staging buffer whole.  A lane with more than
+    // kPrivWords words (or an iteration beyond the staging window) falls back to
+    // the two-pass, window-by-window emission below.
+    uint32_t mybits, nwords;
+    bool ovf = false;
+    {
+      uint32_t nw = 0, ab = 0;
+      unsigned long long a = 0;
+      auto lput = [&](uint32_t v, int n) {  // n <= 32
+        a |= (unsigned long long)v << ab;
+        ab += n;
+        if (ab >= 32) {
+          if (nw < (uint32_t)kPrivWords) s_priv[nw * 256 + tid] = (uint32_t)a;
+          ++nw;
+          a >>= 32;
+          ab -= 32;
+        }
+      };
+      walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
+                   [&](uint32_t pair) { lput(pair & 0xffffffu, (int)(pair >> 24)); },
+                   [&](int sym, int eb, int ev) {
+                     const unsigned long long cl = s_cl[sym];
+                     lput((uint32_t)cl, (int)(cl >> 32));
+                     if (eb) lput((uint32_t)ev, eb);
+                   });
+      mybits = nw * 32u + ab;
+      nwords = nw + (ab ? 1u : 0u);
+      if (ab && nw < (uint32_t)kPrivWords) s_priv[nw * 256 + tid] = (uint32_t)a;
+      ovf = nwords > (uint32_t)kPrivWords;
+    }
     const uint32_t bincl = wave_scan_u32(mybits);
     if (lane == 63) sm_u[par][wave] = bincl;
-    __syncthreads();
+    const int any_ovf = __syncthreads_or(ovf ? 1 : 0);
     uint32_t bpre = 0, iter_bits = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1232,8 +1262,31 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     const uint32_t my_pos = sbit + bpre + bincl - mybits;  // where this lane's first token starts
     const uint32_t iter_end = sbit + iter_bits;
 
-    // Append the tokens to the circular staging buffer, window by window (one
-    // window unless the iteration overflows the buffer).
+    if (!any_ovf && iter_bits <= kWindowBits) {
+      // Fast path: shift the lane's words to its bit offset and OR them in.
+      const uint32_t sh = my_pos & 31;
+      uint32_t widx = (my_pos >> 5) & (kStageWords - 1);
+      for (uint32_t j = 0; j < nwords; ++j) {
+        const unsigned long long v = (unsigned long long)s_priv[j * 256 + tid] << sh;
+        atomicOr(&stage[widx], (uint32_t)v);
+        widx = (widx + 1) & (kStageWords - 1);
+        if (v >> 32) atomicOr(&stage[widx], (uint32_t)(v >> 32));
+      }
+      __syncthreads();   // (C)
+      const uint32_t nw = iter_end >> 5;
+      for (uint32_t k = fw + tid; k < nw; k += 256) {
+        const uint32_t slot = k & (kStageWords - 1);
+        store_word(gw0 + k, stage[slot]);
+        stage[slot] = 0;
+      }
+      fw = nw;
+      sbit = iter_end;
+      w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
+      continue;
+    }
+
+    // Fallback: append the tokens to the circular staging buffer token by token,
+    // window by window.
     uint32_t wlo = sbit;
     for (;;) {
       const uint32_t whi = iter_end - wlo <= kWindowBits ? iter_end : wlo + kWindowBits;
