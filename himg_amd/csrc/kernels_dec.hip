@@ -1,21 +1,22 @@
 // kernels_dec.hip -- HIMG decode path as hand-written HIP for gfx950 (MI355X).
 //
 // Pipeline (all on device, batched over frames):
-//   k_dec_parse       RIFF/chunk walk, tables, Huffman trees, row index
-//                     (decoder.cpp:144-272,428-461, huffman_dec.cpp:152-251)
-//   k_dec_huff        RLE+Huffman decode of the LRES stream and of every FRES
-//                     block row (huffman_dec.cpp:274-418).  Each stream is decoded
-//                     by a whole workgroup: the payload is cut into 256-bit
-//                     sub-sequences, every lane decodes one speculatively and the
-//                     workgroup iterates to the self-synchronised fixpoint, then a
-//                     prefix scan of the symbol counts places the output.
+//   k_dec_parse       RIFF chunk headers, mapping tables, QCFG, both Huffman trees,
+//                     decode tables (decoder.cpp:144-290,428-461, huffman_dec.cpp:152-229)
+//   k_dec_rowwalk     index of the FRES block rows (huffman_dec.cpp:232-248), side stream
+//   k_lres_chain<>, k_lres_verify, k_lres_write, k_lres_finish
+//                     the LRES stream, all chunks in parallel (huffman_dec.cpp:274-418)
 //   k_lres_unpredict  inverse low-res prediction              (downsampled.cpp:318-382)
-//   k_tile_inv        gather, dequantise, inverse WHT, low-res add, clamp,
-//                     colour inverse (decoder.cpp:331-426, quantize.cpp:153-165,
-//                     hadamard.cpp:90-103, ycbcr.cpp:54-82)
+//   k_row_count       fixpoint rounds of every FRES block row (huffman_dec.cpp:274-418)
+//   k_dec_row_fused   per block row: write pass into LDS, dequantise, inverse WHT,
+//                     low-res add, clamp, colour inverse, pixel stores
+//                     (decoder.cpp:331-426, quantize.cpp:153-165, hadamard.cpp:90-103,
+//                     ycbcr.cpp:54-82)
+//   k_dec_huff, k_tile_inv
+//                     the same two steps through HBM for rows wider than the LDS, and
+//                     the serial LRES fallback
+// One entropy-decode engine serves all of them: see "Entropy decoding" below.
 #include "himg_dev.h"
-
-#include <type_traits>
 
 namespace himg_dev {
 
@@ -57,20 +58,6 @@ __device__ bool find_chunk(const uint8_t *p, uint32_t n, uint32_t *idx, uint32_t
     if (t == tag) { *size = sz; return true; }
     *idx += sz;
   }
-}
-
-__device__ bool parse_map(const uint8_t *in, uint32_t size, int16_t *t) {
-  // mapper.cpp:127-157
-  if (size < 1) return false;
-  const int n1 = in[0];
-  if (n1 > 127 || (uint32_t)(1 + n1 + 2 * (127 - n1)) != size) return false;
-  const uint8_t *q = in + 1;
-  t[0] = 0;
-  for (int i = 1; i <= 127; ++i) {
-    if (i <= n1) { t[i] = (int16_t)*q++; }
-    else { t[i] = (int16_t)(uint16_t)(q[0] | (q[1] << 8)); q += 2; }
-  }
-  return true;
 }
 
 // Pre-order tree recovery (huffman_dec.cpp:152-213), iterative.  Node arrays:
@@ -130,7 +117,7 @@ __device__ int recover_tree(const uint32_t *w /* LDS words */, uint32_t nbytes, 
   return 0;
 }
 
-// parse_map on bytes staged in LDS (mapper.cpp:127-157).
+// Mapping table of the LMAP / FMAP chunk, from bytes staged in LDS (mapper.cpp:127-157).
 __device__ bool parse_map_lds(const uint8_t *in, uint32_t size, int16_t *t) {
   if (size < 1) return false;
   const int n1 = in[0];

@@ -4,8 +4,9 @@
 //   k_lowres_avg      colour lift + 8x8 box average          (ycbcr.cpp:24-52, downsampled.cpp:76-96)
 //   k_lowres_blend    1/16-phase blend -> low-res plane      (downsampled.cpp:98-113)
 //   k_lres_predict    predictor select + delta coding        (downsampled.cpp:177-316)
-//   k_tile_fwd        lift, low-res removal, WHT, quantize,  (encoder.cpp:258-327, hadamard.cpp:78-88,
-//                     compand, coefficient-major scatter      quantize.cpp:127-151, mapper.cpp:159-182)
+//   k_tile_fwd_pk /   lift, low-res removal, WHT, quantize,  (encoder.cpp:258-327, hadamard.cpp:78-88,
+//   k_tile_fwd        compand, coefficient-major scatter      quantize.cpp:127-151, mapper.cpp:159-182)
+//                     (_pk: full RGBA8 tiles, two channels per register in packed int16)
 //   k_lres_summary    zero-run summaries of LRES spans
 //   k_tok_hist        RLE tokenise + histogram per span      (huffman_enc.cpp:98-144)
 //   k_tree            Huffman tree, codes, serialised tree   (huffman_enc.cpp:148-238)
@@ -243,10 +244,10 @@ __device__ __forceinline__ void wht8(int &x0, int &x1, int &x2, int &x3, int &x4
 // adjacent tiles of one block row, so for every coefficient the 64 lanes write
 // 64 consecutive symbol bytes (encoder.cpp:320-323 layout).
 //
-// Channels are processed one after the other and the tile's pixels are re-read
-// for each (L1 hits after the first pass) instead of being held in registers:
-// that keeps the kernel under 128 VGPRs, i.e. 4 waves per SIMD instead of 1,
-// which is what hides the load/store latency of this kernel.
+// This is the generic kernel (ragged edges, 1-3 channels, pixel stride != 4);
+// full RGBA8 tiles take k_tile_fwd_pk below.  Channels are processed one after
+// the other and the tile's pixels are re-read for each instead of being held in
+// registers, which keeps the register count down.
 // ---------------------------------------------------------------------------
 enum { kChanRaw = 0, kChanY = 1, kChanCb = 2, kChanCr = 3 };
 
