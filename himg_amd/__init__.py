@@ -72,6 +72,7 @@ def lib():
     L.himg_hip_decode_to.argtypes = [vp, vp, sz, vp, sz, P(i32), P(i32), P(i32)]
     L.himg_hip_fetch_last.argtypes = [vp, vp, sz, P(sz)]
     L.himg_hip_peek.argtypes = [vp, sz, P(i32), P(i32), P(i32)]
+    L.himg_hip_set_option.argtypes = [vp, i32, i32]
     L.himg_hip_free.argtypes = [vp]
     L.himg_hip_free.restype = None
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
@@ -189,6 +190,11 @@ class Engine:
                                       C.byref(w), C.byref(h), C.byref(c))
         self._check(rc, "decode")
         return out.reshape(h.value, w.value, c.value)
+
+    def set_option(self, option, value):
+        """himg_hip_set_option; option names: "fix_t2" (see include/himg_hip.h)."""
+        opt = {"fix_t2": 1}[option] if isinstance(option, str) else int(option)
+        self._check(lib().himg_hip_set_option(self._ctx, opt, int(value)), "set_option")
 
     # device-resident API -------------------------------------------------------
     def encode_device(self, d_frames, batch, width, height, pixel_stride, channels, quality,

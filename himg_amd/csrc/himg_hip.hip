@@ -107,6 +107,7 @@ struct himg_hip_ctx {
   // same for every quality, mapper.cpp:213-223), 32769 entries.
   DevBuf fmap_lut;
   size_t host_bytes = 0;   // bytes of the last host-API result still resident in h_out
+  int fix_t2 = 0;          // HIMG_OPT_FIX_T2 (or HIMG_FIX_T2=1 in the environment)
 
   // Encoder workspace.
   DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist;
@@ -168,6 +169,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->ycbcr = (use_ycbcr && num_channels >= 3) ? 1 : 0;   // encoder.cpp:69
   g->lres_spans = (g->lres_size + kLresSpan - 1) / kLresSpan;
   g->use_blocks = g->rows > 1 ? 1 : 0;                   // block_size < in_size
+  g->fix_t2 = 0;
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
   return true;
@@ -195,6 +197,7 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   ctx->device = device;
   if (const char *e = std::getenv("HIMG_FORCE_UNFUSED")) ctx->allow_fused = !(e[0] == '1');
   if (const char *e = std::getenv("HIMG_SIDE_STREAM")) ctx->use_side = !(e[0] == '0');
+  if (const char *e = std::getenv("HIMG_FIX_T2")) ctx->fix_t2 = e[0] == '1';
   // Companding LUT for every magnitude an int16 can take.
   std::vector<uint8_t> lut(32769);
   int16_t fmap[128];
@@ -237,6 +240,12 @@ extern "C" const char *himg_hip_last_error(const himg_hip_ctx *ctx) {
 }
 
 extern "C" void himg_hip_free(void *p) { std::free(p); }
+
+extern "C" int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value) {
+  if (!ctx) return HIMG_ERR_ARG;
+  if (option == HIMG_OPT_FIX_T2) { ctx->fix_t2 = value ? 1 : 0; return HIMG_OK; }
+  return fail(ctx, HIMG_ERR_ARG, "unknown option");
+}
 
 // ---------------------------------------------------------------------------
 // Host-built tables and container bytes.
@@ -468,6 +477,7 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   Geom g;
   if (!make_geom(width, height, num_channels, num_channels, 1, &g))
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
   if (g.rows + 1 > 65535 || batch * g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if ((in_stride & 3) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
     return fail(ctx, HIMG_ERR_ARG, "in_stride must be a multiple of 4; buffers 16-byte aligned");
@@ -496,6 +506,7 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
   Geom g;
   if (!make_geom(width, height, num_channels, num_channels, 1, &g))
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
   if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
   if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))

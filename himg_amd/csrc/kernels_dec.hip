@@ -211,7 +211,8 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
       df->s[1].chunk_end = idx + sz;
       // Trap T2: the decoder derives use_blocks from the COMPRESSED size
       // (huffman_dec.cpp:215-219); UncompressBlock refuses when it is false (:265).
-      if (!((uint32_t)g.row_block < sz)) { s_chk[cFresFind] = fmt_err(7, 1); break; }
+      // (The opt-in fixed mode derives use_blocks like the encoder does: rows > 1.)
+      if (!g.fix_t2 && !((uint32_t)g.row_block < sz)) { s_chk[cFresFind] = fmt_err(7, 1); break; }
       s_off[4] = idx; s_sz[4] = sz;
     } while (0);
   }
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
     // A tree that is a single leaf decodes without consuming code bits in the
     // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
     // the encoder's 1-bit codes; such streams are rejected.
-    if (!st && df->s[0].num_nodes == 1) s_chk[cLeaf0] = fmt_err(4, 1);
+    // (Fixed mode: read them as the 1-bit codes the encoder writes, huffman_enc.cpp:231-237.)
+    if (!st && df->s[0].num_nodes == 1 && !g.fix_t2) s_chk[cLeaf0] = fmt_err(4, 1);
   }
   if (lane == 64 && s_off[4]) {        // FRES tree (decoder.cpp:290)
     uint32_t tb = 0;
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
       if (df->s[1].payload_off >= df->s[1].chunk_end) st = fmt_err(7, 1);
     }
     s_chk[cFresTree] = st;
-    if (!st && df->s[1].num_nodes == 1) s_chk[cLeaf1] = fmt_err(7, 1);
+    if (!st && df->s[1].num_nodes == 1 && !g.fix_t2) s_chk[cLeaf1] = fmt_err(7, 1);
   }
   if (lane == 128) {                   // mapping tables and QCFG
     if (s_off[0]) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
       uint32_t e = 0;
       // depth 0: a tree that is one leaf (rejected above, kept consistent anyway)
       uint32_t h = s_heap[1];
-      if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], 0) | ((h - 1) << 20);
+      if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], g.fix_t2 ? 1 : 0) | ((h - 1) << 20);
       for (int d = 1; d <= kLutBits && !e; ++d) {
         h = s_heap[(1u << d) | (idx & ((1u << d) - 1u))];
         if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], d) | ((h - 1) << 20);
@@ -457,6 +459,11 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
   uint32_t q = df->s[1].payload_off;
   const uint32_t end = df->s[1].chunk_end;
   uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
+  if (g.fix_t2 && g.rows == 1) {   // the encoder writes one block row without a size header
+    ro[0] = q;
+    rl[0] = end - q;
+    return;
+  }
   int r = 0;
   while (q != end) {
     if (q + 2 > end) { st = fmt_err(7, 1); break; }

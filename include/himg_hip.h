@@ -43,6 +43,20 @@ int himg_hip_create(int device, himg_hip_ctx **ctx);
 void himg_hip_destroy(himg_hip_ctx *ctx);
 const char *himg_hip_last_error(const himg_hip_ctx *ctx);
 
+/* Options (default 0 = behave exactly like the reference).
+ * HIMG_OPT_FIX_T2: the reference DECODER cannot read two kinds of streams its own
+ * encoder writes: (i) highly compressible ones -- it derives "the stream is split
+ * into blocks" from the COMPRESSED size (huffman_dec.cpp:215-219) while the
+ * encoder decides on the uncompressed size (huffman_enc.cpp:256), so flat or
+ * smooth frames are rejected (SURVEY.md trap T2), as is every frame of at most 8
+ * pixel rows; (ii) streams whose token alphabet is one symbol -- written with
+ * 1-bit codes (huffman_enc.cpp:231-237), read with 0 bits.  With the option set the
+ * decoder applies the encoder's rules and decodes them; streams the reference
+ * accepts decode identically either way.  Also enabled by HIMG_FIX_T2=1 in the
+ * environment (for callers that only see the C++ classes). */
+#define HIMG_OPT_FIX_T2 1
+int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value);
+
 /* Upper bound of the packed size of one frame (bytes), a multiple of 256.
  * Replaces HuffmanEnc::MaxCompressedSize (huffman_enc.cpp:242-244) plus the
  * container overhead of encoder.cpp:111-256. */

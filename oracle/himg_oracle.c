@@ -979,6 +979,7 @@ typedef struct {
   int lut_node[256], lut_symbol[256], lut_bits[256];
   bitr stream; /* positioned after the byte-aligned tree */
   int block_size, use_blocks;
+  int one_bit_leaf; /* fixed mode only: the tree is one leaf, read 1 bit per code */
   int num_blocks;
   const uint8_t **block_ptr;
   int *block_len;
@@ -1059,16 +1060,32 @@ static int at_the_end(const uint8_t *p, int bit, const uint8_t *end) {
   return (p == end && bit == 0) || (p == end - 1 && bit > 0);
 }
 
-/* huffman_dec.cpp:215-251 */
-static int hdec_init(hdec *d, const uint8_t *in, int in_size, int block_size) {
+/* Opt-in "fixed" mode used only to check the product's own compatibility switch
+ * (himg_hip_set_option HIMG_OPT_FIX_T2): derive use_blocks the way the ENCODER
+ * does (huffman_enc.cpp:256), from the uncompressed size.  Off by default: the
+ * oracle then is the reference, trap T2 included. */
+static int g_fix_t2 = 0;
+void himg_oracle_set_compat_fix(int on) { g_fix_t2 = on; }
+
+/* huffman_dec.cpp:215-251.  total_out: uncompressed size of the whole stream
+ * (only looked at in the fixed mode above). */
+static int hdec_init(hdec *d, const uint8_t *in, int in_size, int block_size, long total_out) {
   memset(d, 0, sizeof(*d));
   d->stream.p = in;
   d->stream.end = in + in_size;
   d->block_size = block_size > 0 ? block_size : in_size;
   d->use_blocks = d->block_size < in_size; /* trap T2: compares with the COMPRESSED size */
+  if (g_fix_t2 && block_size > 0) d->use_blocks = (long)block_size < total_out;
+  d->one_bit_leaf = 0;
   int count = 0;
   d->root = recover_tree(d, &count, 0, 0);
   if (d->root < 0) return 0;
+  if (g_fix_t2 && d->nodes[d->root].symbol >= 0) {
+    /* fixed mode: a one-symbol tree was WRITTEN with 1-bit codes
+     * (huffman_enc.cpp:231-237) although the reference reads it with 0 bits */
+    for (int e = 0; e < 256; ++e) d->lut_bits[e] = 1;
+    d->one_bit_leaf = 1;
+  }
   if (d->stream.bit) { /* AlignToByte */
     d->stream.bit = 0;
     ++d->stream.p;
@@ -1168,6 +1185,7 @@ static int uncompress_stream(const hdec *d, uint8_t *out, int out_size,
   bitr r = {p, send, bit, 0};
   while (buf < buf_end) {
     int node = d->root;
+    if (d->one_bit_leaf) { (void)read_bit_checked(&r); if (r.failed) return 0; }
     while (d->nodes[node].symbol < 0) {
       int b = read_bit_checked(&r);
       if (r.failed) return 0;
@@ -1245,6 +1263,9 @@ static int decode_block_row(rowjob *j, int y) {
   if (j->hd->root >= 0 && j->hd->use_blocks && v < j->hd->num_blocks)
     ok = uncompress_stream(j->hd, sym, row_size, j->hd->block_ptr[v],
                            j->hd->block_ptr[v] + j->hd->block_len[v], j->hard_end);
+  else if (g_fix_t2 && j->hd->root >= 0 && !j->hd->use_blocks && v == 0)
+    /* fixed mode, one block row: the encoder wrote the payload without a header */
+    ok = uncompress_stream(j->hd, sym, row_size, j->hd->stream.p, j->hd->stream.end, j->hard_end);
   if (ok) {
     for (int c = 0; c < C; ++c) {
       const uint8_t *m = j->low + (size_t)c * j->rows * cols;
@@ -1328,7 +1349,7 @@ static int decode_impl(const uint8_t *packed, int packed_size, int max_threads,
   uint8_t *lres = (uint8_t *)malloc((size_t)lres_size + 8);
   {
     hdec d;
-    int ok = hdec_init(&d, packed + r.idx, sz, 0);
+    int ok = hdec_init(&d, packed + r.idx, sz, 0, 0);
     /* Uncompress, huffman_dec.cpp:253-259 */
     if (ok) ok = d.root >= 0 && !d.use_blocks;
     if (ok)
@@ -1378,7 +1399,7 @@ static int decode_impl(const uint8_t *packed, int packed_size, int max_threads,
     return -7;
   }
   hdec d;
-  if (!hdec_init(&d, packed + r.idx, sz, cols * 64 * C)) {
+  if (!hdec_init(&d, packed + r.idx, sz, cols * 64 * C, (long)rows * cols * 64 * C)) {
     hdec_free(&d);
     free(lres); free(low);
     return -7;

@@ -61,6 +61,9 @@ int himg_oracle_decode_trace(const uint8_t *packed, int packed_size,
                              int *lres_sym_size, uint8_t **fres_sym,
                              int *fres_sym_size, uint8_t **lowres);
 
+/* Test knob for the product's opt-in fixed mode (trap T2); off = the reference. */
+void himg_oracle_set_compat_fix(int on);
+
 void himg_oracle_free(void *p);
 void himg_oracle_trace_free(himg_oracle_trace *t);
 

@@ -101,8 +101,18 @@ def oracle_encode(img, quality=50, use_ycbcr=True, channels=None, stride=None, t
     return packed, t
 
 
-def oracle_decode(packed, threads=1):
+def oracle_decode(packed, threads=1, fix_t2=False):
+    """fix_t2: the oracle's test knob for the product's opt-in fixed mode (trap T2);
+    the default is the reference's behaviour."""
     packed = np.ascontiguousarray(packed, np.uint8)
+    oracle().himg_oracle_set_compat_fix(1 if fix_t2 else 0)
+    try:
+        return _oracle_decode(packed, threads)
+    finally:
+        oracle().himg_oracle_set_compat_fix(0)
+
+
+def _oracle_decode(packed, threads):
     out = C.POINTER(C.c_uint8)()
     w, h, c = C.c_int(), C.c_int(), C.c_int()
     rc = oracle().himg_oracle_decode(packed.ctypes.data_as(C.c_void_p), packed.nbytes, threads,

@@ -120,3 +120,21 @@ def test_cli_round_trip_matches_the_oracle(tools, tmp_path, channels, flags):
     assert r.stdout.splitlines()[0] == "File size: %d" % len(want)
     back = _read_pnm(out_path)
     assert np.array_equal(_freeimage_order(back), pix.reshape(h, w, channels))
+
+
+@pytest.mark.gpu
+def test_dhimg_fixed_mode_through_the_environment(tools, tmp_path):
+    """HIMG_FIX_T2=1 switches the opt-in fixed mode on for callers that only see the
+    C++ classes: a flat picture, which the reference cannot decode (trap T2)."""
+    chimg, dhimg = tools
+    img = np.full((64, 96, 3), 90, np.uint8)
+    src, packed, out = str(tmp_path / "flat.ppm"), str(tmp_path / "flat.himg"), str(tmp_path / "out.ppm")
+    _write_pnm(src, img)
+    assert _run(chimg, src, packed).returncode == 0
+    r = _run(dhimg, packed, out)
+    assert r.returncode == 255 and r.stdout.splitlines()[-1] == "Unable to decode image."
+    r = subprocess.run([dhimg, packed, out], env=dict(os.environ, HIMG_FIX_T2="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout
+    back = _read_pnm(out)
+    assert back.shape == img.shape and np.abs(back.astype(int) - img.astype(int)).max() <= 2

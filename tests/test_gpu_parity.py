@@ -309,3 +309,33 @@ def test_bit_flips_in_the_payload_decode_like_the_reference(engine, unfused_engi
         accepted += rc == 0
         rejected += rc != 0
     assert accepted > 10 and rejected > 10   # the mutations exercise both outcomes
+
+
+def test_fixed_mode_decodes_what_the_reference_cannot(engine):
+    """HIMG_OPT_FIX_T2 (opt-in): streams of the reference's own encoder that its
+    decoder rejects -- compressible frames (trap T2), frames of one block row,
+    one-symbol token alphabets -- decode, bit-identical to the oracle with the same
+    rules switched on; everything else decodes exactly as before; the default stays
+    the reference's behaviour."""
+    cases = [("flat", np.full((64, 256, 4), 77, np.uint8)), ("flat-large", np.full((1024, 1024, 4), 200, np.uint8)),
+             ("grad", himg_amd.synth("grad", 0, 512, 512)), ("one block row", himg_amd.synth("randtile", 1, 256, 8)),
+             ("ordinary", himg_amd.synth("randtile", 1, 256, 64))]
+    fixed = himg_amd.Engine(0)
+    fixed.set_option("fix_t2", 1)
+    try:
+        for name, img in cases:
+            packed = ol.oracle_encode(img, 50, True)
+            rc_ref, pix_ref = ol.oracle_decode(packed)
+            rc_fix, pix_fix = ol.oracle_decode(packed, fix_t2=True)
+            assert rc_fix == 0, name
+            got = fixed.decode(packed)
+            _eq(got.ravel(), pix_fix.ravel(), "fixed-mode pixels of " + name)
+            assert himg_amd.psnr(img, got) > 30.0
+            if rc_ref == 0:
+                _eq(pix_ref.ravel(), pix_fix.ravel(), "fixed mode changes nothing for " + name)
+                _eq(engine.decode(packed).ravel(), pix_ref.ravel(), "default-mode pixels of " + name)
+            else:
+                with pytest.raises(himg_amd.HimgError):
+                    engine.decode(packed)
+    finally:
+        fixed.close()
