@@ -165,6 +165,20 @@ def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, 
     td = (time.perf_counter() - t) / 5
     out["host_api_incl_pcie_mpx_s"] = {"encode": round(W * H / te / 1e6, 1), "decode": round(W * H / td / 1e6, 1),
                                        "encode_decode": round(W * H / (te + td) / 1e6, 1)}
+    # Batched host API: 8 frames in flight (H2D / kernels / D2H overlapped).
+    nb = 8
+    eouts = [np.empty(cap, np.uint8) for _ in range(nb)]
+    pouts = [np.empty(W * H * 4, np.uint8) for _ in range(nb)]
+    streams = eng.encode_batch([frame0] * nb, Q, True, outs=eouts)
+    eng.decode_batch(streams, outs=pouts)
+    t = time.perf_counter()
+    streams = eng.encode_batch([frame0] * nb, Q, True, outs=eouts)
+    teb = (time.perf_counter() - t) / nb
+    t = time.perf_counter()
+    eng.decode_batch(streams, outs=pouts)
+    tdb = (time.perf_counter() - t) / nb
+    out["host_batch_api_incl_pcie_mpx_s"] = {"encode": round(W * H / teb / 1e6, 1), "decode": round(W * H / tdb / 1e6, 1),
+                                             "encode_decode": round(W * H / (teb + tdb) / 1e6, 1), "frames_in_flight": nb}
     return out
 
 

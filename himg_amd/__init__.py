@@ -73,6 +73,8 @@ def lib():
     L.himg_hip_fetch_last.argtypes = [vp, vp, sz, P(sz)]
     L.himg_hip_peek.argtypes = [vp, sz, P(i32), P(i32), P(i32)]
     L.himg_hip_set_option.argtypes = [vp, i32, i32]
+    L.himg_hip_encode_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_decode_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.himg_hip_free.argtypes = [vp]
     L.himg_hip_free.restype = None
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
@@ -190,6 +192,47 @@ class Engine:
                                       C.byref(w), C.byref(h), C.byref(c))
         self._check(rc, "decode")
         return out.reshape(h.value, w.value, c.value)
+
+    def encode_batch(self, frames, quality=50, use_ycbcr=True, outs=None):
+        """himg_hip_encode_batch: frames of one geometry, transfers overlapped with the
+        kernels.  `outs` (optional) are reusable uint8 buffers of at least
+        max_packed_size bytes; returns the streams (views into outs when given)."""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        n = len(frames)
+        h, w = frames[0].shape[:2]
+        ch = frames[0].shape[2] if frames[0].ndim == 3 else 1
+        cap = max_packed_size(w, h, ch)
+        if outs is None:
+            outs = [np.empty(cap, np.uint8) for _ in range(n)]
+        src = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+        sizes = (C.c_size_t * n)()
+        rc = lib().himg_hip_encode_batch(self._ctx, src, n, w, h, ch, ch, quality, 1 if use_ycbcr else 0,
+                                         dst, caps, sizes)
+        self._check(rc, "encode_batch")
+        return [o[: sizes[i]] for i, o in enumerate(outs)]
+
+    def decode_batch(self, streams, outs=None):
+        """himg_hip_decode_batch: returns the decoded frames; `outs` (optional) are
+        reusable uint8 buffers large enough for the pixels."""
+        streams = [np.ascontiguousarray(np.frombuffer(s, np.uint8) if isinstance(s, (bytes, bytearray)) else s)
+                   for s in streams]
+        n = len(streams)
+        if outs is None:
+            outs = []
+            for s_ in streams:
+                w, h, c = C.c_int(), C.c_int(), C.c_int()
+                ok = lib().himg_hip_peek(s_.ctypes.data, s_.nbytes, C.byref(w), C.byref(h), C.byref(c)) == HIMG_OK
+                outs.append(np.empty(w.value * h.value * c.value if ok else 1, np.uint8))
+        src = (C.c_void_p * n)(*[s_.ctypes.data for s_ in streams])
+        szs = (C.c_size_t * n)(*[s_.nbytes for s_ in streams])
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+        ws, hs, cs = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+        rc = lib().himg_hip_decode_batch(self._ctx, src, szs, n, dst, caps, ws, hs, cs)
+        self._check(rc, "decode_batch")
+        return [o.ravel()[: ws[i] * hs[i] * cs[i]].reshape(hs[i], ws[i], cs[i]) for i, o in enumerate(outs)]
 
     def set_option(self, option, value):
         """himg_hip_set_option; option names: "fix_t2" (see include/himg_hip.h)."""

@@ -108,6 +108,15 @@ struct himg_hip_ctx {
   DevBuf fmap_lut;
   size_t host_bytes = 0;   // bytes of the last host-API result still resident in h_out
   int fix_t2 = 0;          // HIMG_OPT_FIX_T2 (or HIMG_FIX_T2=1 in the environment)
+  // Batched host API: H2D of frame i+1, kernels of frame i and D2H of frame i-1 overlap
+  // on three streams; staging is double buffered.
+  struct Pipe {
+    bool ready = false;
+    hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    DevBuf in[2], out[2], meta[2];     // meta: u32 packed size, i32 status
+    uint32_t *h_meta = nullptr;        // pinned mirror of meta[2] (+ the decode sizes), 2 x 4 words
+  } pipe;
 
   // Encoder workspace.
   DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist;
@@ -227,6 +236,14 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->side) hipStreamDestroy(ctx->side);
   ctx->prof.collect();
+  if (ctx->pipe.ready) {
+    for (int k = 0; k < 2; ++k) {
+      hipEventDestroy(ctx->pipe.ev_in[k]); hipEventDestroy(ctx->pipe.ev_k[k]); hipEventDestroy(ctx->pipe.ev_out[k]);
+      ctx->pipe.in[k].release(); ctx->pipe.out[k].release(); ctx->pipe.meta[k].release();
+    }
+    hipStreamDestroy(ctx->pipe.s_in); hipStreamDestroy(ctx->pipe.s_comp); hipStreamDestroy(ctx->pipe.s_out);
+    hipHostFree(ctx->pipe.h_meta);
+  }
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
                    &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
@@ -696,6 +713,147 @@ extern "C" int himg_hip_decode_to(himg_hip_ctx *ctx, const uint8_t *packed, size
   if (!dst || dst_cap < ctx->host_bytes) return fail(ctx, HIMG_ERR_CAPACITY, "output buffer too small");
   HIP_TRY(ctx, hipMemcpy(dst, ctx->h_out.p, ctx->host_bytes, hipMemcpyDeviceToHost));
   return HIMG_OK;
+}
+
+// ---- batched host API: frames in flight ------------------------------------------
+
+static int pipe_init(himg_hip_ctx *ctx) {
+  himg_hip_ctx::Pipe &p = ctx->pipe;
+  if (p.ready) return HIMG_OK;
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&p.s_comp, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_in[k], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_k[k], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&p.ev_out[k], hipEventDisableTiming));
+    if (!p.meta[k].reserve(256)) return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+  }
+  HIP_TRY(ctx, hipHostMalloc((void **)&p.h_meta, 64, hipHostMallocDefault));
+  p.ready = true;
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_encode_batch(himg_hip_ctx *ctx, const uint8_t *const *frames, int n, int width,
+                                     int height, int pixel_stride, int num_channels, int quality,
+                                     int use_ycbcr, uint8_t *const *dst, const size_t *dst_cap,
+                                     size_t *out_sizes) {
+  if (!ctx || !frames || !dst || !dst_cap || !out_sizes || n < 0) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, pixel_stride, num_channels, use_ycbcr, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = pipe_init(ctx);
+  if (rc) return rc;
+  himg_hip_ctx::Pipe &p = ctx->pipe;
+  const size_t cap = himg_hip_max_packed_size(width, height, num_channels);
+  for (int k = 0; k < 2; ++k)
+    if (!p.in[k].reserve(round_up((size_t)g.frame_bytes, 256)) || !p.out[k].reserve(cap))
+      return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+  ctx->host_bytes = 0;
+  int first_err = HIMG_OK;
+  // Fetch frame j's verdict and start the copy of its stream.
+  auto finish = [&](int j) -> int {
+    const int slot = j & 1;
+    out_sizes[j] = 0;
+    HIP_TRY(ctx, hipEventSynchronize(p.ev_k[slot]));
+    const uint32_t nbytes = p.h_meta[slot * 4 + 0];
+    const int32_t st = (int32_t)p.h_meta[slot * 4 + 1];
+    int err = HIMG_OK;
+    if (st) err = fail(ctx, status_to_code(st), "device encode reported an error");
+    else if (!dst[j] || dst_cap[j] < nbytes) err = fail(ctx, HIMG_ERR_CAPACITY, "output buffer too small");
+    if (!err) {
+      HIP_TRY(ctx, hipMemcpyAsync(dst[j], p.out[slot].p, nbytes, hipMemcpyDeviceToHost, p.s_out));
+      out_sizes[j] = nbytes;
+    } else if (!first_err) {
+      first_err = err;
+    }
+    HIP_TRY(ctx, hipEventRecord(p.ev_out[slot], p.s_out));
+    return HIMG_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const int slot = i & 1;
+    if (!frames[i]) return fail(ctx, HIMG_ERR_ARG, "null frame");
+    if (i >= 2) HIP_TRY(ctx, hipEventSynchronize(p.ev_out[slot]));   // staging of frame i-2 is free again
+    HIP_TRY(ctx, hipMemcpyAsync(p.in[slot].p, frames[i], (size_t)g.frame_bytes, hipMemcpyHostToDevice, p.s_in));
+    HIP_TRY(ctx, hipEventRecord(p.ev_in[slot], p.s_in));
+    HIP_TRY(ctx, hipStreamWaitEvent(p.s_comp, p.ev_in[slot], 0));
+    rc = himg_hip_encode_device(ctx, p.in[slot].p, 1, width, height, pixel_stride, num_channels, quality,
+                                use_ycbcr, p.out[slot].p, cap, (uint32_t *)p.meta[slot].p,
+                                (int32_t *)p.meta[slot].p + 1, p.s_comp);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(p.h_meta + slot * 4, p.meta[slot].p, 8, hipMemcpyDeviceToHost, p.s_comp));
+    HIP_TRY(ctx, hipEventRecord(p.ev_k[slot], p.s_comp));
+    if (i >= 1 && (rc = finish(i - 1))) return rc;
+  }
+  if (n >= 1 && (rc = finish(n - 1))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(p.s_out));
+  return first_err;
+}
+
+extern "C" int himg_hip_decode_batch(himg_hip_ctx *ctx, const uint8_t *const *packed,
+                                     const size_t *packed_sizes, int n, uint8_t *const *dst,
+                                     const size_t *dst_cap, int *widths, int *heights, int *channels) {
+  if (!ctx || !packed || !packed_sizes || !dst || !dst_cap || !widths || !heights || !channels || n < 0)
+    return HIMG_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = pipe_init(ctx);
+  if (rc) return rc;
+  himg_hip_ctx::Pipe &p = ctx->pipe;
+  ctx->host_bytes = 0;
+  int first_err = HIMG_OK;
+  std::vector<size_t> out_bytes((size_t)n, 0);
+  std::vector<int> launched((size_t)n, 0);
+  auto finish = [&](int j) -> int {
+    const int slot = j & 1;
+    if (launched[j]) {
+      HIP_TRY(ctx, hipEventSynchronize(p.ev_k[slot]));
+      const int32_t st = (int32_t)p.h_meta[slot * 4 + 1];
+      int err = HIMG_OK;
+      if (st) {
+        err = status_to_code(st);
+        if (err == HIMG_ERR_FORMAT) ctx->err = format_message(st);
+        else fail(ctx, err, "device decode reported an error");
+      } else if (!dst[j] || dst_cap[j] < out_bytes[j]) {
+        err = fail(ctx, HIMG_ERR_CAPACITY, "output buffer too small");
+      }
+      if (!err) HIP_TRY(ctx, hipMemcpyAsync(dst[j], p.out[slot].p, out_bytes[j], hipMemcpyDeviceToHost, p.s_out));
+      else { widths[j] = heights[j] = channels[j] = 0; if (!first_err) first_err = err; }
+    }
+    HIP_TRY(ctx, hipEventRecord(p.ev_out[slot], p.s_out));
+    return HIMG_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const int slot = i & 1;
+    widths[i] = heights[i] = channels[i] = 0;
+    if (i >= 2) HIP_TRY(ctx, hipEventSynchronize(p.ev_out[slot]));
+    int W = 0, H = 0, C = 0;
+    Geom g;
+    const char *msg = packed[i] ? parse_header(packed[i], packed_sizes[i], &W, &H, &C) : "Not a RIFF HIMG file.\n";
+    if (msg || !make_geom(W, H, C, C, 1, &g)) {
+      if (!first_err) first_err = msg ? fail(ctx, HIMG_ERR_FORMAT, msg) : fail(ctx, HIMG_ERR_UNSUPPORTED, "unsupported geometry");
+    } else {
+      const size_t in_cap = round_up(packed_sizes[i] + 16, 256);
+      out_bytes[i] = (size_t)W * H * C;
+      if (!p.in[slot].reserve(in_cap) || !p.out[slot].reserve(round_up(out_bytes[i], 256)))
+        return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
+      HIP_TRY(ctx, hipMemcpyAsync(p.in[slot].p, packed[i], packed_sizes[i], hipMemcpyHostToDevice, p.s_in));
+      HIP_TRY(ctx, hipEventRecord(p.ev_in[slot], p.s_in));
+      HIP_TRY(ctx, hipStreamWaitEvent(p.s_comp, p.ev_in[slot], 0));
+      p.h_meta[8 + slot] = (uint32_t)packed_sizes[i];   // pinned: stays valid until the copy has run
+      rc = himg_hip_decode_device(ctx, p.in[slot].p, in_cap, p.h_meta + 8 + slot, 1, W, H, C, p.out[slot].p,
+                                  (int32_t *)p.meta[slot].p + 1, p.s_comp);
+      if (rc) return rc;
+      HIP_TRY(ctx, hipMemcpyAsync(p.h_meta + slot * 4, p.meta[slot].p, 8, hipMemcpyDeviceToHost, p.s_comp));
+      HIP_TRY(ctx, hipEventRecord(p.ev_k[slot], p.s_comp));
+      widths[i] = W; heights[i] = H; channels[i] = C;
+      launched[i] = 1;
+    }
+    if (i >= 1 && (rc = finish(i - 1))) return rc;
+  }
+  if (n >= 1 && (rc = finish(n - 1))) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(p.s_out));
+  return first_err;
 }
 
 // ---------------------------------------------------------------------------

@@ -98,6 +98,24 @@ int himg_hip_fetch_last(himg_hip_ctx *ctx, uint8_t *dst, size_t dst_cap, size_t 
 int himg_hip_peek(const uint8_t *packed, size_t packed_size, int *width, int *height,
                   int *num_channels);
 
+/* ---- batched host API: frames in flight -------------------------------------- */
+/* n frames from / to host memory with the transfers hidden behind the kernels:
+ * H2D of frame i+1, the kernels of frame i and D2H of frame i-1 run on three
+ * streams over double-buffered staging (reference protocol to mirror:
+ * benchmark.cpp:111-149, one picture after the other).  Same per-frame semantics
+ * as himg_hip_encode_to / himg_hip_decode_to.  A frame that fails (or whose dst is
+ * too small) gets out_sizes[i] = 0 / widths[i] = 0 and does not stop the others;
+ * the return value is the first such error, HIMG_OK if there was none.
+ * All frames of one encode call share the geometry; decode takes it per frame
+ * from the FRMT chunk. */
+int himg_hip_encode_batch(himg_hip_ctx *ctx, const uint8_t *const *frames, int n, int width,
+                          int height, int pixel_stride, int num_channels, int quality,
+                          int use_ycbcr, uint8_t *const *dst, const size_t *dst_cap,
+                          size_t *out_sizes);
+int himg_hip_decode_batch(himg_hip_ctx *ctx, const uint8_t *const *packed, const size_t *packed_sizes,
+                          int n, uint8_t *const *dst, const size_t *dst_cap, int *widths,
+                          int *heights, int *channels);
+
 /* ---- device-resident batched API (roofline measurements, pipelines) ----- */
 
 /* Encode `batch` frames that already live in HBM.

@@ -339,3 +339,40 @@ def test_fixed_mode_decodes_what_the_reference_cannot(engine):
                     engine.decode(packed)
     finally:
         fixed.close()
+
+
+def test_batched_host_api_frames_in_flight(engine):
+    """himg_hip_encode_batch / himg_hip_decode_batch: the pipelined host path gives
+    the same bytes and pixels as frame-by-frame calls; a bad stream in the middle
+    fails alone (mixed geometries in one decode call)."""
+    frames = [himg_amd.synth("randtile", s, 640, 360) for s in range(5)]
+    want = [ol.oracle_encode(f, 50, True) for f in frames]
+    got = engine.encode_batch(frames, 50, True)
+    assert len(got) == 5
+    for g_, w_ in zip(got, want):
+        _eq(g_, w_, "stream")
+    # decode: different geometries, one T2 stream (rejected), outputs reused
+    small = ol.oracle_encode(himg_amd.synth("gradn", 1, 128, 72), 90, True)
+    t2 = ol.oracle_encode(himg_amd.synth("grad", 0, 512, 512), 50, True)
+    assert ol.oracle_decode(t2)[0] != 0
+    streams = [want[0], small, want[1]]
+    pix = engine.decode_batch(streams)
+    for p_, s_ in zip(pix, streams):
+        _eq(p_.ravel(), ol.oracle_decode(s_)[1].ravel(), "pixels")
+    import ctypes as C
+    L = himg_amd.lib()
+    streams = [want[0], t2, want[2], small]
+    n = len(streams)
+    outs = [np.zeros(640 * 360 * 4, np.uint8) for _ in range(n)]
+    src = (C.c_void_p * n)(*[s_.ctypes.data for s_ in streams])
+    szs = (C.c_size_t * n)(*[s_.nbytes for s_ in streams])
+    dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+    ws, hs, cs = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+    rc = L.himg_hip_decode_batch(engine._ctx, src, szs, n, dst, caps, ws, hs, cs)
+    assert rc == himg_amd.HIMG_ERR_FORMAT            # the first (only) failure
+    assert (ws[1], hs[1], cs[1]) == (0, 0, 0)       # the T2 stream
+    for i in (0, 2, 3):
+        ref = ol.oracle_decode(streams[i])[1]
+        assert (hs[i], ws[i], cs[i]) == ref.shape
+        _eq(outs[i][: ref.size], ref.ravel(), "pixels of frame %d" % i)
