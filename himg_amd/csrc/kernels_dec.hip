@@ -513,6 +513,7 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
 // first token alone otherwise.
 // ---------------------------------------------------------------------------
 constexpr int kWinBytes = 32768;  // output window in LDS (streams that go to HBM)
+constexpr uint32_t kMinSubBits = 128;  // shortest sub-sequence a lane decodes (short rows: more lanes busy)
 
 struct GrpTables {
   const uint2 *grp;           // LDS, 1 << kLutBits entries
@@ -863,7 +864,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
     const unsigned long long rem = P1 - cur;
     uint32_t sub = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
     sub = (sub + 31u) & ~31u;
-    sub = sub < 256u ? 256u : (sub > 4096u ? 4096u : sub);
+    sub = sub < kMinSubBits ? kMinSubBits : (sub > 4096u ? 4096u : sub);
     const unsigned long long chunk_bits = (unsigned long long)sub * kDecThreads;
     const uint32_t rel_end = rel0 + (uint32_t)(rem < chunk_bits ? rem : chunk_bits);
     const uint32_t my_b0 = rel0 + (uint32_t)tid * sub;
@@ -1467,14 +1468,37 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       // scan index through kInvScanD), dequantise (quantize.cpp:153-165, int16
       // wrap), butterfly, and keep the int16 results packed two per register.
       uint32_t P[32];
+      // With a run-time column count the 64 slot offsets are not immediates: the
+      // generic variant walks the slots in scan order with ONE running pointer and
+      // collects the dequantised coefficients (packed int16) first -- 64 separate
+      // offsets would live in SGPRs, spill into VGPR lanes and from there to scratch.
+      uint32_t D[32];
+      if (!COLS) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) D[k] = 0;
+        const uint8_t *q = slot;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          const int pos = kScanD[i];
+          const int code = *q;
+          q += cols;
+          if ((i & 7) == 7) asm volatile("" : "+v"(q));   // keep it a running pointer
+          const uint32_t val = (uint32_t)(uint16_t)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
+          D[pos >> 1] |= val << ((pos & 1) * 16);
+        }
+      }
 #pragma unroll
       for (int y = 0; y < 8; ++y) {
         int r[8];
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
           const int pos = y * 8 + x;
-          const int code = slot[(size_t)kInvScanD[pos] * cols];
-          r[x] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
+          if (COLS) {
+            const int code = slot[(size_t)kInvScanD[pos] * cols];
+            r[x] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
+          } else {
+            r[x] = (int)(int16_t)(D[pos >> 1] >> ((pos & 1) * 16));
+          }
         }
         iwht8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
 #pragma unroll
@@ -1500,6 +1524,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       }
       // Column pass, one column at a time; results go straight back to the tile's
       // own slots (buf0[i] += lowres[i] in int16, ClampTo8Bit: decoder.cpp:401-413).
+      // Generic variant: running pointers again, from a copy of the base the compiler
+      // cannot see through -- otherwise it keeps the gather's 64 addresses alive for
+      // these stores (common subexpressions) and spills them.
+      uint8_t *qcol = slot;
+      if (!COLS) asm volatile("" : "+v"(qcol));
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
         int cv[8];
@@ -1507,11 +1536,16 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
         for (int y = 0; y < 8; ++y)
           cv[y] = (int)(int16_t)(P[y * 4 + x / 2] >> ((x & 1) * 16));
         iwht8(cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7]);
+        uint8_t *qy = qcol;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
           const int lo = (int)((L[2 * y + x / 4] >> ((x & 3) * 8)) & 255u);
-          slot[(size_t)(y * 8 + x) * cols] = (uint8_t)clamp255d((int)(int16_t)(cv[y] + lo));
+          const uint8_t px = (uint8_t)clamp255d((int)(int16_t)(cv[y] + lo));
+          if (COLS) slot[(size_t)(y * 8 + x) * cols] = px;
+          else { *qy = px; qy += 8 * cols; }
         }
+        qcol += cols;
+        if (!COLS) asm volatile("" : "+v"(qcol));
       }
     }
   }
@@ -1590,7 +1624,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, con
   const unsigned long long rem = 8ull * pay_len;
   uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
   sb = (sb + 31u) & ~31u;
-  sb = sb < 256u ? 256u : sb;
+  sb = sb < kMinSubBits ? kMinSubBits : sb;
   if (sb > 4096u || rem == 0) return;          // more than one chunk: the fused kernel does it all
   load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
   __syncthreads();
