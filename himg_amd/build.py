@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libhimg_hip.so")
 HIP_SOURCES = ["kernels_enc.hip", "kernels_dec.hip", "himg_hip.hip"]
 CXX_SOURCES = ["encoder.cpp", "decoder.cpp"]
 C_SOURCES = ["himg_tables.c", "himg_synth.c"]
-HEADERS = ["himg_dev.h", "himg_tables.h", "../../include/himg_hip.h",
+HEADERS = ["himg_dev.h", "himg_tables.h", "ctx_pool.h", "../../include/himg_hip.h",
            "../../include/encoder.h", "../../include/decoder.h"]
 
 
@@ -72,11 +72,11 @@ BINDIR = os.path.join(ROOT, "himg_amd", "bin")
 
 
 def build_cli(verbose=False):
-    """chimg / dhimg (reference-style command line tools) against the in-tree library."""
+    """chimg / dhimg / benchmark (the reference's three callers) against the in-tree library."""
     lib = build_lib(verbose=verbose)
     os.makedirs(BINDIR, exist_ok=True)
     out = []
-    for name in ("chimg", "dhimg"):
+    for name in ("chimg", "dhimg", "benchmark"):
         src = os.path.join(CLIDIR, name + ".cpp")
         exe = os.path.join(BINDIR, name)
         if _stale(exe, [src, os.path.join(CLIDIR, "pnm_io.h"), lib]):

@@ -3,6 +3,7 @@
 
 #include <iostream>
 
+#include "ctx_pool.h"
 #include "himg_hip.h"
 
 namespace himg {
@@ -12,12 +13,13 @@ Decoder::Decoder(int max_threads)
       m_height(0), m_num_channels(0) {}
 
 Decoder::~Decoder() {
-  if (m_ctx) himg_hip_destroy(m_ctx);
+  detail::release_ctx(m_ctx);
 }
 
 bool Decoder::Decode(const uint8_t *packed_data, int packed_size) {
   m_unpacked_size = 0;
-  if (!m_ctx && himg_hip_create(0, &m_ctx) != HIMG_OK) {
+  if (!m_ctx) m_ctx = detail::acquire_ctx();
+  if (!m_ctx) {
     std::cout << "Error: no usable MI355X device (the HIMG engine has no CPU fallback).\n";
     return false;
   }

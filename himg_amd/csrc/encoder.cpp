@@ -4,6 +4,7 @@
 #include <cstring>
 #include <iostream>
 
+#include "ctx_pool.h"
 #include "himg_hip.h"
 
 namespace himg {
@@ -26,14 +27,15 @@ long ChunkSize(const uint8_t *s, size_t size, const char tag[4]) {
 Encoder::Encoder() : m_ctx(nullptr), m_packed_size(0) {}
 
 Encoder::~Encoder() {
-  if (m_ctx) himg_hip_destroy(m_ctx);
+  detail::release_ctx(m_ctx);
 }
 
 bool Encoder::Encode(const uint8_t *data, int width, int height, int pixel_stride,
                      int num_channels, int quality, bool use_ycbcr) {
   m_packed_data.reset();
   m_packed_size = 0;
-  if (!m_ctx && himg_hip_create(0, &m_ctx) != HIMG_OK) {
+  if (!m_ctx) m_ctx = detail::acquire_ctx();
+  if (!m_ctx) {
     std::cout << "Error: no usable MI355X device (the HIMG engine has no CPU fallback).\n";
     return false;
   }

@@ -15,7 +15,7 @@ import oracle_lib as ol
 
 @pytest.fixture(scope="module")
 def tools():
-    chimg, dhimg = hb.build_cli()
+    chimg, dhimg = hb.build_cli()[:2]
     return chimg, dhimg
 
 
@@ -138,3 +138,41 @@ def test_dhimg_fixed_mode_through_the_environment(tools, tmp_path):
     assert r.returncode == 0, r.stdout
     back = _read_pnm(out)
     assert back.shape == img.shape and np.abs(back.astype(int) - img.astype(int)).max() <= 2
+
+
+def _benchmark():
+    return hb.build_cli()[2]
+
+
+def test_benchmark_usage():
+    exe = _benchmark()
+    r = _run(exe)
+    assert r.returncode == 0 and r.stdout == "Usage: %s [-d][-e] image\n  -d Decode (default)\n  -e Encode\n" % exe
+    r = _run(exe, "a", "b")
+    assert r.returncode == 0 and r.stdout.startswith("Usage: ")
+
+
+@pytest.mark.gpu
+def test_benchmark_decode_and_encode(tools, tmp_path):
+    """The reference's timing protocol (benchmark.cpp:108-156): one Decoder, 30
+    decodes, iteration lines, then Min / Max / Average."""
+    chimg, _ = tools
+    exe = _benchmark()
+    img = himg_amd.synth("randtile", 2, 512, 256)[:, :, :3]
+    src, packed = str(tmp_path / "in.ppm"), str(tmp_path / "in.himg")
+    _write_pnm(src, img)
+    assert _run(chimg, "-q", "80", src, packed).returncode == 0
+    for args in ([packed], ["-d", packed], ["-e", src]):
+        r = _run(exe, *args)
+        lines = r.stdout.splitlines()
+        assert r.returncode == 0, r.stdout
+        assert lines[0].startswith("File size: ")
+        assert lines[1:31] == ["Iteration %d/30" % i for i in range(1, 31)]
+        assert lines[31].startswith("    Min: ") and lines[32].startswith("    Max: ") and lines[33].startswith("Average: ")
+        assert float(lines[33].split()[1]) > 0
+    # a stream the reference cannot decode (flat picture, trap T2)
+    flat = str(tmp_path / "flat.ppm")
+    _write_pnm(flat, np.full((64, 64, 3), 9, np.uint8))
+    assert _run(chimg, flat, packed).returncode == 0
+    r = _run(exe, packed)
+    assert r.returncode == 255 and r.stdout.splitlines()[-1] == "Unable to decode image."
