@@ -415,28 +415,35 @@ __device__ __forceinline__ pk16 pair_value(uint32_t px) {
 }
 
 template <bool YCBCR, int PAIR>
-__device__ __forceinline__ void residual_pair(const uint4 px[16], const int lA[9], const int rA[9],
-                                              const int lB[9], const int rB[9], pk16 b[64]) {
+__device__ __forceinline__ void residual_pair(const uint8_t *row0, size_t pitch, const int lA[9],
+                                              const int rA[9], const int lB[9], const int rB[9],
+                                              pk16 b[64]) {
+  // The pixel rows are loaded just in time, two rows ahead at most (the scheduling
+  // barrier keeps the compiler from hoisting all 16 loads to the top): the tile's
+  // 64 pixels never sit in registers at once, which is what decides between two
+  // and three waves per SIMD for this kernel.
 #pragma unroll
   for (int y = 0; y < 8; ++y) {
+    const uint4 *rp = reinterpret_cast<const uint4 *>(row0 + (size_t)y * pitch);
+    const uint4 q0 = rp[0], q1 = rp[1];
     int aA[9], aB[9];
     aA[0] = lA[y]; aA[8] = rA[y];
     aB[0] = lB[y]; aB[8] = rB[y];
     interp9(aA);
     interp9(aB);
-    const uint32_t q[8] = {px[2 * y].x, px[2 * y].y, px[2 * y].z, px[2 * y].w,
-                           px[2 * y + 1].x, px[2 * y + 1].y, px[2 * y + 1].z, px[2 * y + 1].w};
+    const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       pk16 lo;
       lo.x = (short)aA[x]; lo.y = (short)aB[x];
       b[y * 8 + x] = pair_value<YCBCR, PAIR>(q[x]) - lo;
     }
+    if (y & 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 template <bool YCBCR, int COLS>
-__global__ __launch_bounds__(kTileThreads) void k_tile_fwd_pk(Geom g, const uint8_t *frames,
+__global__ __launch_bounds__(kTileThreads, 3) void k_tile_fwd_pk(Geom g, const uint8_t *frames,
                                                      const uint8_t *low, size_t plane_stride,
                                                      uint8_t *fres_sym, size_t fres_stride,
                                                      const uint8_t *__restrict__ fmap_lut,
@@ -453,15 +460,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_fwd_pk(Geom g, const uint
 
 #pragma unroll 1
   for (int pr = 0; pr < 2; ++pr) {
-    // The tile's pixels: read for each PAIR of channels (the second read hits L2),
-    // so that they are not live during the transform and the quantiser.
-    uint4 px[16];
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      const uint4 *rp = reinterpret_cast<const uint4 *>(row0 + (size_t)y * pitch);
-      px[2 * y] = rp[0];
-      px[2 * y + 1] = rp[1];
-    }
     // Bilinear low-res blocks of both channels from their four corners
     // (downsampled.cpp:116-169).
     const uint8_t *mA = low + (size_t)f * plane_stride + (size_t)(2 * pr) * g.rows * g.cols;
@@ -474,8 +472,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_fwd_pk(Geom g, const uint
     interp9(lA); interp9(rA); interp9(lB); interp9(rB);
 
     pk16 b[64];
-    if (pr == 0) residual_pair<YCBCR, 0>(px, lA, rA, lB, rB, b);
-    else residual_pair<YCBCR, 1>(px, lA, rA, lB, rB, b);
+    if (pr == 0) residual_pair<YCBCR, 0>(row0, pitch, lA, rA, lB, rB, b);
+    else residual_pair<YCBCR, 1>(row0, pitch, lA, rA, lB, rB, b);
 
     // Forward 2-D WHT: rows, then columns (hadamard.cpp:78-88).
 #pragma unroll
