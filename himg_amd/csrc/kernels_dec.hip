@@ -844,7 +844,7 @@ template <bool FUSED>
 __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
-                             uint32_t *stats, const uint32_t *pre_start = nullptr,
+                             uint32_t *stats, uint32_t max_sub, const uint32_t *pre_start = nullptr,
                              const uint32_t *pre_off = nullptr) {
   const int tid = threadIdx.x;
   if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
@@ -864,7 +864,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
     const unsigned long long rem = P1 - cur;
     uint32_t sub = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
     sub = (sub + 31u) & ~31u;
-    sub = sub < kMinSubBits ? kMinSubBits : (sub > 4096u ? 4096u : sub);
+    sub = sub < kMinSubBits ? kMinSubBits : (sub > max_sub ? max_sub : sub);
     const unsigned long long chunk_bits = (unsigned long long)sub * kDecThreads;
     const uint32_t rel_end = rel0 + (uint32_t)(rem < chunk_bits ? rem : chunk_bits);
     const uint32_t my_b0 = rel0 + (uint32_t)tid * sub;
@@ -991,7 +991,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   GrpTables tb;
   tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
-                                       out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8);
+                                       out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8,
+                                       (uint32_t)g.max_sub);
   if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
 }
 
@@ -1442,7 +1443,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const int bad = decode_stream<true>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
       (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
-      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8,
+      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub,
       ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
       ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
   if (bad) {
@@ -1625,7 +1626,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, con
   uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
   sb = (sb + 31u) & ~31u;
   sb = sb < kMinSubBits ? kMinSubBits : sb;
-  if (sb > 4096u || rem == 0) return;          // more than one chunk: the fused kernel does it all
+  if (sb > (uint32_t)g.max_sub || rem == 0) return;   // more than one chunk: the fused kernel does it all
   load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
   __syncthreads();
   GrpTables tb;

@@ -376,3 +376,36 @@ def test_batched_host_api_frames_in_flight(engine):
         ref = ol.oracle_decode(streams[i])[1]
         assert (hs[i], ws[i], cs[i]) == ref.shape
         _eq(outs[i][: ref.size], ref.ravel(), "pixels of frame %d" % i)
+
+
+def test_streams_longer_than_one_chunk():
+    """A stream whose payload exceeds 1024 sub-sequences is decoded chunk after chunk
+    (each chunk's first token is exact once the previous chunk has finished).  With
+    sub-sequences of up to 4096 bits that takes a > 4 Mbit block row, so the test
+    lowers the cap (HIMG_MAX_SUB_BITS, a test knob) to 128 / 256 bits: ordinary
+    rows then need several chunks -- in the fused row kernel (k_row_count steps
+    aside), in the generic path, and in the serial LRES fallback."""
+    import os
+    img = himg_amd.synth("randtile", 6, 4096, 64)
+    img2 = himg_amd.synth("rand", 2, 1024, 128)
+    cases = [(img, 90), (img, 50), (img2, 50)]
+    for cap, unfused in ((128, False), (256, False), (256, True)):
+        os.environ["HIMG_MAX_SUB_BITS"] = str(cap)
+        if unfused:
+            os.environ["HIMG_FORCE_UNFUSED"] = "1"
+        try:
+            eng = himg_amd.Engine(0)
+        finally:
+            del os.environ["HIMG_MAX_SUB_BITS"]
+            os.environ.pop("HIMG_FORCE_UNFUSED", None)
+        try:
+            for im, q in cases:
+                packed = ol.oracle_encode(im, q, True)
+                rc, pix = ol.oracle_decode(packed)
+                assert rc == 0
+                _eq(eng.decode(packed).ravel(), pix.ravel(), "pixels (cap %d, unfused %s, q %d)" % (cap, unfused, q))
+                st = eng.debug_read("dec_stats", 0, ((im.shape[0] + 7) // 8 + 1) * 32, np.uint32, decoder=True)
+                if q == 90 or cap == 128:   # these certainly exceed 1024 sub-sequences per row
+                    assert st.reshape(-1, 8)[1:, 0].max() > 1, "no block row needed more than one chunk"
+        finally:
+            eng.close()
