@@ -30,6 +30,7 @@ struct Geom {
   int lres_spans;            // ceil(lres_size / kLresSpan)
   int use_blocks;            // FRES: block_size < in_size (huffman_enc.cpp:256)
   int fix_t2;                // decoder, opt-in: accept the encoder's own compressible streams (see himg_hip.h)
+  int lres_serial;           // decoder test knob: distrust the parallel LRES chain, take the serial fallback
   int max_sub;               // decoder: longest sub-sequence in bits (4096; tests lower it to force several chunks per stream)
   long long frame_bytes;     // W*H*stride
   long long fres_size;       // rows*row_block

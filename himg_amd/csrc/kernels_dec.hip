@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_verify(Geom g, DecWs ws) {
   const unsigned long long base = block_scan_u64(ntot, sm64, &tot);
   if (k < nact) ws.ver_base[slot] = base;
   __syncthreads();
-  if (k == 0) ws.ver_ok[f] = s_bad ? 0 : 1;
+  if (k == 0) ws.ver_ok[f] = (s_bad || g.lres_serial) ? 0 : 1;
 }
 
 __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, const uint8_t *packed,

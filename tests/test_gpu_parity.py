@@ -409,3 +409,41 @@ def test_streams_longer_than_one_chunk():
                     assert st.reshape(-1, 8)[1:, 0].max() > 1, "no block row needed more than one chunk"
         finally:
             eng.close()
+
+
+def test_lres_serial_fallback():
+    """If a mis-speculation runs through a whole LRES chunk the parallel chunk chain
+    does not verify and the frame's LRES stream is decoded by one workgroup instead
+    (k_dec_huff).  HIMG_FORCE_LRES_SERIAL=1 (a test knob) takes that path on purpose;
+    with HIMG_MAX_SUB_BITS=256 the serial stream also needs several chunks."""
+    import os
+    os.environ["HIMG_FORCE_LRES_SERIAL"] = "1"
+    os.environ["HIMG_MAX_SUB_BITS"] = "256"
+    try:
+        eng = himg_amd.Engine(0)
+    finally:
+        del os.environ["HIMG_FORCE_LRES_SERIAL"]
+        del os.environ["HIMG_MAX_SUB_BITS"]
+    try:
+        for kind, w, h, q in [("randtile", 2048, 1024, 50), ("gradn", 640, 360, 90), ("randtile", 64, 64, 100)]:
+            packed = ol.oracle_encode(himg_amd.synth(kind, 8, w, h), q, True)
+            rc, pix = ol.oracle_decode(packed)
+            assert rc == 0
+            _eq(eng.decode(packed).ravel(), pix.ravel(), "pixels %dx%d" % (w, h))
+            st = eng.debug_read("dec_stats", 0, ((h + 7) // 8 + 1) * 32, np.uint32, decoder=True).reshape(-1, 8)
+            # Row 0 of the statistics is the LRES stream; only the serial decode fills in
+            # the payload and output sizes (slots 6, 7).
+            assert st[0, 7] > 0 and st[0, 6] > 0, "the serial LRES path did not run"
+            if w == 2048:
+                assert st[0, 0] > 1, "the serial LRES decode did not need more than one chunk"
+        bad = ol.oracle_encode(himg_amd.synth("randtile", 8, 640, 360), 70, True)
+        lres = _chunks(bad)["LRES"]
+        bad[lres[0] + lres[1] // 2] ^= 0x10
+        rc, pix = ol.oracle_decode(bad)
+        if rc == 0:
+            _eq(eng.decode(bad).ravel(), pix.ravel(), "pixels of the mutated stream")
+        else:
+            with pytest.raises(himg_amd.HimgError):
+                eng.decode(bad)
+    finally:
+        eng.close()
