@@ -850,6 +850,8 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   __shared__ int cnt[2 * kNumSym];
+  __shared__ int s_cnt[kNumSym];          // leaves sorted by (count, -index)
+  __shared__ short s_idx[kNumSym];
   __shared__ short ca[2 * kNumSym], cb[2 * kNumSym], nsym[2 * kNumSym];
   __shared__ uint32_t bits[kTreeStride / 4];
   __shared__ short stk_node[kNumSym + 8];
@@ -879,33 +881,69 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   }
   __syncthreads();
 
-  int next = num;
-  for (int left = num; left > 1; --left) {
-    unsigned long long b1 = ~0ull, b2 = ~0ull;
-    for (int k = lane; k < next; k += 64) {
-      const int c = cnt[k];
-      if (c > 0) {
-        const unsigned long long key = ((unsigned long long)(uint32_t)c << 10) | (uint32_t)(1023 - k);
-        if (key < b1) { b2 = b1; b1 = key; }
-        else if (key < b2) { b2 = key; }
-      }
+  // Join the two lightest nodes until one is left (huffman_enc.cpp:199-227).  The
+  // reference's scan picks them under the total order (count ascending, node index
+  // DESCENDING).  Instead of searching all nodes every time (O(n^2)):
+  //   * the leaves are sorted once by that order (rank sort, all 64 lanes);
+  //   * internal nodes are created with non-decreasing counts, so among them the
+  //     lightest is the LAST node of the leading group of equal counts.  A group is
+  //     final once consumption from it starts (any later node weighs at least
+  //     twice as much), and a new node can only join the last group while that
+  //     group is still untouched -- so "current group [ib, ie)" plus "next group
+  //     starts at inext" describes the queue, consumed from ie - 1 downwards;
+  //   * ties between a leaf and an internal node go to the internal node (its
+  //     index is larger).
+  // One lane then merges in O(n).
+  for (int j = lane; j < num; j += 64) {
+    const int cj = cnt[j];
+    int rank = 0;
+    for (int i = 0; i < num; ++i) {
+      const int ci = cnt[i];
+      rank += (ci < cj || (ci == cj && i > j)) ? 1 : 0;
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const unsigned long long o1 = __shfl_xor(b1, d), o2 = __shfl_xor(b2, d);
-      if (o1 < b1) { b2 = (b1 < o2) ? b1 : o2; b1 = o1; }
-      else { b2 = (b2 < o1) ? b2 : o1; }
-    }
-    const int n1 = 1023 - (int)(b1 & 1023), n2 = 1023 - (int)(b2 & 1023);
-    __syncthreads();
-    if (lane == 0) {
-      ca[next] = (short)n1; cb[next] = (short)n2; nsym[next] = -1;
-      cnt[next] = cnt[n1] + cnt[n2];
-      cnt[n1] = 0; cnt[n2] = 0;
-    }
-    ++next;
-    __syncthreads();
+    s_cnt[rank] = cj;
+    s_idx[rank] = (short)j;
   }
+  __syncthreads();
+  int next = num;
+  if (lane == 0 && num > 1) {
+    int lh = 0;                          // head of the sorted leaves
+    int ib = num, ie = num, inext = num; // current internal group [ib, ie), next group from inext
+    int g = 0;                           // count of the current group
+    int lc = s_cnt[0], li = s_idx[0];    // the head leaf
+    for (int left = num; left > 1; --left) {
+      int pick[2], pc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (ib == ie && inext < next) {  // open the next group of equal counts
+          ib = inext;
+          g = cnt[ib];
+          int e = ib + 1;
+          while (e < next && cnt[e] == g) ++e;
+          ie = inext = e;
+        }
+        const bool have_int = ib < ie, have_leaf = lh < num;
+        if (have_int && (!have_leaf || g <= lc)) {
+          pick[t] = --ie;
+          pc[t] = g;
+        } else {
+          pick[t] = li;
+          pc[t] = lc;
+          ++lh;
+          if (lh < num) { lc = s_cnt[lh]; li = s_idx[lh]; }
+        }
+      }
+      const int c = pc[0] + pc[1];
+      ca[next] = (short)pick[0]; cb[next] = (short)pick[1]; nsym[next] = -1;
+      cnt[next] = c;
+      // The new node extends the current group iff that group is the last one,
+      // untouched, and of the same count.
+      if (ib < ie && ie == inext && inext == next && g == c) ie = inext = next + 1;
+      ++next;
+    }
+  }
+  __syncthreads();
+  next = num > 1 ? 2 * num - 1 : num;
 
   if (lane == 0) {
     int err = 0;
