@@ -767,6 +767,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
   __shared__ uint32_t hist2[kPairRuns][256];
   __shared__ uint32_t hrun[kRunTab + 1];   // runs of kPairRuns..278 zeros, by exact length
+  __shared__ uint32_t s_sym[8 * 256];      // [word][lane]: the lane's 32 symbols of this iteration
   __shared__ ZR sm[4];
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
@@ -777,26 +778,36 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   carry.tz = span_carry_in(g, ws, sp, f);
   carry.az = 0;
   __syncthreads();
-  for (int base = 0; base < s.len; base += kIterSyms) {
-    const int off = base + threadIdx.x * 16;
-    const int nvalid = max(0, min(16, s.len - off));
-    uint32_t w[4];
+  // 32 symbols per lane and iteration: the wave waits for its busiest lane, and
+  // with 32 symbols the busiest lane is 1.6x the mean instead of 1.9x with 16; the
+  // scans and the barrier are paid half as often per symbol.  The lane's symbols sit
+  // in LDS (transposed), where the walk fetches them by position.
+  for (int base = 0; base < s.len; base += 2 * kIterSyms) {
+    const int off = base + threadIdx.x * 32;
+    const int nvalid = max(0, min(32, s.len - off));
+    uint32_t w[8];
     load16(s.sym + off, s.len - off, w);
-    const uint32_t mask = nonzero_mask16(w, nvalid);
-    const ZR mine = summarize16(mask, nvalid);
+    load16(s.sym + off + 16, s.len - off - 16, w + 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s_sym[q * 256 + threadIdx.x] = w[q];
+    const uint32_t mask = nonzero_mask16(w, min(nvalid, 16)) | (nonzero_mask16(w + 4, max(nvalid - 16, 0)) << 16);
+    ZR mine;
+    mine.tz = mask ? nvalid - (32 - __clz(mask)) : nvalid;
+    mine.az = mask ? 0 : 1;
     ZR total;
     const ZR ex = block_scan_zr(mine, carry, sm, &total);
     carry = total;
     carry.az = 0;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
     auto one = [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); };
+    const uint8_t *mysym = reinterpret_cast<const uint8_t *>(s_sym) + threadIdx.x * 4;
     int prev = -1;
     uint32_t m = mask;
     while (m) {
       const int k = __ffs(m) - 1;
       m &= m - 1;
       const int run = k - prev - 1 + (prev < 0 ? ex.tz : 0);
-      const int sym = symbol_at(w, k);
+      const int sym = mysym[(k >> 2) * 1024 + (k & 3)];
       prev = k;
       if (__builtin_expect(run < kPairRuns, 1)) {
         atomicAdd(&hist2[run][sym], 1u);
