@@ -1,12 +1,13 @@
-// chimg -- compress an image to .himg on the MI355X engine.
+// chimg -- compress a picture to .himg on the MI355X engine.
 //
-// Same command line, messages and exit codes as the reference tool
-// (src/chimg.cpp:36-169): "chimg [-q N] [-rgb] image outfile", exit 0 on bad
-// arguments, -1 on I/O failure.  Input: binary PGM / PPM / PAM (see pnm_io.h).
+// Command line, messages and exit codes follow the reference tool
+// (src/chimg.cpp:36-169): "chimg [-q N] [-rgb] image outfile"; exit 0 after the
+// usage text, -1 when the input cannot be read or the output cannot be written.
+// Input: binary PGM / PPM / PAM (pnm_io.h) instead of the formats FreeImage reads.
+#include <cerrno>
+#include <cstdio>
 #include <cstdlib>
-#include <fstream>
-#include <iostream>
-#include <string>
+#include <cstring>
 #include <vector>
 
 #include "encoder.h"
@@ -14,70 +15,81 @@
 
 namespace {
 
-const int kDefaultQuality = 50;  // src/chimg.cpp:20
+struct Request {
+  int quality = 50;        // the reference's default (src/chimg.cpp:22)
+  bool ycbcr = true;
+  const char *input = nullptr;
+  const char *output = nullptr;
+};
 
-bool to_int(const char *arg, int *value) {
-  char *end = nullptr;
-  const long v = strtol(arg, &end, 10);
-  if (end != arg && *end == '\0') { *value = (int)v; return true; }
-  std::cout << "Invalid integer expression: " << arg << "\n";
-  return false;
+// Returns false (after the reference's message, if any) when the usage text is due.
+bool parse(int argc, const char **argv, Request *rq) {
+  int nfiles = 0;
+  for (int i = 1; i < argc; ++i) {
+    const char *a = argv[i];
+    if (a[0] != '-') {
+      if (nfiles == 0) rq->input = a;
+      else if (nfiles == 1) rq->output = a;
+      ++nfiles;
+    } else if (!strcmp(a, "-rgb")) {
+      rq->ycbcr = false;
+    } else if (!strcmp(a, "-q")) {
+      if (++i >= argc) return false;
+      char *end = nullptr;
+      const long v = strtol(argv[i], &end, 10);
+      if (end == argv[i] || *end) {
+        printf("Invalid integer expression: %s\n", argv[i]);
+        return false;
+      }
+      rq->quality = static_cast<int>(v);
+      if (v < 0 || v > 100) {
+        printf("Invalid quality level: %d\n", rq->quality);
+        return false;
+      }
+    } else {
+      printf("Invalid option: %s\n", a);
+      return false;
+    }
+  }
+  return nfiles == 2;
 }
 
 }  // namespace
 
 int main(int argc, const char **argv) {
-  int quality = kDefaultQuality;
-  bool use_ycbcr = true, ok = true;
-  std::vector<const char *> files;
-  for (int k = 1; k < argc && ok; ++k) {
-    const std::string arg = argv[k];
-    if (!arg.empty() && arg[0] == '-') {
-      if (arg == "-q") {
-        if (k + 1 < argc && to_int(argv[++k], &quality)) {
-          if (quality < 0 || quality > 100) {
-            std::cout << "Invalid quality level: " << quality << "\n";
-            ok = false;
-          }
-        } else {
-          ok = false;
-        }
-      } else if (arg == "-rgb") {
-        use_ycbcr = false;
-      } else {
-        std::cout << "Invalid option: " << arg << "\n";
-        ok = false;
-      }
-    } else {
-      files.push_back(argv[k]);
-    }
-  }
-  if (!ok || files.size() != 2) {
-    std::cout << "Usage: " << argv[0] << " [options] image outfile\n";
-    std::cout << "Options:\n";
-    std::cout << " -q <quality> Set the quality (0-100)\n";
-    std::cout << " -rgb         Use RGB color space (instead of YCbCr)\n";
+  Request rq;
+  if (!parse(argc, argv, &rq)) {
+    printf("Usage: %s [options] image outfile\n"
+           "Options:\n"
+           " -q <quality> Set the quality (0-100)\n"
+           " -rgb         Use RGB color space (instead of YCbCr)\n",
+           argv[0]);
     return 0;
   }
 
-  pnm::Image img;
-  const int rc = pnm::read(files[0], &img);
-  if (rc == 2) { std::cerr << "Unknown file format for " << files[0] << std::endl; return -1; }
-  if (rc != 0) { std::cerr << "Unable to load " << files[0] << std::endl; return -1; }
+  pnm::Image picture;
+  switch (pnm::read(rq.input, &picture)) {
+    case 0: break;
+    case 2: fprintf(stderr, "Unknown file format for %s\n", rq.input); return -1;
+    default: fprintf(stderr, "Unable to load %s\n", rq.input); return -1;
+  }
+  // The reference hands the codec FreeImage's memory layout (bottom-up scanlines,
+  // BGR(A)); do the same so that both tools make the same stream of one picture.
+  std::vector<uint8_t> pixels(picture.data.size());
+  pnm::flip_and_swap(picture.data.data(), pixels.data(), picture.width, picture.height, picture.channels);
 
-  // FreeImage memory convention (bottom-up, BGR(A)), so that the stream equals
-  // what the reference chimg makes of the same picture.
-  std::vector<uint8_t> pixels(img.data.size());
-  pnm::flip_and_swap(img.data.data(), pixels.data(), img.width, img.height, img.channels);
-
+  fflush(stdout);   // the library reports through std::cout
   himg::Encoder encoder;
-  if (!encoder.Encode(pixels.data(), img.width, img.height, img.channels, img.channels, quality, use_ycbcr)) {
-    std::cerr << "Unable to encode " << files[0] << std::endl;  // no GPU engine: there is no CPU fallback
+  const int c = picture.channels;
+  if (!encoder.Encode(pixels.data(), picture.width, picture.height, c, c, rq.quality, rq.ycbcr)) {
+    fprintf(stderr, "Unable to encode %s\n", rq.input);   // no GPU engine: there is no CPU fallback
     return -1;
   }
-  std::cout << "Compressed size: " << encoder.packed_size() << std::endl;
+  printf("Compressed size: %d\n", encoder.packed_size());
 
-  std::ofstream f(files[1], std::ofstream::out | std::ofstream::binary);
-  f.write(reinterpret_cast<const char *>(encoder.packed_data()), encoder.packed_size());
-  return f.good() ? 0 : -1;
+  FILE *f = fopen(rq.output, "wb");
+  const size_t n = static_cast<size_t>(encoder.packed_size());
+  const bool ok = f && fwrite(encoder.packed_data(), 1, n, f) == n;
+  if (f) fclose(f);
+  return ok ? 0 : -1;
 }

@@ -1,51 +1,50 @@
 // dhimg -- decompress a .himg file on the MI355X engine.
 //
-// Same command line, messages and exit codes as the reference tool
-// (src/dhimg.cpp:17-72): "dhimg image outfile".  Output: binary PGM / PPM / PAM
-// by channel count (the reference writes PNG through FreeImage).
-#include <fstream>
-#include <iostream>
+// Command line, messages and exit codes follow the reference tool
+// (src/dhimg.cpp:17-72): "dhimg image outfile"; exit 0 on bad arguments, -1 when
+// the input cannot be read, decoded or the output cannot be written.  The picture
+// is written as binary PGM / PPM / PAM by channel count (the reference writes PNG
+// through FreeImage, which this image does not have).
+#include <cstdio>
 #include <vector>
 
 #include "decoder.h"
 #include "pnm_io.h"
 
+namespace {
+
+int fail(const char *what, const char *path) {
+  if (path) printf("%s %s\n", what, path);
+  else printf("%s\n", what);
+  return -1;
+}
+
+}  // namespace
+
 int main(int argc, const char **argv) {
   if (argc < 3) {
-    std::cout << "Usage: " << argv[0] << " image outfile" << std::endl;
+    printf("Usage: %s image outfile\n", argv[0]);
     return 0;
   }
-  std::vector<uint8_t> packed;
-  {
-    std::ifstream f(argv[1], std::ifstream::in | std::ifstream::binary);
-    if (!f.good()) {
-      std::cout << "Unable to read file " << argv[1] << std::endl;
-      return -1;
-    }
-    f.seekg(0, std::ifstream::end);
-    const std::streamoff file_size = f.tellg();
-    f.seekg(0, std::ifstream::beg);
-    std::cout << "File size: " << file_size << std::endl;
-    packed.resize((size_t)file_size);
-    f.read(reinterpret_cast<char *>(packed.data()), file_size);
-  }
+  const char *in_path = argv[1], *out_path = argv[2];
+
+  std::vector<uint8_t> stream;
+  if (!pnm::slurp(in_path, &stream)) return fail("Unable to read file", in_path);
+  printf("File size: %zu\n", stream.size());
+  fflush(stdout);   // the library reports through std::cout
 
   himg::Decoder decoder;
-  if (!decoder.Decode(packed.data(), (int)packed.size())) {
-    std::cout << "Unable to decode image." << std::endl;
-    return -1;
-  }
+  if (!decoder.Decode(stream.data(), static_cast<int>(stream.size()))) return fail("Unable to decode image.", nullptr);
 
-  pnm::Image img;
-  img.width = decoder.width();
-  img.height = decoder.height();
-  img.channels = decoder.num_channels();
-  img.data.resize((size_t)decoder.unpacked_size());
-  // Back from FreeImage's bottom-up BGR(A) to top-down RGB(A).
-  pnm::flip_and_swap(decoder.unpacked_data(), img.data.data(), img.width, img.height, img.channels);
-  if ((img.channels != 1 && img.channels != 3 && img.channels != 4) || !pnm::write(argv[2], img)) {
-    std::cout << "Unable to write file " << argv[2] << std::endl;
-    return -1;
-  }
+  // The codec hands back FreeImage's memory convention (bottom-up, BGR(A)); files
+  // are top-down RGB(A).
+  pnm::Image picture;
+  picture.width = decoder.width();
+  picture.height = decoder.height();
+  picture.channels = decoder.num_channels();
+  picture.data.resize(static_cast<size_t>(decoder.unpacked_size()));
+  pnm::flip_and_swap(decoder.unpacked_data(), picture.data.data(), picture.width, picture.height, picture.channels);
+  const bool writable = picture.channels == 1 || picture.channels == 3 || picture.channels == 4;
+  if (!writable || !pnm::write(out_path, picture)) return fail("Unable to write file", out_path);
   return 0;
 }

@@ -89,6 +89,18 @@ inline bool write(const char *path, const Image &img) {
   return ok;
 }
 
+// Whole file into memory.  Returns false if it cannot be opened.
+inline bool slurp(const char *path, std::vector<uint8_t> *bytes) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  bytes->clear();
+  uint8_t chunk[1 << 16];
+  size_t n;
+  while ((n = fread(chunk, 1, sizeof(chunk), f)) > 0) bytes->insert(bytes->end(), chunk, chunk + n);
+  fclose(f);
+  return true;
+}
+
 // Top-down RGB(A) <-> FreeImage's bottom-up BGR(A) (the conversion is its own inverse).
 inline void flip_and_swap(const uint8_t *src, uint8_t *dst, int width, int height, int channels) {
   const size_t pitch = (size_t)width * channels;
