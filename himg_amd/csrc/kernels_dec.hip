@@ -929,8 +929,9 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
   if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
   if (tid == 0 && stats) {
-    stats[0] = st_chunks; stats[1] = st_rounds; stats[2] = 0;
-    stats[3] = (uint32_t)(c_r1 >> 4); stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
+    stats[0] = st_chunks; stats[1] = st_rounds;
+    if (!FUSED) { stats[2] = 0; stats[3] = (uint32_t)(c_r1 >> 4); }   // fused: the caller's slots
+    stats[4] = (uint32_t)(c_sync >> 4); stats[5] = (uint32_t)(c_write >> 4);
     stats[6] = pay_len; stats[7] = out_size;
   }
   return bad;
@@ -1378,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // The symbols never touch HBM: traffic is the packed row in, the pixels out.
 // ---------------------------------------------------------------------------
 struct FusedLayout {
-  uint32_t sym, grp, sub, ca, cb, sy, sh, unmap, shift, total;
+  uint32_t sym, grp, sub, ca, cb, sy, sh, unmap, shift, shiftp, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int row_block) {
   FusedLayout L;
@@ -1393,8 +1394,188 @@ __host__ __device__ inline FusedLayout fused_layout(int row_block) {
   L.sh = carve((uint32_t)sizeof(StreamShared));
   L.unmap = carve(512u);
   L.shift = carve(128u);
+  L.shiftp = carve(256u);
   L.total = o;
   return L;
+}
+
+// ---------------------------------------------------------------------------
+// Packed-int16 inverse transform of one 8x8 plane (one channel of one tile).
+//
+// The reference does every butterfly in int32 and narrows after the >>3
+// (hadamard.cpp:47-74), so 16-bit lanes are only exact while no sum of eight
+// terms leaves int16.  With every dequantised coefficient in [-4096, 4095] that
+// holds for both passes (|sum| <= 32767 + the one -32768 that still fits, and a
+// pass maps the range onto itself), which is the case for anything but
+// synthetic full-swing noise; a plane with a larger coefficient takes the
+// scalar int32 path below.  Both paths are bit-exact.
+//
+// Layout of the packed path: V[x*4 + j] = rows (2j, 2j+1) of column x, so the
+// row pass (along x) is element-wise over registers; one v_perm per register
+// pair turns that into T[y*4 + i] = columns (2i, 2i+1) of row y for the column
+// pass (along y).  The bilinear low-res block (downsampled.cpp:116-169) is
+// built four rows per register with v_lerp_u8 ((a + b + 1) >> 1 per byte), the
+// int16 add + ClampTo8Bit (decoder.cpp:401-413) is pk_add + v_sat_pk_u8_i16.
+// Output: O[y*2 + h] = the clamped bytes of row y, x = 4h..4h+3.
+// ---------------------------------------------------------------------------
+typedef short dpk16 __attribute__((ext_vector_type(2)));
+typedef unsigned short dupk16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t x) {
+  uint32_t r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(x));
+  return r;   // byte 0 = sat(lo half), byte 1 = sat(hi half)
+}
+
+__device__ __forceinline__ void iwht8_pk(dpk16 &x0, dpk16 &x1, dpk16 &x2, dpk16 &x3, dpk16 &x4,
+                                         dpk16 &x5, dpk16 &x6, dpk16 &x7) {
+  const dpk16 three = {3, 3};
+  const dpk16 a0 = x0 + x4, a1 = x1 + x5, a2 = x2 + x6, a3 = x3 + x7;
+  const dpk16 a4 = x0 - x4, a5 = x1 - x5, a6 = x2 - x6, a7 = x3 - x7;
+  const dpk16 b0 = a0 + a2, b1 = a1 + a3, b2 = a0 - a2, b3 = a1 - a3;
+  const dpk16 b4 = a4 + a6, b5 = a5 + a7, b6 = a4 - a6, b7 = a5 - a7;
+  x0 = (b0 + b1) >> three; x1 = (b4 + b5) >> three;
+  x2 = (b6 + b7) >> three; x3 = (b2 + b3) >> three;
+  x4 = (b2 - b3) >> three; x5 = (b6 - b7) >> three;
+  x6 = (b4 - b5) >> three; x7 = (b0 - b1) >> three;
+}
+
+// lerp tree of downsampled.cpp:116-169 on four packed bytes.
+__device__ __forceinline__ void interp9_u8x4(uint32_t a[9]) {
+  const uint32_t rnd = 0x01010101u;
+  a[4] = __builtin_amdgcn_lerp(a[0], a[8], rnd);
+  a[2] = __builtin_amdgcn_lerp(a[0], a[4], rnd);
+  a[6] = __builtin_amdgcn_lerp(a[4], a[8], rnd);
+  a[1] = __builtin_amdgcn_lerp(a[0], a[2], rnd);
+  a[3] = __builtin_amdgcn_lerp(a[2], a[4], rnd);
+  a[5] = __builtin_amdgcn_lerp(a[4], a[6], rnd);
+  a[7] = __builtin_amdgcn_lerp(a[6], a[8], rnd);
+}
+
+// Low-res block: LQ[q][x] = bytes of rows 4q..4q+3 at column x.
+__device__ __forceinline__ void lowres_quads(uint32_t lr0, uint32_t lr8, uint32_t LQ[2][8]) {
+  uint32_t lr[9];
+  lr[0] = lr0; lr[8] = lr8;
+  interp9_u8x4(lr);   // bytes 0,1 = left,right of rows 0..7
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t p01 = __builtin_amdgcn_perm(lr[4 * q + 1], lr[4 * q], 0x05010400u);      // L0 L1 R0 R1
+    const uint32_t p23 = __builtin_amdgcn_perm(lr[4 * q + 3], lr[4 * q + 2], 0x05010400u);  // L2 L3 R2 R3
+    uint32_t a[9];
+    a[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    a[8] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+    interp9_u8x4(a);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) LQ[q][x] = a[x];
+  }
+}
+
+// slot: the tile's first symbol (scan index k is at slot[k * cols]); shift: the
+// 64 per-position shifts; shiftp: the same as 32 packed pairs in V order; lr0 /
+// lr8: (left, right) low-res samples of this and the next block row in bytes 0, 1.
+template <int COLS>
+__device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, const int16_t *s_unmap,
+                                           const uint8_t *shift, const uint32_t *shiftp,
+                                           uint32_t lr0, uint32_t lr8, uint32_t O[16]) {
+  const int cols = COLS ? COLS : cols_rt;
+  // Gather + dequantise (quantize.cpp:153-165: int16 wrap == 16-bit shift left).
+  dpk16 V[32];
+  uint32_t acc = 0;
+  {
+    uint32_t W[32];
+    if (COLS) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const int x = e >> 2, j = e & 3, p0 = (2 * j) * 8 + x;
+        const int c0 = slot[(size_t)kInvScanD[p0] * cols], c1 = slot[(size_t)kInvScanD[p0 + 8] * cols];
+        W[e] = (uint32_t)(uint16_t)s_unmap[c0] | ((uint32_t)(uint16_t)s_unmap[c1] << 16);
+      }
+    } else {
+      // Run-time column count: walk the slots in scan order with one running
+      // pointer (64 separate offsets would not stay in registers).
+#pragma unroll
+      for (int e = 0; e < 32; ++e) W[e] = 0;
+      const uint8_t *q = slot;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) {
+        const int pos = kScanD[k], y = pos >> 3, x = pos & 7;
+        const int code = *q;
+        q += cols;
+        if ((k & 7) == 7) asm volatile("" : "+v"(q));
+        W[x * 4 + (y >> 1)] |= (uint32_t)(uint16_t)s_unmap[code] << ((y & 1) * 16);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const dupk16 d = __builtin_bit_cast(dupk16, W[e]) << __builtin_bit_cast(dupk16, shiftp[e]);
+      V[e] = __builtin_bit_cast(dpk16, d);
+      const dupk16 bias = {0x1000, 0x1000};
+      acc |= __builtin_bit_cast(uint32_t, (dupk16)(d + bias));
+    }
+  }
+  dpk16 T[32];   // T[y*4 + i] = columns (2i, 2i+1) of row y after both passes
+  if (__builtin_expect((acc & 0xe000e000u) == 0, 1)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      iwht8_pk(V[j], V[4 + j], V[8 + j], V[12 + j], V[16 + j], V[20 + j], V[24 + j], V[28 + j]);
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        T[y * 4 + i] = __builtin_bit_cast(
+            dpk16, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, V[(2 * i + 1) * 4 + (y >> 1)]),
+                                         __builtin_bit_cast(uint32_t, V[(2 * i) * 4 + (y >> 1)]),
+                                         (y & 1) ? 0x07060302u : 0x05040100u));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      iwht8_pk(T[i], T[4 + i], T[8 + i], T[12 + i], T[16 + i], T[20 + i], T[24 + i], T[28 + i]);
+  } else {
+    // Scalar int32 path, one row / two columns at a time (same arithmetic as k_tile_inv).
+    uint32_t P[32];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      int r[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const uint32_t w = __builtin_bit_cast(uint32_t, V[x * 4 + (y >> 1)]);
+        r[x] = (int)(int16_t)(uint16_t)(w >> ((y & 1) * 16));
+      }
+      iwht8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+#pragma unroll
+      for (int x = 0; x < 8; x += 2)
+        P[y * 4 + x / 2] = ((uint32_t)r[x] & 0xffffu) | ((uint32_t)r[x + 1] << 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ca[8], cb[8];
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        ca[y] = (int)(int16_t)(uint16_t)(P[y * 4 + i] & 0xffffu);
+        cb[y] = (int)(int16_t)(uint16_t)(P[y * 4 + i] >> 16);
+      }
+      iwht8(ca[0], ca[1], ca[2], ca[3], ca[4], ca[5], ca[6], ca[7]);
+      iwht8(cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], cb[6], cb[7]);
+#pragma unroll
+      for (int y = 0; y < 8; ++y)
+        T[y * 4 + i] = __builtin_bit_cast(dpk16, ((uint32_t)ca[y] & 0xffffu) | ((uint32_t)cb[y] << 16));
+    }
+  }
+  uint32_t LQ[2][8];
+  lowres_quads(lr0, lr8, LQ);
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    uint32_t sb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t sel = 0x0c000c00u | (uint32_t)(y & 3) | ((uint32_t)(4 + (y & 3)) << 16);
+      const dpk16 lo = __builtin_bit_cast(
+          dpk16, __builtin_amdgcn_perm(LQ[y >> 2][2 * i + 1], LQ[y >> 2][2 * i], sel));
+      sb[i] = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(T[y * 4 + i] + lo)));
+    }
+    O[y * 2] = __builtin_amdgcn_perm(sb[1], sb[0], 0x05040100u);
+    O[y * 2 + 1] = __builtin_amdgcn_perm(sb[3], sb[2], 0x05040100u);
+  }
+  (void)shift;
 }
 
 // COLS != 0 fixes the tile count per block row at compile time (512 = 4096-pixel
@@ -1418,8 +1599,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   StreamShared *sh = reinterpret_cast<StreamShared *>(smem + L.sh);
   int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
   uint8_t *s_shift = smem + L.shift;
+  uint32_t *s_shiftp = reinterpret_cast<uint32_t *>(smem + L.shiftp);
 
-  const int r = blockIdx.x + r0, f = blockIdx.y, tid = threadIdx.x;
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const long long c_in = clock64();
   DecFrame *df = ws.frames + f;
   if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
@@ -1429,7 +1612,14 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
   } else if (tid < 384) {
     s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
+  } else if (tid < 448) {
+    // The same shifts as packed pairs in tile_plane's register order.
+    const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
+    s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
   }
+  GrpTables tb;
+  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const int r = r0 + (int)blockIdx.x;
   {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
@@ -1438,15 +1628,17 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   }
   __syncthreads();
 
-  GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  if (tid == 0) {
+    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
+    st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
+  }
   const int bad = decode_stream<true>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
       (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
       ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub,
       ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
       ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
-  if (bad) {
+  if (bad) {   // uniform: every lane gets the same verdict
     if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
     return;
   }
@@ -1455,147 +1647,115 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const int ycbcr = df->ycbcr;
   const int cols = COLS ? COLS : g.cols, v = r;
   const int v2 = min(v + 1, g.rows - 1);
-  // ---- phase 2: per-tile inverse transform, in place ----
-#pragma unroll 1
-  for (int it = tid; it < cols * g.C; it += kDecThreads) {
-    const int c = it / cols, u = it - c * cols;
-    const int u2 = min(u + 1, cols - 1);
-    {
-      const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * cols;
-      const bool chroma = ycbcr && (c == 1 || c == 2);  // decoder.cpp:376
-      const uint8_t *shift = s_shift + (chroma ? 64 : 0);
-      uint8_t *slot = sym + (size_t)c * 64 * cols + u;
-      // Row pass: gather one row of coefficients at a time (row-major position ->
-      // scan index through kInvScanD), dequantise (quantize.cpp:153-165, int16
-      // wrap), butterfly, and keep the int16 results packed two per register.
-      uint32_t P[32];
-      // With a run-time column count the 64 slot offsets are not immediates: the
-      // generic variant walks the slots in scan order with ONE running pointer and
-      // collects the dequantised coefficients (packed int16) first -- 64 separate
-      // offsets would live in SGPRs, spill into VGPR lanes and from there to scratch.
-      uint32_t D[32];
-      if (!COLS) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) D[k] = 0;
-        const uint8_t *q = slot;
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          const int pos = kScanD[i];
-          const int code = *q;
-          q += cols;
-          if ((i & 7) == 7) asm volatile("" : "+v"(q));   // keep it a running pointer
-          const uint32_t val = (uint32_t)(uint16_t)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
-          D[pos >> 1] |= val << ((pos & 1) * 16);
-        }
-      }
-#pragma unroll
-      for (int y = 0; y < 8; ++y) {
-        int r[8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-          const int pos = y * 8 + x;
-          if (COLS) {
-            const int code = slot[(size_t)kInvScanD[pos] * cols];
-            r[x] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
-          } else {
-            r[x] = (int)(int16_t)(D[pos >> 1] >> ((pos & 1) * 16));
-          }
-        }
-        iwht8(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
-#pragma unroll
-        for (int x = 0; x < 8; x += 2)
-          P[y * 4 + x / 2] = ((uint32_t)r[x] & 0xffffu) | ((uint32_t)r[x + 1] << 16);
-      }
-      // Bilinear low-res block (downsampled.cpp:116-169), packed one byte per pixel.
-      uint32_t L[16];
-      {
-        int left[9], right[9];
-        left[0] = m[(size_t)v * cols + u];   left[8] = m[(size_t)v2 * cols + u];
-        right[0] = m[(size_t)v * cols + u2]; right[8] = m[(size_t)v2 * cols + u2];
-        interp9d(left);
-        interp9d(right);
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-          int a[9];
-          a[0] = left[y]; a[8] = right[y];
-          interp9d(a);
-          L[2 * y] = (uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24);
-          L[2 * y + 1] = (uint32_t)a[4] | ((uint32_t)a[5] << 8) | ((uint32_t)a[6] << 16) | ((uint32_t)a[7] << 24);
-        }
-      }
-      // Column pass, one column at a time; results go straight back to the tile's
-      // own slots (buf0[i] += lowres[i] in int16, ClampTo8Bit: decoder.cpp:401-413).
-      // Generic variant: running pointers again, from a copy of the base the compiler
-      // cannot see through -- otherwise it keeps the gather's 64 addresses alive for
-      // these stores (common subexpressions) and spills them.
-      uint8_t *qcol = slot;
-      if (!COLS) asm volatile("" : "+v"(qcol));
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        int cv[8];
-#pragma unroll
-        for (int y = 0; y < 8; ++y)
-          cv[y] = (int)(int16_t)(P[y * 4 + x / 2] >> ((x & 1) * 16));
-        iwht8(cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7]);
-        uint8_t *qy = qcol;
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-          const int lo = (int)((L[2 * y + x / 4] >> ((x & 3) * 8)) & 255u);
-          const uint8_t px = (uint8_t)clamp255d((int)(int16_t)(cv[y] + lo));
-          if (COLS) slot[(size_t)(y * 8 + x) * cols] = px;
-          else { *qy = px; qy += 8 * cols; }
-        }
-        qcol += cols;
-        if (!COLS) asm volatile("" : "+v"(qcol));
-      }
-    }
-  }
-  __syncthreads();
-  const long long c_p3 = clock64();
-
-  // ---- phase 3: colour inverse + coalesced stores ----
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
-  const int bh = min(8, g.H - 8 * v);
-  const int items = cols * 8;
-  for (int it = tid; it < items; it += kDecThreads) {
-    const int y = it / cols, u = it - y * cols;
-    if (y >= bh) continue;
-    const int bw = min(8, g.W - 8 * u);
-    uint32_t px[8];
+  // ---- phase 2: inverse transform, colour inverse and stores ----
+  // Two adjacent lanes share a tile: lane s of the pair transforms channels 2s
+  // and 2s+1 (packed int16 butterflies, see tile_plane), the pair swaps halves
+  // with one DPP move per register, and lane s finishes pixel rows 4s..4s+3 --
+  // colour inverse on packed pairs, then two 16-byte stores per pixel row.  The
+  // decoded symbols stay read-only in LDS: no barrier, no second pass over them.
+#pragma unroll 1
+  for (int it = tid; it < 2 * cols; it += kDecThreads) {
+    const int u = it >> 1, s = it & 1;
+    const int u2 = min(u + 1, cols - 1);
+    uint32_t QA[16], QB[16];
+#pragma unroll 1
+    for (int cc = 0; cc < 2; ++cc) {
+      const int c = 2 * s + cc;
+      uint32_t O[16];
+      if (c < g.C) {
+        const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * cols;
+        const int chroma = (ycbcr && (c == 1 || c == 2)) ? 1 : 0;  // decoder.cpp:376
+        uint32_t lr0 = (uint32_t)m[(size_t)v * cols + u] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
+        uint32_t lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
+        tile_plane<COLS>(sym + (size_t)c * 64 * cols + u, cols, s_unmap, s_shift + chroma * 64,
+                         s_shiftp + chroma * 32, lr0, lr8, O);
+      } else {
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      uint32_t w = 0;
-      for (int c = 0; c < g.C; ++c)
-        w |= (uint32_t)sym[((size_t)c * 64 + y * 8 + x) * cols + u] << (8 * c);
-      if (ycbcr) {  // ycbcr.cpp:54-82
-        const int yy = w & 255;
-        const int cbv = (int)((w >> 8) & 255) * 2 - 255;
-        const int crv = (int)((w >> 16) & 255) * 2 - 255;
-        const int gg = yy - ((cbv + crv + 2) >> 2);
-        const int bb = gg + cbv, rr = gg + crv;
-        w = (w & 0xff000000u) | (uint32_t)clamp255d(rr) | ((uint32_t)clamp255d(gg) << 8) |
-            ((uint32_t)clamp255d(bb) << 16);
+        for (int i = 0; i < 16; ++i) O[i] = 0;
       }
-      px[x] = w;
-    }
-    uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * g.C;
-    if (g.C == 4 && bw == 8) {
-      uint4 q0, q1;
-      q0.x = px[0]; q0.y = px[1]; q0.z = px[2]; q0.w = px[3];
-      q1.x = px[4]; q1.y = px[5]; q1.z = px[6]; q1.w = px[7];
-      reinterpret_cast<uint4 *>(dst)[0] = q0;
-      reinterpret_cast<uint4 *>(dst)[1] = q1;
-    } else {
+      if (cc == 0) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x)
-        if (x < bw)
-          for (int c = 0; c < g.C; ++c) dst[x * g.C + c] = (uint8_t)(px[x] >> (8 * c));
+        for (int i = 0; i < 16; ++i) QA[i] = O[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) QB[i] = O[i];
+      }
+    }
+    // Swap halves inside the lane pair (quad_perm [1,0,3,2]).
+    uint32_t ch0[8], ch1[8], ch2[8], ch3[8];   // [r*2+h]: pixel row 4s+r, x = 4h..4h+3
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t a_lo = __builtin_amdgcn_update_dpp(0u, QA[i], 0xB1, 0xf, 0xf, true);
+      const uint32_t a_hi = __builtin_amdgcn_update_dpp(0u, QA[8 + i], 0xB1, 0xf, 0xf, true);
+      const uint32_t b_lo = __builtin_amdgcn_update_dpp(0u, QB[i], 0xB1, 0xf, 0xf, true);
+      const uint32_t b_hi = __builtin_amdgcn_update_dpp(0u, QB[8 + i], 0xB1, 0xf, 0xf, true);
+      ch0[i] = s ? a_hi : QA[i];
+      ch1[i] = s ? b_hi : QB[i];
+      ch2[i] = s ? QA[8 + i] : a_lo;
+      ch3[i] = s ? QB[8 + i] : b_lo;
+    }
+    const int bw = min(8, g.W - 8 * u);
+    const int bh = min(8, g.H - 8 * v);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int y = 4 * s + rr;
+      uint32_t px[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t q0 = ch0[rr * 2 + h], q1 = ch1[rr * 2 + h], q2 = ch2[rr * 2 + h], q3 = ch3[rr * 2 + h];
+        if (ycbcr) {  // ycbcr.cpp:54-82, two pixels per packed op
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const uint32_t sel = k ? 0x0c030c02u : 0x0c010c00u;
+            const dpk16 yy = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q0, sel));
+            const dpk16 cbq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q1, sel));
+            const dpk16 crq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q2, sel));
+            const dpk16 c255 = {255, 255}, c254 = {254, 254}, one = {1, 1};
+            const dpk16 cbv = cbq + cbq - c255, crv = crq + crq - c255;
+            // (cbv + crv + 2) >> 2 == (cb + cr - 254) >> 1 exactly.
+            const dpk16 gg = yy - ((cbq + crq - c254) >> one);
+            const uint32_t rs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + crv)));
+            const uint32_t gs = sat_pk_u8(__builtin_bit_cast(uint32_t, gg));
+            const uint32_t bs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + cbv)));
+            const uint32_t rg = __builtin_amdgcn_perm(gs, rs, 0x05010400u);            // r0 g0 r1 g1
+            const uint32_t ba = __builtin_amdgcn_perm(q3, bs, k ? 0x07010600u : 0x05010400u);  // b0 a0 b1 a1
+            px[4 * h + 2 * k] = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+            px[4 * h + 2 * k + 1] = __builtin_amdgcn_perm(ba, rg, 0x07060302u);
+          }
+        } else {
+          const uint32_t t0 = __builtin_amdgcn_perm(q1, q0, 0x05010400u), t1 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
+          const uint32_t w0 = __builtin_amdgcn_perm(q3, q2, 0x05010400u), w1 = __builtin_amdgcn_perm(q3, q2, 0x07030602u);
+          px[4 * h + 0] = __builtin_amdgcn_perm(w0, t0, 0x05040100u);
+          px[4 * h + 1] = __builtin_amdgcn_perm(w0, t0, 0x07060302u);
+          px[4 * h + 2] = __builtin_amdgcn_perm(w1, t1, 0x05040100u);
+          px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
+        }
+      }
+      if (y < bh) {
+        uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * g.C;
+        if (g.C == 4 && bw == 8) {
+          uint4 o0, o1;
+          o0.x = px[0]; o0.y = px[1]; o0.z = px[2]; o0.w = px[3];
+          o1.x = px[4]; o1.y = px[5]; o1.z = px[6]; o1.w = px[7];
+          reinterpret_cast<uint4 *>(dst)[0] = o0;
+          reinterpret_cast<uint4 *>(dst)[1] = o1;
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; ++x)
+            if (x < bw)
+              for (int c = 0; c < g.C; ++c) dst[x * g.C + c] = (uint8_t)(px[x] >> (8 * c));
+        }
+      }
     }
   }
-  if (tid == 0) {
+  // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
+  // first wave finishes long before the last one).
+  if ((tid & 63) == 0) {
     uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
-    st[2] = (uint32_t)((c_p3 - c_p2) >> 4);
-    st[7] = (uint32_t)((clock64() - c_p3) >> 4);
+    const long long c_out = clock64();
+    atomicMax(&st[2], (uint32_t)((c_out - c_p2) >> 4));   // transform + stores
+    atomicMax(&st[3], (uint32_t)((c_out - c_in) >> 4));   // the whole workgroup
   }
 }
 
@@ -1614,44 +1774,49 @@ __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, con
   __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
-  const int r = blockIdx.x + r0, f = blockIdx.y, tid = threadIdx.x;
+  const int f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
-  uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
-  if (tid == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
-  if (df->status) return;
-  const uint8_t *p = packed + (size_t)f * in_stride;
-  const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
-  const unsigned long long rem = 8ull * pay_len;
-  uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
-  sb = (sb + 31u) & ~31u;
-  sb = sb < kMinSubBits ? kMinSubBits : sb;
-  if (sb > (uint32_t)g.max_sub || rem == 0) return;   // more than one chunk: the fused kernel does it all
-  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
+  const int failed = df->status;   // set by earlier kernels only: the same for every lane
+  if (!failed) load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
   __syncthreads();
   GrpTables tb;
   tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  GReader rd;
-  const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
-  const uint32_t rel_end = rel0 + (uint32_t)rem;
-  const uint32_t my_b0 = rel0 + (uint32_t)tid * sb;
-  uint32_t lim = my_b0 + sb;
-  if (lim > rel_end) lim = rel_end;
-  const bool active = my_b0 < rel_end;
-  const int last_active = (int)((rel_end - rel0 - 1u) / sb);
-  uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
-  lean_fixpoint(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false);
-  unsigned long long tot;
-  const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
-  l_start[tid] = start - rel0;
-  l_off[tid] = off < 0xffffffffull ? (uint32_t)off : 0xffffffffu;
-  if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
-  if (tid == 0) {
-    l_off[kDecThreads] = tot < 0xffffffffull ? (uint32_t)tot : 0xffffffffu;
-    l_off[kDecThreads + 3] = rounds;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  const int r = r0 + (int)blockIdx.x;
+  {
+    uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+    if (tid == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
+    const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
+    const unsigned long long rem = 8ull * pay_len;
+    uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
+    sb = (sb + 31u) & ~31u;
+    sb = sb < kMinSubBits ? kMinSubBits : sb;
+    // More than one chunk: the fused kernel does it all.
+    if (!failed && sb <= (uint32_t)g.max_sub && rem != 0) {
+      GReader rd;
+      const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
+      const uint32_t rel_end = rel0 + (uint32_t)rem;
+      const uint32_t my_b0 = rel0 + (uint32_t)tid * sb;
+      uint32_t lim = my_b0 + sb;
+      if (lim > rel_end) lim = rel_end;
+      const bool active = my_b0 < rel_end;
+      const int last_active = (int)((rel_end - rel0 - 1u) / sb);
+      uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
+      lean_fixpoint(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false);
+      unsigned long long tot;
+      const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
+      l_start[tid] = start - rel0;
+      l_off[tid] = off < 0xffffffffull ? (uint32_t)off : 0xffffffffu;
+      if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
+      if (tid == 0) {
+        l_off[kDecThreads] = tot < 0xffffffffull ? (uint32_t)tot : 0xffffffffu;
+        l_off[kDecThreads + 3] = rounds;
+      }
+      __syncthreads();
+      if (tid == 0) { __threadfence(); l_off[kDecThreads + 2] = 1; }
+    }
   }
-  __syncthreads();
-  if (tid == 0) { __threadfence(); l_off[kDecThreads + 2] = 1; }
 }
 
 // k_dec_status: copy the per-frame verdict out of the workspace.
