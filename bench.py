@@ -214,9 +214,13 @@ def bench_rows(args, rank, local_rank, world, dev):
     backend = sharded.EngineBackend(eng, d_shard, y0, W, H, Q, True)
 
     def step():
-        return sharded.encode_sharded(backend, rows, cols, 4, rows > 1)
+        # The stream stays in rank 0's HBM (like the frames metric); the one host
+        # copy below is for the bit-exactness check.
+        return sharded.encode_sharded(backend, rows, cols, 4, rows > 1, host=False)
 
     out = step()
+    if rank == 0:
+        out = out.cpu().numpy()
     verified = "n/a"
     if rank == 0:
         if want is None:
@@ -279,8 +283,8 @@ def bench_rows(args, rank, local_rank, world, dev):
             "dtype": "u8/i16/i32 integer", "data": "synthetic",
             "config": {"workload": "%dx%d RGBA %s q=%d, encode, block rows sharded over %d rank(s), "
                                    "host-orchestrated collectives (all-reduce 261xi64, all-gather row "
-                                   "bits, gather low-res rows and packed rows to rank 0), result includes "
-                                   "D2H of the final stream" % (W, H, args.kind, Q, world),
+                                   "bits, gather low-res rows and packed rows to rank 0), the stream stays in "
+                                   "rank 0's HBM" % (W, H, args.kind, Q, world),
                        "bit_exact": verified}}), flush=True)
     if world > 1:
         dist.barrier()

@@ -90,6 +90,22 @@ def build_cli(verbose=False):
     return out
 
 
+def build_unit_checks(verbose=False):
+    """Device-side unit checks (tests/ run them on the GPU box): tile_plane_check
+    compares the packed inverse transform with a scalar host model."""
+    os.makedirs(BINDIR, exist_ok=True)
+    src = os.path.join(ROOT, "tools", "micro", "tile_plane_check.hip")
+    exe = os.path.join(BINDIR, "tile_plane_check")
+    deps = [src, os.path.join(CSRC, "kernels_dec.hip")] + [os.path.join(CSRC, h) for h in HEADERS]
+    if _stale(exe, deps):
+        cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-unused-value",
+               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, "-o", exe]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return [exe]
+
+
 def build_oracle(verbose=False):
     """Build the CPU checker (tests / smoke / cpu_baseline only)."""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")] + ([] if verbose else ["-s"]),

@@ -1241,18 +1241,8 @@ __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
 }
 
 // ---------------------------------------------------------------------------
-// k_tile_inv: one lane per 8x8 tile.
+// Inverse transform (shared by k_dec_row_fused and k_tile_inv).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void interp9d(int a[9]) {
-  a[4] = (a[0] + a[8] + 1) >> 1;
-  a[2] = (a[0] + a[4] + 1) >> 1;
-  a[6] = (a[4] + a[8] + 1) >> 1;
-  a[1] = (a[0] + a[2] + 1) >> 1;
-  a[3] = (a[2] + a[4] + 1) >> 1;
-  a[5] = (a[4] + a[6] + 1) >> 1;
-  a[7] = (a[6] + a[8] + 1) >> 1;
-}
-
 // Inverse 8-point butterfly: int32, floor >>3, narrowed to int16 (hadamard.cpp:47-74).
 __device__ __forceinline__ void iwht8(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5,
                                       int &x6, int &x7) {
@@ -1264,108 +1254,6 @@ __device__ __forceinline__ void iwht8(int &x0, int &x1, int &x2, int &x3, int &x
   x2 = (int16_t)((b6 + b7) >> 3); x3 = (int16_t)((b2 + b3) >> 3);
   x4 = (int16_t)((b2 - b3) >> 3); x5 = (int16_t)((b6 - b7) >> 3);
   x6 = (int16_t)((b4 - b5) >> 3); x7 = (int16_t)((b0 - b1) >> 3);
-}
-
-__global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames, int v0) {
-  __shared__ int16_t s_unmap[256];   // indexed by the code byte
-  __shared__ uint8_t s_shift[2][64];
-  const int v = blockIdx.y + v0, f = blockIdx.z;
-  const DecFrame *df = ws.frames + f;
-  if (df->status) return;
-  for (int k = threadIdx.x; k < 256; k += 256) {
-    const int sc = (int8_t)k;
-    s_unmap[k] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
-  }
-  for (int k = threadIdx.x; k < 128; k += 256) s_shift[k >> 6][k & 63] = df->shift[k >> 6][k & 63];
-  __syncthreads();
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= g.cols) return;
-  const int ycbcr = df->ycbcr;
-  const int bw = min(8, g.W - 8 * u), bh = min(8, g.H - 8 * v);
-  const int u2 = min(u + 1, g.cols - 1), v2 = min(v + 1, g.rows - 1);
-  const uint8_t *src_row = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)v * g.row_block + u;
-  uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
-
-  uint32_t px[64];
-#pragma unroll
-  for (int i = 0; i < 64; ++i) px[i] = 0;
-
-  for (int c = 0; c < g.C; ++c) {
-    const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * g.cols;
-    const bool chroma = ycbcr && (c == 1 || c == 2);  // decoder.cpp:376
-    const uint8_t *shift = s_shift[chroma ? 1 : 0];
-    const uint8_t *src = src_row + (size_t)c * 64 * g.cols;
-    int b[64];
-    // Gather (decoder.cpp:384-392) + Quantize::Unpack (quantize.cpp:153-165; int16 wrap).
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int pos = kScanD[i];
-      const int code = src[(size_t)i * g.cols];
-      b[pos] = (int)(int16_t)((int)s_unmap[code] * (1 << shift[pos]));
-    }
-    // Inverse WHT: rows first, then columns, >>3 after each pass (trap T8).
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-      iwht8(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
-            b[y * 8 + 6], b[y * 8 + 7]);
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-      iwht8(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
-
-    int left[9], right[9];
-    left[0] = m[(size_t)v * g.cols + u];   left[8] = m[(size_t)v2 * g.cols + u];
-    right[0] = m[(size_t)v * g.cols + u2]; right[8] = m[(size_t)v2 * g.cols + u2];
-    interp9d(left);
-    interp9d(right);
-    const int sh = 8 * c;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      int a[9];
-      a[0] = left[y]; a[8] = right[y];
-      interp9d(a);
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        // buf0[i] += lowres[i] in int16, then ClampTo8Bit (decoder.cpp:401-413, common.h:37-39).
-        const int val = clamp255d((int)(int16_t)(b[y * 8 + x] + a[x]));
-        px[y * 8 + x] |= (uint32_t)val << sh;
-      }
-    }
-  }
-
-  // Colour inverse on the clamped planes (ycbcr.cpp:54-82) and store.
-  const bool fast = (g.C == 4 && bw == 8 && bh == 8);
-#pragma unroll
-  for (int y = 0; y < 8; ++y) {
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      uint32_t w = px[y * 8 + x];
-      if (ycbcr) {
-        const int yy = w & 255;
-        const int cbv = (int)((w >> 8) & 255) * 2 - 255;
-        const int crv = (int)((w >> 16) & 255) * 2 - 255;
-        const int gg = yy - ((cbv + crv + 2) >> 2);
-        const int bb = gg + cbv, rr = gg + crv;
-        w = (w & 0xff000000u) | (uint32_t)clamp255d(rr) | ((uint32_t)clamp255d(gg) << 8) |
-            ((uint32_t)clamp255d(bb) << 16);
-      }
-      px[y * 8 + x] = w;
-    }
-    if (fast) {
-      uint4 *rp = reinterpret_cast<uint4 *>(img + ((size_t)(8 * v + y) * g.W + 8 * u) * 4);
-      uint4 q0, q1;
-      q0.x = px[y * 8 + 0]; q0.y = px[y * 8 + 1]; q0.z = px[y * 8 + 2]; q0.w = px[y * 8 + 3];
-      q1.x = px[y * 8 + 4]; q1.y = px[y * 8 + 5]; q1.z = px[y * 8 + 6]; q1.w = px[y * 8 + 7];
-      rp[0] = q0; rp[1] = q1;
-    } else if (y < bh) {
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        if (x < bw) {
-          uint8_t *q = img + ((size_t)(8 * v + y) * g.W + 8 * u + x) * g.C;
-          for (int c = 0; c < g.C; ++c) q[c] = (uint8_t)(px[y * 8 + x] >> (8 * c));
-        }
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1530,7 +1418,7 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
     for (int i = 0; i < 4; ++i)
       iwht8_pk(T[i], T[4 + i], T[8 + i], T[12 + i], T[16 + i], T[20 + i], T[24 + i], T[28 + i]);
   } else {
-    // Scalar int32 path, one row / two columns at a time (same arithmetic as k_tile_inv).
+    // Scalar int32 path, one row / two columns at a time.
     uint32_t P[32];
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
@@ -1578,85 +1466,20 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
   (void)shift;
 }
 
-// COLS != 0 fixes the tile count per block row at compile time (512 = 4096-pixel
-// rows): the 64 symbol slots of a tile are then at immediate LDS offsets instead
-// of 64 live address registers, which is what keeps the transform phase from
-// spilling.
+// One lane of a lane pair: lane s transforms channels 2s and 2s+1 of tile u in
+// block row v (packed int16 butterflies, see tile_plane), the pair swaps halves
+// with one DPP move per register, and lane s finishes pixel rows 4s..4s+3 --
+// colour inverse on packed pairs (ycbcr.cpp:54-82), then two 16-byte stores per
+// pixel row.  sym: the block row's symbols (channel c, scan index k, tile u at
+// sym[(c*64 + k)*cols + u]), LDS or HBM; low: the frame's low-res planes.  Both
+// lanes of a pair must be active.
 template <int COLS>
-__global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
-                                                               const uint8_t *packed,
-                                                               size_t in_stride,
-                                                               const uint32_t *sizes,
-                                                               uint8_t *out_frames, int r0) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const FusedLayout L = fused_layout(g.row_block);
-  uint8_t *sym = smem + L.sym;
-  uint2 *grp = reinterpret_cast<uint2 *>(smem + L.grp);
-  uint32_t *sub = reinterpret_cast<uint32_t *>(smem + L.sub);
-  short *ca = reinterpret_cast<short *>(smem + L.ca);
-  short *cb = reinterpret_cast<short *>(smem + L.cb);
-  short *sy = reinterpret_cast<short *>(smem + L.sy);
-  StreamShared *sh = reinterpret_cast<StreamShared *>(smem + L.sh);
-  int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
-  uint8_t *s_shift = smem + L.shift;
-  uint32_t *s_shiftp = reinterpret_cast<uint32_t *>(smem + L.shiftp);
-
-  const int f = blockIdx.y, tid = threadIdx.x;
-  const long long c_in = clock64();
-  DecFrame *df = ws.frames + f;
-  if (df->status) return;
-  const uint8_t *p = packed + (size_t)f * in_stride;
-  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
-  if (tid < 256) {
-    const int sc = (int8_t)tid;
-    s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
-  } else if (tid < 384) {
-    s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
-  } else if (tid < 448) {
-    // The same shifts as packed pairs in tile_plane's register order.
-    const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
-    s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
-  }
-  GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  const int r = r0 + (int)blockIdx.x;
-  {
-    uint4 z;
-    z.x = z.y = z.z = z.w = 0;
-    const int n16 = (g.row_block + 15) >> 4;
-    for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym)[k] = z;
-  }
-  __syncthreads();
-
-  if (tid == 0) {
-    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
-    st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
-  }
-  const int bad = decode_stream<true>(
-      p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
-      (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
-      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub,
-      ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
-      ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
-  if (bad) {   // uniform: every lane gets the same verdict
-    if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
-    return;
-  }
-
-  const long long c_p2 = clock64();
-  const int ycbcr = df->ycbcr;
-  const int cols = COLS ? COLS : g.cols, v = r;
+__device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt, const uint8_t *sym,
+                                                     const uint8_t *low, const int16_t *s_unmap,
+                                                     const uint8_t *s_shift, const uint32_t *s_shiftp,
+                                                     int ycbcr, int u, int s, int v, uint8_t *img) {
+  const int cols = COLS ? COLS : cols_rt;
   const int v2 = min(v + 1, g.rows - 1);
-  uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
-  // ---- phase 2: inverse transform, colour inverse and stores ----
-  // Two adjacent lanes share a tile: lane s of the pair transforms channels 2s
-  // and 2s+1 (packed int16 butterflies, see tile_plane), the pair swaps halves
-  // with one DPP move per register, and lane s finishes pixel rows 4s..4s+3 --
-  // colour inverse on packed pairs, then two 16-byte stores per pixel row.  The
-  // decoded symbols stay read-only in LDS: no barrier, no second pass over them.
-#pragma unroll 1
-  for (int it = tid; it < 2 * cols; it += kDecThreads) {
-    const int u = it >> 1, s = it & 1;
     const int u2 = min(u + 1, cols - 1);
     uint32_t QA[16], QB[16];
 #pragma unroll 1
@@ -1664,7 +1487,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       const int c = 2 * s + cc;
       uint32_t O[16];
       if (c < g.C) {
-        const uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * cols;
+        const uint8_t *m = low + (size_t)c * g.rows * cols;
         const int chroma = (ycbcr && (c == 1 || c == 2)) ? 1 : 0;  // decoder.cpp:376
         uint32_t lr0 = (uint32_t)m[(size_t)v * cols + u] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
         uint32_t lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
@@ -1748,7 +1571,112 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
         }
       }
     }
+}
+
+// k_tile_inv: the transform of the unfused path (rows too wide for LDS): the
+// symbols come from HBM (ws.fres_sym, written by k_dec_huff); two adjacent lanes
+// per tile, 128 tiles per workgroup.
+__global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames, int v0) {
+  __shared__ int16_t s_unmap[256];   // indexed by the code byte
+  __shared__ uint8_t s_shift[2][64];
+  __shared__ uint32_t s_shiftp[2][32];
+  const int v = blockIdx.y + v0, f = blockIdx.z;
+  const DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  {
+    const int k = threadIdx.x;
+    const int sc = (int8_t)k;
+    s_unmap[k] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
+    if (k < 128) s_shift[k >> 6][k & 63] = df->shift[k >> 6][k & 63];
+    if (k < 64) {
+      const int ch = k >> 5, e = k & 31, x = e >> 2, j = e & 3;
+      s_shiftp[ch][e] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
+    }
   }
+  __syncthreads();
+  const int it = blockIdx.x * 256 + threadIdx.x;   // (tile, half): pairs never straddle the edge
+  if (it >= 2 * g.cols) return;
+  transform_store_pair<0>(g, g.cols, ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)v * g.row_block,
+                          ws.low + (size_t)f * ws.plane_stride, s_unmap, &s_shift[0][0], &s_shiftp[0][0],
+                          df->ycbcr, it >> 1, it & 1, v, out_frames + (size_t)f * ((size_t)g.W * g.H * g.C));
+}
+
+// COLS != 0 fixes the tile count per block row at compile time (512 = 4096-pixel
+// rows): the 64 symbol slots of a tile are then at immediate LDS offsets instead
+// of 64 live address registers, which is what keeps the transform phase from
+// spilling.
+template <int COLS>
+__global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
+                                                               const uint8_t *packed,
+                                                               size_t in_stride,
+                                                               const uint32_t *sizes,
+                                                               uint8_t *out_frames, int r0) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const FusedLayout L = fused_layout(g.row_block);
+  uint8_t *sym = smem + L.sym;
+  uint2 *grp = reinterpret_cast<uint2 *>(smem + L.grp);
+  uint32_t *sub = reinterpret_cast<uint32_t *>(smem + L.sub);
+  short *ca = reinterpret_cast<short *>(smem + L.ca);
+  short *cb = reinterpret_cast<short *>(smem + L.cb);
+  short *sy = reinterpret_cast<short *>(smem + L.sy);
+  StreamShared *sh = reinterpret_cast<StreamShared *>(smem + L.sh);
+  int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
+  uint8_t *s_shift = smem + L.shift;
+  uint32_t *s_shiftp = reinterpret_cast<uint32_t *>(smem + L.shiftp);
+
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const long long c_in = clock64();
+  DecFrame *df = ws.frames + f;
+  if (df->status) return;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
+  if (tid < 256) {
+    const int sc = (int8_t)tid;
+    s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
+  } else if (tid < 384) {
+    s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
+  } else if (tid < 448) {
+    // The same shifts as packed pairs in tile_plane's register order.
+    const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
+    s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
+  }
+  GrpTables tb;
+  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const int r = r0 + (int)blockIdx.x;
+  {
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0;
+    const int n16 = (g.row_block + 15) >> 4;
+    for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym)[k] = z;
+  }
+  __syncthreads();
+
+  if (tid == 0) {
+    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
+    st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
+  }
+  const int bad = decode_stream<true>(
+      p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
+      (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
+      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub,
+      ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
+      ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
+  if (bad) {   // uniform: every lane gets the same verdict
+    if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
+    return;
+  }
+
+  const long long c_p2 = clock64();
+  const int ycbcr = df->ycbcr;
+  const int cols = COLS ? COLS : g.cols;
+  // ---- phase 2: inverse transform, colour inverse and stores ----
+  // Two adjacent lanes share a tile (transform_store_pair).  The decoded symbols
+  // stay read-only in LDS: no barrier, no second pass over them.
+  uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
+  const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
+#pragma unroll 1
+  for (int it = tid; it < 2 * cols; it += kDecThreads)
+    transform_store_pair<COLS>(g, cols, sym, low, s_unmap, s_shift, s_shiftp, ycbcr, it >> 1, it & 1, r, img);
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
   if ((tid & 63) == 0) {
@@ -1839,7 +1767,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // Block rows [r0, r1) only (row-sharded decode: every rank decodes the small
   // LRES stream and walks all row headers, then its own FRES rows).
   const int nrows = r1 - r0;
-  const unsigned gx = (unsigned)((g.cols + 255) / 256);
+  const unsigned gx = (unsigned)((2 * g.cols + 255) / 256);   // k_tile_inv: two lanes per tile
   // Fused row kernel when the row's symbols and the decode tables fit the 160 KiB
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;

@@ -63,13 +63,15 @@ def _pad(t, n):
     return out
 
 
-def encode_sharded(backend, rows, cols, channels, use_blocks, group=None):
-    """Run the sharded encode.  Returns the packed stream (uint8 numpy array) on
-    rank 0 and None elsewhere.  `backend` provides:
+def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=True):
+    """Run the sharded encode.  Returns the packed stream on rank 0 (a uint8 numpy
+    array; with host=False whatever backend.assemble leaves where it was built --
+    the engine backend returns a CUDA tensor, sparing the 268 MB D2H copy of a
+    16384x16384 stream) and None elsewhere.  `backend` provides:
         stats(r0, r1)          -> (hist int64[261], low uint8[C*(r1-r0)*cols])   comm tensors
         row_bits(hist_global)  -> int32[r1-r0]
         emit(all_bits int32[rows], start, end) -> uint8[end-start]   (the local byte range)
-        assemble(low_full uint8[C*rows*cols], all_bits, rel_full uint8[total]) -> numpy uint8
+        assemble(low_full uint8[C*rows*cols], all_bits, rel_full uint8[total], host) -> numpy uint8 / tensor
     All tensors live where the process group can move them (CUDA for nccl/RCCL,
     CPU for gloo)."""
     import torch
@@ -124,7 +126,7 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None):
     for ll, (p0, p1) in zip(low_list, parts):
         if p1 > p0:
             lf[:, p0:p1, :] = ll[: channels * (p1 - p0) * cols].view(channels, p1 - p0, cols)
-    return backend.assemble(low_full, all_bits, rel_full)
+    return backend.assemble(low_full, all_bits, rel_full, host)
 
 
 class EngineBackend:
@@ -181,7 +183,7 @@ class EngineBackend:
         torch.cuda.synchronize(self.dev)
         return self._to_comm(rel[start:end])
 
-    def assemble(self, low_full, all_bits, rel_full):
+    def assemble(self, low_full, all_bits, rel_full, host=True):
         import torch
         import himg_amd
         cap = himg_amd.max_packed_size(self.W, self.H, self.C)
@@ -195,7 +197,8 @@ class EngineBackend:
         torch.cuda.synchronize(self.dev)
         if int(status[0]) != 0:
             raise himg_amd.HimgError(-int(status[0]), "sharded assemble failed")
-        return out[: int(size[0])].cpu().numpy()
+        out = out[: int(size[0])]
+        return out.cpu().numpy() if host else out
 
 
 # ---------------------------------------------------------------------------

@@ -91,7 +91,7 @@ class StubBackend:
         rel = self.stream[off + self.tr["fres_tree_bytes"]: off + sz]
         return torch.from_numpy(rel[start:end].copy())
 
-    def assemble(self, low_full, all_bits, rel_full):
+    def assemble(self, low_full, all_bits, rel_full, host=True):
         assert np.array_equal(low_full.numpy(), self.tr["lowres"]), "gathered low-res plane is wrong"
         off, sz = self.chunks["FRES"]
         head = self.stream[: off + self.tr["fres_tree_bytes"]]
