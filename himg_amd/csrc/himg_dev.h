@@ -32,6 +32,7 @@ struct Geom {
   int fix_t2;                // decoder, opt-in: accept the encoder's own compressible streams (see himg_hip.h)
   int lres_serial;           // decoder test knob: distrust the parallel LRES chain, take the serial fallback
   int max_sub;               // decoder: longest sub-sequence in bits (4096; tests lower it to force several chunks per stream)
+  int lead_bits;             // decoder: lead-in before a lane's nominal start (lean_fixpoint; 0 = start blind)
   long long frame_bytes;     // W*H*stride
   long long fres_size;       // rows*row_block
 };

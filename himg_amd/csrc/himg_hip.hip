@@ -109,6 +109,7 @@ struct himg_hip_ctx {
   size_t host_bytes = 0;   // bytes of the last host-API result still resident in h_out
   int fix_t2 = 0;          // HIMG_OPT_FIX_T2 (or HIMG_FIX_T2=1 in the environment)
   int max_sub = 4096;      // HIMG_MAX_SUB_BITS: test knob, see Geom::max_sub
+  int lead_bits = 64;      // HIMG_LEAD_BITS: tuning knob, see Geom::lead_bits
   int lres_serial = 0;     // HIMG_FORCE_LRES_SERIAL=1: test knob, see Geom::lres_serial
   // Batched host API: H2D of frame i+1, kernels of frame i and D2H of frame i-1 overlap
   // on three streams; staging is double buffered.
@@ -182,6 +183,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->use_blocks = g->rows > 1 ? 1 : 0;                   // block_size < in_size
   g->fix_t2 = 0;
   g->max_sub = 4096;
+  g->lead_bits = 64;
   g->lres_serial = 0;
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
@@ -215,6 +217,10 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   if (const char *e = std::getenv("HIMG_MAX_SUB_BITS")) {
     const int v = std::atoi(e);
     if (v >= 128 && v <= 4096 && v % 32 == 0) ctx->max_sub = v;
+  }
+  if (const char *e = std::getenv("HIMG_LEAD_BITS")) {
+    const int v = std::atoi(e);
+    if (v >= 0 && v <= 4096) ctx->lead_bits = v;
   }
   // Companding LUT for every magnitude an int16 can take.
   std::vector<uint8_t> lut(32769);
@@ -505,6 +511,7 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
   g.fix_t2 = ctx->fix_t2;
   g.max_sub = ctx->max_sub;
+  g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   if (g.rows + 1 > 65535 || batch * g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if ((in_stride & 3) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
@@ -536,6 +543,7 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
   g.fix_t2 = ctx->fix_t2;
   g.max_sub = ctx->max_sub;
+  g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
   if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");

@@ -697,12 +697,24 @@ __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, 
                                               uint32_t first, bool active, uint32_t lim,
                                               uint32_t *start_io, uint32_t *endpos_io,
                                               uint32_t *cnt_io, uint32_t *rounds, bool warm,
-                                              long long *c_first = nullptr) {
+                                              uint32_t lead_bits, long long *c_first = nullptr) {
   const int tid = threadIdx.x;
   const long long t_in = clock64();
   uint32_t start = *start_io, endpos = *endpos_io, cnt = *cnt_io;
   bool dirty = active;
   if (tid == 0 && !warm) start = first;
+  // Lead-in: instead of starting blind at its nominal boundary, a lane decodes the
+  // last lead_bits of its left neighbour's range first.  Huffman codes resynchronise
+  // within a few tokens, so the first token boundary at or past the nominal start
+  // found that way is almost always the true one, and round 1 is then already the
+  // final round (1 + lead_bits/sub passes over the payload instead of 2+).  A lane
+  // that did not synchronise is corrected by the rounds below as before.
+  if (!warm && tid > 0 && active && lead_bits) {
+    const uint32_t from = start - first > lead_bits ? start - lead_bits : first;
+    uint32_t guess, none;
+    lean_count(rd, tb, from, start, &guess, &none);
+    start = guess;
+  }
   if (warm) {
     dirty = (tid == 0) && (first != start);
     if (dirty) start = first;
@@ -844,8 +856,8 @@ template <bool FUSED>
 __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
-                             uint32_t *stats, uint32_t max_sub, const uint32_t *pre_start = nullptr,
-                             const uint32_t *pre_off = nullptr) {
+                             uint32_t *stats, uint32_t max_sub, uint32_t lead_bits,
+                             const uint32_t *pre_start = nullptr, const uint32_t *pre_off = nullptr) {
   const int tid = threadIdx.x;
   if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
   __syncthreads();
@@ -887,7 +899,7 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
       st_rounds += pre_off[kDecThreads + 3];
     } else {
       long long c_first = 0;
-      lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false, &c_first);
+      lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false, lead_bits, &c_first);
       c_r1 += c_first;
       off = block_scan_u64(cnt, sh->sm64, &tot);
     }
@@ -993,7 +1005,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
                                        out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8,
-                                       (uint32_t)g.max_sub);
+                                       (uint32_t)g.max_sub, (uint32_t)g.lead_bits);
   if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
 }
 
@@ -1094,7 +1106,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     endpos = rel0 + ws.spec_endpos[slot * kDecThreads + tid];
     cnt = ws.spec_cnt[slot * kDecThreads + tid];
   }
-  lean_fixpoint(rd, tb, &sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX);
+  lean_fixpoint(rd, tb, &sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX, (uint32_t)g.lead_bits);
   unsigned long long tot;
   block_scan_u64(cnt, sh.sm64, &tot);
   ws.spec_start[slot * kDecThreads + tid] = start - rel0;
@@ -1658,7 +1670,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const int bad = decode_stream<true>(
       p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
       (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
-      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub,
+      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
       ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
       ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
   if (bad) {   // uniform: every lane gets the same verdict
@@ -1731,7 +1743,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, con
       const bool active = my_b0 < rel_end;
       const int last_active = (int)((rel_end - rel0 - 1u) / sb);
       uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
-      lean_fixpoint(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false);
+      lean_fixpoint(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, (uint32_t)g.lead_bits);
       unsigned long long tot;
       const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
       l_start[tid] = start - rel0;
