@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=24, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams (one engine context each) the batch is split over, so the short "
                          "serial kernels of one group overlap the wide kernels of the other")
@@ -469,8 +469,12 @@ def main():
             # (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration)): these kernels are
             # instruction-bound, the HBM fraction is an upper bound on what is left.
             valu_busy = None
-            ppath = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
-            if os.path.exists(ppath) and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
+            import glob
+            import re
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")),
+                           key=lambda q: [int(x) for x in re.findall(r"\d+", os.path.basename(q))])
+            ppath = cands[-1] if cands else ""   # the newest committed PMC summary
+            if ppath and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
                 for k, v in json.load(open(ppath)).items():
                     if k.split("<")[0] == dom.strip("()").split("<")[0] and v.get("dur_us"):
                         valu_busy = round(v.get("SQ_INSTS_VALU", 0) * 4 / (1024 * v["dur_us"] * 1e-6 * 2.4e9), 3)

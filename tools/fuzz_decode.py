@@ -21,7 +21,8 @@ eng = himg_amd.Engine(0)
 rng = np.random.default_rng(7)
 bad_cases = 0
 for kind, w, h, q in [("randtile", 4096, 64, 50), ("randtile", 4096, 32, 90), ("gradn", 1024, 256, 70),
-                      ("rand", 512, 128, 50), ("randtile", 200, 116, 70)]:
+                      ("rand", 512, 128, 50), ("randtile", 200, 116, 70), ("randtile", 4400, 24, 50),
+                      ("rand", 4400, 16, 90)]:
     img = himg_amd.synth(kind, 5, w, h)
     good = ol.oracle_encode(img, q, True)
     if ol.oracle_decode(good)[0] != 0:
@@ -30,7 +31,12 @@ for kind, w, h, q in [("randtile", 4096, 64, 50), ("randtile", 4096, 32, 90), ("
     acc = rej = 0
     for t in range(N):
         bad = good.copy()
+        # Mostly the entropy-coded payloads; every 7th mutation hits the companding
+        # map or the shift table instead (large dequantised coefficients: the
+        # transform's int32 path and its int16 wrap).
         off, sz = ch["FRES" if t % 3 else "LRES"]
+        if t % 7 == 3:
+            off, sz = ch["FMAP" if t % 2 else "QCFG"]
         nflip = 1 + (t % 5 == 0)
         for _ in range(nflip):
             bad[int(rng.integers(off, off + sz))] ^= 1 << int(rng.integers(0, 8))
