@@ -517,6 +517,9 @@ constexpr uint32_t kMinSubBits = 128;  // shortest sub-sequence a lane decodes (
 
 struct GrpTables {
   const uint2 *grp;           // LDS, 1 << kLutBits entries
+  const uint32_t *gx, *gy;    // the same table as two arrays (count-only kernels: the hot
+                              // read is .y alone, and a stride-2 dword read of the
+                              // interleaved table uses every other LDS bank only)
   const uint32_t *sub;        // LDS, second-level entries (codes longer than kLutBits)
   const short *ca, *cb, *sy;  // LDS tree nodes
 };
@@ -606,7 +609,7 @@ __device__ __forceinline__ uint32_t class_base(uint32_t c) {
 // case is branch free; `single` is true only in a lane's last kLutBits bits, and
 // codes longer than the table are rare.  bad is set (never cleared) on symbols
 // the reference rejects (huffman_dec.cpp:349-352).
-template <bool WANT_BYTES>
+template <bool WANT_BYTES, bool SOA = false>
 __device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool single,
                                           uint32_t *nbits, uint32_t *count, uint32_t *bytes,
                                           bool *bad) {
@@ -614,6 +617,7 @@ __device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool 
   const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
   uint32_t y, bx = 0;
   if (WANT_BYTES) { const uint2 e = t.grp[idx]; bx = e.x; y = e.y; }
+  else if (SOA) y = t.gy[idx];
   else y = reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
   uint32_t tb = y & 15u, eb = (y >> 4) & 15u, cb = (y >> 8) & 511u, pre = 0, by = bx;
   if (single) {
@@ -633,7 +637,7 @@ __device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool 
     // Code longer than the table (huffman_dec.cpp:291-328): the second-level
     // table resolves it with one more read; whatever is deeper still walks the
     // tree from the node found there.
-    const uint32_t ex = WANT_BYTES ? bx : t.grp[idx].x;
+    const uint32_t ex = WANT_BYTES ? bx : (SOA ? t.gx[idx] : t.grp[idx].x);
     int node = (int)(ex & 0xffffu), len = (int)((ex >> 16) & 0x7fffu);
     if (ex >> 31) {
       const uint32_t e2 = t.sub[((ex >> 8) & 0xffffu) +
@@ -667,6 +671,7 @@ __device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool 
 
 // Count pass: the tokens that start in [pos, lim).  Returns where the last one
 // ends and how many symbols they produce.
+template <bool SOA = false>
 __device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint32_t pos,
                                            uint32_t lim, uint32_t *endpos, uint32_t *count) {
   uint32_t c = 0;
@@ -676,7 +681,7 @@ __device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint
     bool bad = false;
     do {
       uint32_t nbits, cnt, by;
-      lean_step<false>(rd, t, (int)pos > limk, &nbits, &cnt, &by, &bad);
+      lean_step<false, SOA>(rd, t, (int)pos > limk, &nbits, &cnt, &by, &bad);
       pos += nbits;
       c += cnt;
     } while (pos < lim);
@@ -693,6 +698,7 @@ __device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint
 // lanes whose start changes decode again.
 // Lanes whose range lies beyond the payload (`active` false) own nothing and stay
 // out of it: passing the chain's end along them would cost one round per lane.
+template <bool SOA = false>
 __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, StreamShared *sh,
                                               uint32_t first, bool active, uint32_t lim,
                                               uint32_t *start_io, uint32_t *endpos_io,
@@ -712,7 +718,7 @@ __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, 
   if (!warm && tid > 0 && active && lead_bits) {
     const uint32_t from = start - first > lead_bits ? start - lead_bits : first;
     uint32_t guess, none;
-    lean_count(rd, tb, from, start, &guess, &none);
+    lean_count<SOA>(rd, tb, from, start, &guess, &none);
     start = guess;
   }
   if (warm) {
@@ -720,7 +726,7 @@ __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, 
     if (dirty) start = first;
   }
   for (;;) {
-    if (dirty) lean_count(rd, tb, start, lim, &endpos, &cnt);
+    if (dirty) lean_count<SOA>(rd, tb, start, lim, &endpos, &cnt);
     sh->nxt[tid + 1] = endpos;
     __syncthreads();
     if (c_first && *c_first == 0) *c_first = clock64() - t_in;
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   load_dec_tables(ws, df, f, strm, grp, sub, ca, cb, sy);
   __syncthreads();
   GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
                                        out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8,
                                        (uint32_t)g.max_sub, (uint32_t)g.lead_bits);
@@ -1057,7 +1063,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
   }
   load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
   GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
   const unsigned long long rem = P1 - cur;
@@ -1167,7 +1173,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
   if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
   GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
   const unsigned long long rem = P1 - cur;
@@ -1653,7 +1659,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
   }
   GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int r = r0 + (int)blockIdx.x;
   {
     uint4 z;
@@ -1710,17 +1716,35 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, const uint8_t *packed,
                                                            size_t in_stride, const uint32_t *sizes,
                                                            int r0) {
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ __attribute__((aligned(16))) uint32_t gx[1 << kLutBits], gy[1 << kLutBits];
   __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
-  const int failed = df->status;   // set by earlier kernels only: the same for every lane
-  if (!failed) load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
+  // One read for the whole workgroup: the LRES kernels run concurrently on the
+  // other stream and may flag the frame while this kernel starts.
+  if (tid == 0) sh.flag = df->status;
+  __syncthreads();
+  const int failed = sh.flag;
+  if (!failed) {   // load_dec_tables with the group table split into its two halves
+    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
+    const int nn = df->s[1].num_nodes;
+    for (int k = tid; k < nn; k += kDecThreads) {
+      ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
+    }
+    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
+      const uint4 q = gg[k];
+      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);
+      reinterpret_cast<uint2 *>(gy)[k] = make_uint2(q.y, q.w);
+    }
+    const uint32_t *gs = ws.sub + ((size_t)f * 2 + 1) * kSubEntries;
+    for (int k = tid; k < kSubEntries; k += kDecThreads) sub[k] = gs[k];
+  }
   __syncthreads();
   GrpTables tb;
-  tb.grp = grp; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = nullptr; tb.gx = gx; tb.gy = gy; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const uint8_t *p = packed + (size_t)f * in_stride;
   const int r = r0 + (int)blockIdx.x;
   {
@@ -1743,7 +1767,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, con
       const bool active = my_b0 < rel_end;
       const int last_active = (int)((rel_end - rel0 - 1u) / sb);
       uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
-      lean_fixpoint(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, (uint32_t)g.lead_bits);
+      lean_fixpoint<true>(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, (uint32_t)g.lead_bits);
       unsigned long long tot;
       const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
       l_start[tid] = start - rel0;
@@ -1794,6 +1818,14 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     prof_begin(prof, "k_dec_rowwalk", side);
     hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride);
     prof_end(prof, side);
+    // The FRES fixpoint rounds need the row offsets only, not the low-res plane:
+    // they fill the CUs the latency-bound LRES kernels leave idle.
+    if (wps && nrows > 0) {
+      prof_begin(prof, "k_row_count", side);
+      hipLaunchKernelGGL(k_row_count, dim3(nrows, batch), dim3(kDecThreads), 0, side, g, ws, d_packed,
+                         in_stride, d_sizes, r0);
+      prof_end(prof, side);
+    }
     (void)hipEventRecord(ev_join, side);
   } else {
     HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride);
@@ -1813,7 +1845,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                 d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-    if (nrows > 0)
+    if (!side && nrows > 0)
       HIMG_LAUNCH(k_row_count, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, r0);
     const uint32_t lds = fused_layout(g.row_block).total;
