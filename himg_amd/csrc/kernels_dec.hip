@@ -978,7 +978,8 @@ __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, const uint8_t *packed,
                                                           size_t in_stride, const uint32_t *sizes,
-                                                          int first_block, int lres_fallback_only) {
+                                                          int first_block, int lres_fallback_only,
+                                                          int use_row_count) {
   __shared__ uint32_t win[kWinBytes / 4 + 1];
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
   __shared__ uint32_t sub[kSubEntries];
@@ -993,6 +994,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   const uint8_t *p = packed + (size_t)f * in_stride;
   uint32_t pay_off, pay_len, out_size;
   uint8_t *out;
+  const uint32_t *pre_start = nullptr, *pre_off = nullptr;   // k_row_count's fixpoint, if it ran
   if (strm == 0) {
     pay_off = df->s[0].payload_off;
     pay_len = df->s[0].chunk_end - pay_off;
@@ -1004,6 +1006,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     pay_len = ws.row_len[(size_t)f * g.rows + r];
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
+    if (use_row_count) {
+      pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+    }
   }
   load_dec_tables(ws, df, f, strm, grp, sub, ca, cb, sy);
   __syncthreads();
@@ -1011,7 +1017,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
   tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
                                        out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8,
-                                       (uint32_t)g.max_sub, (uint32_t)g.lead_bits);
+                                       (uint32_t)g.max_sub, (uint32_t)g.lead_bits, pre_start, pre_off);
   if (bad && threadIdx.x == 0) atomicMax(&df->status, fmt_err(strm == 0 ? 4 : 7, 1));
 }
 
@@ -1820,7 +1826,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     prof_end(prof, side);
     // The FRES fixpoint rounds need the row offsets only, not the low-res plane:
     // they fill the CUs the latency-bound LRES kernels leave idle.
-    if (wps && nrows > 0) {
+    if (nrows > 0) {
       prof_begin(prof, "k_row_count", side);
       hipLaunchKernelGGL(k_row_count, dim3(nrows, batch), dim3(kDecThreads), 0, side, g, ws, d_packed,
                          in_stride, d_sizes, r0);
@@ -1842,7 +1848,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);
   if (wps) {
     HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
+                d_sizes, 0, 1, 0);  // LRES serial fallback (no-op when verified)
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (!side && nrows > 0)
@@ -1866,10 +1872,13 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   } else {
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                d_sizes, 0, 1);  // LRES serial fallback (no-op when verified)
-    if (nrows > 0)
+                d_sizes, 0, 1, 0);  // LRES serial fallback (no-op when verified)
+    if (!side && nrows > 0)
+      HIMG_LAUNCH(k_row_count, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
+                  d_sizes, r0);
+    if (nrows > 0)   // write pass only: the rounds were k_row_count's, at twice the occupancy
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, 1 + r0, 1);
+                  d_sizes, 1 + r0, 1, 1);
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (nrows > 0) HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
   }
