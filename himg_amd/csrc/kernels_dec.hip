@@ -1490,13 +1490,19 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
   (void)shift;
 }
 
-// One lane of a lane pair: lane s transforms channels 2s and 2s+1 of tile u in
-// block row v (packed int16 butterflies, see tile_plane), the pair swaps halves
-// with one DPP move per register, and lane s finishes pixel rows 4s..4s+3 --
+// One lane of a lane pair (lanes l and l + 32 of a wave: each half-wave then reads
+// 32 adjacent symbol bytes of ONE plane per LDS instruction, free of bank
+// conflicts): lane s transforms channels 2s and 2s+1 of tile u in block row v
+// (packed int16 butterflies, see tile_plane), the pair swaps halves with one
+// v_permlane32_swap per register pair, and lane s finishes pixel rows 4s..4s+3 --
 // colour inverse on packed pairs (ycbcr.cpp:54-82), then two 16-byte stores per
 // pixel row.  sym: the block row's symbols (channel c, scan index k, tile u at
 // sym[(c*64 + k)*cols + u]), LDS or HBM; low: the frame's low-res planes.  Both
-// lanes of a pair must be active.
+// lanes of a pair must be active (pair_tile / pair_half give the mapping).
+// Item index -> (tile, half): 32 tiles per wave, lanes 0..31 half 0, lanes 32..63 half 1.
+__device__ __forceinline__ int pair_tile(int it) { return (it >> 6) * 32 + (it & 31); }
+__device__ __forceinline__ int pair_half(int it) { return (it >> 5) & 1; }
+
 template <int COLS>
 __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt, const uint8_t *sym,
                                                      const uint8_t *low, const int16_t *s_unmap,
@@ -1529,18 +1535,17 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
         for (int i = 0; i < 16; ++i) QB[i] = O[i];
       }
     }
-    // Swap halves inside the lane pair (quad_perm [1,0,3,2]).
+    // Swap halves between lane l and lane l + 32: one v_permlane32_swap per register
+    // pair hands the upper lanes the partner's rows 4..7 of channels 0/1 and the
+    // lower lanes the partner's rows 0..3 of channels 2/3 -- afterwards either half
+    // holds its four pixel rows of all four channels, no selects.
     uint32_t ch0[8], ch1[8], ch2[8], ch3[8];   // [r*2+h]: pixel row 4s+r, x = 4h..4h+3
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const uint32_t a_lo = __builtin_amdgcn_update_dpp(0u, QA[i], 0xB1, 0xf, 0xf, true);
-      const uint32_t a_hi = __builtin_amdgcn_update_dpp(0u, QA[8 + i], 0xB1, 0xf, 0xf, true);
-      const uint32_t b_lo = __builtin_amdgcn_update_dpp(0u, QB[i], 0xB1, 0xf, 0xf, true);
-      const uint32_t b_hi = __builtin_amdgcn_update_dpp(0u, QB[8 + i], 0xB1, 0xf, 0xf, true);
-      ch0[i] = s ? a_hi : QA[i];
-      ch1[i] = s ? b_hi : QB[i];
-      ch2[i] = s ? QA[8 + i] : a_lo;
-      ch3[i] = s ? QB[8 + i] : b_lo;
+      const auto ra = __builtin_amdgcn_permlane32_swap(QA[i], QA[8 + i], false, false);
+      const auto rb = __builtin_amdgcn_permlane32_swap(QB[i], QB[8 + i], false, false);
+      ch0[i] = ra[0]; ch2[i] = ra[1];
+      ch1[i] = rb[0]; ch3[i] = rb[1];
     }
     const int bw = min(8, g.W - 8 * u);
     const int bh = min(8, g.H - 8 * v);
@@ -1598,8 +1603,8 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
 }
 
 // k_tile_inv: the transform of the unfused path (rows too wide for LDS): the
-// symbols come from HBM (ws.fres_sym, written by k_dec_huff); two adjacent lanes
-// per tile, 128 tiles per workgroup.
+// symbols come from HBM (ws.fres_sym, written by k_dec_huff); two lanes per tile,
+// 128 tiles per workgroup.
 __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames, int v0) {
   __shared__ int16_t s_unmap[256];   // indexed by the code byte
   __shared__ uint8_t s_shift[2][64];
@@ -1618,11 +1623,12 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
     }
   }
   __syncthreads();
-  const int it = blockIdx.x * 256 + threadIdx.x;   // (tile, half): pairs never straddle the edge
-  if (it >= 2 * g.cols) return;
+  const int it = blockIdx.x * 256 + threadIdx.x;   // (tile, half): both lanes of a pair are in or out
+  if (pair_tile(it) >= g.cols) return;
   transform_store_pair<0>(g, g.cols, ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)v * g.row_block,
                           ws.low + (size_t)f * ws.plane_stride, s_unmap, &s_shift[0][0], &s_shiftp[0][0],
-                          df->ycbcr, it >> 1, it & 1, v, out_frames + (size_t)f * ((size_t)g.W * g.H * g.C));
+                          df->ycbcr, pair_tile(it), pair_half(it), v,
+                          out_frames + (size_t)f * ((size_t)g.W * g.H * g.C));
 }
 
 // COLS != 0 fixes the tile count per block row at compile time (512 = 4096-pixel
@@ -1699,8 +1705,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
   const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
 #pragma unroll 1
-  for (int it = tid; it < 2 * cols; it += kDecThreads)
-    transform_store_pair<COLS>(g, cols, sym, low, s_unmap, s_shift, s_shiftp, ycbcr, it >> 1, it & 1, r, img);
+  for (int it = tid; it < ((cols + 31) >> 5) * 64; it += kDecThreads)
+    if (pair_tile(it) < cols)
+      transform_store_pair<COLS>(g, cols, sym, low, s_unmap, s_shift, s_shiftp, ycbcr, pair_tile(it),
+                                 pair_half(it), r, img);
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
   if ((tid & 63) == 0) {
@@ -1809,7 +1817,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // Block rows [r0, r1) only (row-sharded decode: every rank decodes the small
   // LRES stream and walks all row headers, then its own FRES rows).
   const int nrows = r1 - r0;
-  const unsigned gx = (unsigned)((2 * g.cols + 255) / 256);   // k_tile_inv: two lanes per tile
+  const unsigned gx = (unsigned)((((g.cols + 31) / 32) * 64 + 255) / 256);   // k_tile_inv: two lanes per tile, 32 tiles per wave
   // Fused row kernel when the row's symbols and the decode tables fit the 160 KiB
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;
