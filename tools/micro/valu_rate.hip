@@ -1,0 +1,153 @@
+// Issue rate of the VALU instructions the codec kernels lean on (MI355X).
+// Each wave runs 8 independent dependency chains of one opcode; with 8 waves per
+// SIMD the result is wave-instructions per SIMD-cycle (1/4 = full rate for wave64).
+// Build: hipcc -O3 --offload-arch=gfx950 tools/micro/valu_rate.hip -o tools/micro/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define CHAIN8(OP)                                                         \
+  for (int i = 0; i < iters; ++i) {                                        \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                        \
+      OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)              \
+    }                                                                      \
+  }
+
+#define OP_ADD(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_PKADD(x) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_PKSUB(x) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_PKASHR(x) asm volatile("v_pk_ashrrev_i16 %0, 3, %0 op_sel_hi:[0,1]" : "+v"(x));
+#define OP_PKLSHL(x) asm volatile("v_pk_lshlrev_b16 %0, %1, %0" : "+v"(x) : "v"(k));
+#define OP_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(k), "s"(sel));
+#define OP_LERP(x) asm volatile("v_lerp_u8 %0, %0, %1, %2" : "+v"(x) : "v"(k), "s"(sel));
+#define OP_SAT(x) asm volatile("v_sat_pk_u8_i16 %0, %0" : "+v"(x));
+#define OP_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(k));
+#define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, %1, 11" : "+v"(x) : "v"(k));
+#define OP_OR3(x) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+#define OP_ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+#define OP_DPP(x) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));
+#define OP_CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(k) : );
+#define OP_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_MAD24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+
+#define OP_X16(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[6:7]" : "+v"(x) : "v"(k));
+#define OP_X17(x) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X18(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X19(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X20(x) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
+#define OP_X21(x) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(x) : "v"(k));
+#define OP_X22(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X23(x) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+#define OP_X24(x) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X25(x) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+#define OP_X26(x) asm volatile("v_ffbh_u32 %0, %0" : "+v"(x));
+#define OP_X27(x) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+#define OP_X28(x) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(x) : "v"(k));
+#define OP_X29(x) asm volatile("v_add_u32 %0, s6, %0" : "+v"(x));
+#define OP_X30(x) asm volatile("v_add_u32 %0, 5, %0" : "+v"(x));
+#define OP_X31(x) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X32(x) asm volatile("v_ashrrev_i32 %0, 3, %0" : "+v"(x));
+#define OP_X33(x) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X34(x) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(x));
+#define OP_X35(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(k) : "vcc");
+
+template <int WHICH>
+__global__ __launch_bounds__(512) void k_rate(uint32_t *out, int iters, uint32_t k, uint32_t sel) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  if (WHICH == 0) { CHAIN8(OP_ADD) }
+  if (WHICH == 1) { CHAIN8(OP_PKADD) }
+  if (WHICH == 2) { CHAIN8(OP_PKSUB) }
+  if (WHICH == 3) { CHAIN8(OP_PKASHR) }
+  if (WHICH == 4) { CHAIN8(OP_PKLSHL) }
+  if (WHICH == 5) { CHAIN8(OP_PERM) }
+  if (WHICH == 6) { CHAIN8(OP_LERP) }
+  if (WHICH == 7) { CHAIN8(OP_SAT) }
+  if (WHICH == 8) { CHAIN8(OP_LSHLADD) }
+  if (WHICH == 9) { CHAIN8(OP_BFE) }
+  if (WHICH == 10) { CHAIN8(OP_OR3) }
+  if (WHICH == 11) { CHAIN8(OP_ADD3) }
+  if (WHICH == 12) { CHAIN8(OP_DPP) }
+  if (WHICH == 13) { CHAIN8(OP_CNDMASK) }
+  if (WHICH == 14) { CHAIN8(OP_MULLO) }
+  if (WHICH == 15) { CHAIN8(OP_MAD24) }
+  if (WHICH == 16) { CHAIN8(OP_X16) }
+  if (WHICH == 17) { CHAIN8(OP_X17) }
+  if (WHICH == 18) { CHAIN8(OP_X18) }
+  if (WHICH == 19) { CHAIN8(OP_X19) }
+  if (WHICH == 20) { CHAIN8(OP_X20) }
+  if (WHICH == 21) { CHAIN8(OP_X21) }
+  if (WHICH == 22) { CHAIN8(OP_X22) }
+  if (WHICH == 23) { CHAIN8(OP_X23) }
+  if (WHICH == 24) { CHAIN8(OP_X24) }
+  if (WHICH == 25) { CHAIN8(OP_X25) }
+  if (WHICH == 26) { CHAIN8(OP_X26) }
+  if (WHICH == 27) { CHAIN8(OP_X27) }
+  if (WHICH == 28) { CHAIN8(OP_X28) }
+  if (WHICH == 29) { CHAIN8(OP_X29) }
+  if (WHICH == 30) { CHAIN8(OP_X30) }
+  if (WHICH == 31) { CHAIN8(OP_X31) }
+  if (WHICH == 32) { CHAIN8(OP_X32) }
+  if (WHICH == 33) { CHAIN8(OP_X33) }
+  if (WHICH == 34) { CHAIN8(OP_X34) }
+  if (WHICH == 35) { CHAIN8(OP_X35) }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+template <int WHICH>
+static void run(const char *name, uint32_t *d_out) {
+  const int iters = 2000, blocks = 256 * 4, threads = 512;   // 4 x 8 waves per CU = 8 per SIMD
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, d_out, 10, 3u, 0x05040100u);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 3u, 0x05040100u);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double winstr = (double)blocks * (threads / 64) * iters * 64.0;   // wave-instructions
+  const double per_simd_cycle = winstr / (ms * 1e-3 * 2.4e9 * 256 * 4);
+  printf("%-20s %.3f ms  %.3f wave-instr per SIMD-cycle (at 2.4 GHz; 0.25 = full rate)\n", name, ms, per_simd_cycle);
+}
+
+int main() {
+  uint32_t *d_out;
+  hipMalloc(&d_out, 256 * 4 * 512 * 4);
+  run<0>("v_add_u32", d_out);
+  run<1>("v_pk_add_u16", d_out);
+  run<2>("v_pk_sub_i16", d_out);
+  run<3>("v_pk_ashrrev_i16", d_out);
+  run<4>("v_pk_lshlrev_b16", d_out);
+  run<5>("v_perm_b32", d_out);
+  run<6>("v_lerp_u8", d_out);
+  run<7>("v_sat_pk_u8_i16", d_out);
+  run<8>("v_lshl_add_u32", d_out);
+  run<9>("v_bfe_u32", d_out);
+  run<10>("v_or3_b32", d_out);
+  run<11>("v_add3_u32", d_out);
+  run<12>("v_mov_b32_dpp", d_out);
+  run<13>("v_cndmask_b32", d_out);
+  run<14>("v_mul_lo_u32", d_out);
+  run<15>("v_mad_u32_u24", d_out);
+  run<16>("v_cndmask_b32_e64 sgpr", d_out);
+  run<17>("v_bfi_b32", d_out);
+  run<18>("v_and_b32", d_out);
+  run<19>("v_xor_b32", d_out);
+  run<20>("v_lshlrev_b32", d_out);
+  run<21>("v_lshrrev_b32 vgpr", d_out);
+  run<22>("v_min_u32", d_out);
+  run<23>("v_med3_i32", d_out);
+  run<24>("v_sub_u32", d_out);
+  run<25>("v_mov_b32", d_out);
+  run<26>("v_ffbh_u32", d_out);
+  run<27>("v_and_or_b32", d_out);
+  run<28>("v_lshl_or_b32", d_out);
+  run<29>("v_add_u32 sgpr", d_out);
+  run<30>("v_add_u32 imm", d_out);
+  run<31>("v_or_b32", d_out);
+  run<32>("v_ashrrev_i32", d_out);
+  run<33>("v_mul_u32_u24", d_out);
+  run<34>("v_bfe_i32", d_out);
+  run<35>("v_cmp+cndmask pair", d_out);
+  return 0;
+}
