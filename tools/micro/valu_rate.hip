@@ -51,8 +51,27 @@
 #define OP_X34(x) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(x));
 #define OP_X35(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(k) : "vcc");
 
+#define OP_X36(x) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(y##x) : "v"(k));
+#define OP_X37(x) asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(y##x) : "v"(k));
+#define OP_X38(x) asm volatile("v_lshl_add_u64 %0, %0, 2, %0" : "+v"(y##x));
+#define OP_X39(x) asm volatile("v_alignbit_b32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+#define OP_X40(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(k) : "vcc");
+#define OP_X41(x) asm volatile("v_cmp_lt_u32_e64 s[6:7], %0, %1" : : "v"(x), "v"(k) : "s6", "s7");
+#define OP_X42(x) asm volatile("v_and_b32 %0, 0x7ff, %0" : "+v"(x));
+#define OP_X43(x) asm volatile("v_and_b32 %0, s6, %0" : "+v"(x));
+#define OP_X44(x) asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X45(x) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x) : "v"(k) : "vcc");
+#define OP_X46(x) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x) : "v"(k));
+#define OP_X47(x) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X48(x) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(x) : "v"(k));
+#define OP_X49(x) asm volatile("v_readfirstlane_b32 s6, %0" : : "v"(x) : "s6");
+#define OP_X50(x) asm volatile("v_sub_u16 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X51(x) asm volatile("v_add_u16 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_X52(x) asm volatile("v_ashrrev_i16 %0, 3, %0" : "+v"(x));
+
 template <int WHICH>
 __global__ __launch_bounds__(512) void k_rate(uint32_t *out, int iters, uint32_t k, uint32_t sel) {
+  unsigned long long ya0 = threadIdx.x, ya1 = ya0 * 3, ya2 = ya0 * 5, ya3 = ya0 * 7, ya4 = ya0 * 9, ya5 = ya0 * 11, ya6 = ya0 * 13, ya7 = ya0 * 17;
   uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   if (WHICH == 0) { CHAIN8(OP_ADD) }
   if (WHICH == 1) { CHAIN8(OP_PKADD) }
@@ -90,7 +109,24 @@ __global__ __launch_bounds__(512) void k_rate(uint32_t *out, int iters, uint32_t
   if (WHICH == 33) { CHAIN8(OP_X33) }
   if (WHICH == 34) { CHAIN8(OP_X34) }
   if (WHICH == 35) { CHAIN8(OP_X35) }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+  if (WHICH == 36) { CHAIN8(OP_X36) }
+  if (WHICH == 37) { CHAIN8(OP_X37) }
+  if (WHICH == 38) { CHAIN8(OP_X38) }
+  if (WHICH == 39) { CHAIN8(OP_X39) }
+  if (WHICH == 40) { CHAIN8(OP_X40) }
+  if (WHICH == 41) { CHAIN8(OP_X41) }
+  if (WHICH == 42) { CHAIN8(OP_X42) }
+  if (WHICH == 43) { CHAIN8(OP_X43) }
+  if (WHICH == 44) { CHAIN8(OP_X44) }
+  if (WHICH == 45) { CHAIN8(OP_X45) }
+  if (WHICH == 46) { CHAIN8(OP_X46) }
+  if (WHICH == 47) { CHAIN8(OP_X47) }
+  if (WHICH == 48) { CHAIN8(OP_X48) }
+  if (WHICH == 49) { CHAIN8(OP_X49) }
+  if (WHICH == 50) { CHAIN8(OP_X50) }
+  if (WHICH == 51) { CHAIN8(OP_X51) }
+  if (WHICH == 52) { CHAIN8(OP_X52) }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(ya0 ^ ya1 ^ ya2 ^ ya3 ^ ya4 ^ ya5 ^ ya6 ^ ya7) ^ a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
 template <int WHICH>
@@ -149,5 +185,22 @@ int main() {
   run<33>("v_mul_u32_u24", d_out);
   run<34>("v_bfe_i32", d_out);
   run<35>("v_cmp+cndmask pair", d_out);
+  run<36>("v_lshrrev_b64", d_out);
+  run<37>("v_lshlrev_b64", d_out);
+  run<38>("v_lshl_add_u64", d_out);
+  run<39>("v_alignbit_b32", d_out);
+  run<40>("v_cmp_lt_u32 (vcc)", d_out);
+  run<41>("v_cmp_lt_u32_e64 (sgpr)", d_out);
+  run<42>("v_and_b32 literal", d_out);
+  run<43>("v_and_b32 sgpr", d_out);
+  run<44>("v_max_i32", d_out);
+  run<45>("v_addc_co_u32", d_out);
+  run<46>("v_lshlrev_b32 vgpr", d_out);
+  run<47>("v_bcnt_u32_b32", d_out);
+  run<48>("v_mbcnt_lo", d_out);
+  run<49>("v_readfirstlane", d_out);
+  run<50>("v_sub_u16", d_out);
+  run<51>("v_add_u16", d_out);
+  run<52>("v_ashrrev_i16", d_out);
   return 0;
 }
