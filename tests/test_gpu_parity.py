@@ -411,6 +411,43 @@ def test_streams_longer_than_one_chunk():
             eng.close()
 
 
+@pytest.mark.parametrize("lead,side", [(0, "1"), (32, "1"), (200, "0"), (4096, "1")])
+def test_lead_in_and_side_stream_do_not_change_results(lead, side):
+    """The lead-in of the speculative sub-sequence decode (HIMG_LEAD_BITS) and the
+    side stream (HIMG_SIDE_STREAM) are pure scheduling: every setting decodes the
+    oracle's streams to the oracle's pixels, on the fused and the generic path,
+    mutated streams included."""
+    import os
+    os.environ["HIMG_LEAD_BITS"] = str(lead)
+    os.environ["HIMG_SIDE_STREAM"] = side
+    try:
+        eng = himg_amd.Engine(0)
+    finally:
+        del os.environ["HIMG_LEAD_BITS"]
+        del os.environ["HIMG_SIDE_STREAM"]
+    try:
+        rng = np.random.default_rng(lead)
+        for kind, w, h, q in [("randtile", 4096, 48, 50), ("rand", 520, 72, 90), ("randtile", 4400, 40, 70),
+                              ("gradn", 1920, 136, 50)]:
+            good = ol.oracle_encode(himg_amd.synth(kind, 3, w, h), q, True)
+            rc, pix = ol.oracle_decode(good)
+            if rc != 0:
+                continue   # trap T2: the reference rejects its own stream
+            _eq(eng.decode(good).ravel(), pix.ravel(), "pixels %dx%d lead %d" % (w, h, lead))
+            fres = _chunks(good)["FRES"]
+            for _ in range(6):
+                bad = good.copy()
+                bad[int(rng.integers(fres[0], fres[0] + fres[1]))] ^= 1 << int(rng.integers(0, 8))
+                rc, pix = ol.oracle_decode(bad)
+                if rc == 0:
+                    _eq(eng.decode(bad).ravel(), pix.ravel(), "pixels of a mutated stream, lead %d" % lead)
+                else:
+                    with pytest.raises(himg_amd.HimgError):
+                        eng.decode(bad)
+    finally:
+        eng.close()
+
+
 def test_lres_serial_fallback():
     """If a mis-speculation runs through a whole LRES chunk the parallel chunk chain
     does not verify and the frame's LRES stream is decoded by one workgroup instead
