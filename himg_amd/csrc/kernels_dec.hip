@@ -1129,6 +1129,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1)) * 8;
     atomicAdd(&st[FIX ? 2 : 0], 1u);
     atomicAdd(&st[FIX ? 3 : 1], rounds);
+    atomicMax(&st[FIX ? 5 : 4], rounds);   // the slowest chunk sets the kernel's duration
   }
 }
 
