@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <vector>  // the reference's headers pull it in (encoder.h:13, decoder.h:13) and its callers rely on that
 
 struct himg_hip_ctx;
 
