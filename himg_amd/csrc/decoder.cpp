@@ -2,6 +2,7 @@
 #include "decoder.h"
 
 #include <iostream>
+#include <new>
 
 #include "ctx_pool.h"
 #include "himg_hip.h"
@@ -29,8 +30,13 @@ bool Decoder::Decode(const uint8_t *packed_data, int packed_size) {
   if (himg_hip_peek(packed_data, size, &w, &h, &c) == HIMG_OK) {
     const size_t need = static_cast<size_t>(w) * h * c;
     if (need > m_capacity) {
-      m_unpacked_data.reset(new uint8_t[need]);
-      m_capacity = need;
+      // Decode returns false, it never throws (decoder.cpp:87-138).
+      m_unpacked_data.reset(new (std::nothrow) uint8_t[need]);
+      m_capacity = m_unpacked_data ? need : 0;
+      if (!m_unpacked_data) {
+        std::cout << "Error: out of memory for a " << w << "x" << h << "x" << c << " image.\n";
+        return false;
+      }
     }
   }
   const int rc = himg_hip_decode_to(m_ctx, packed_data, size, m_unpacked_data.get(), m_capacity, &w, &h, &c);

@@ -138,6 +138,19 @@ struct himg_hip_ctx {
   // Staging for the host-buffer API.
   DevBuf h_in, h_out, h_sizes, h_status;
 
+  // Packed sizes handed to the decoder: the caller's array (or a by-value argument)
+  // may be gone before an asynchronous copy reads it, so the sizes are first copied
+  // into a ctx-owned pinned slot; a slot is reused only after the copy that read it
+  // has run (event).
+  struct SizeRing {
+    static constexpr int kSlots = 4;
+    uint32_t *h[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[kSlots] = {0, 0, 0, 0};
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool busy[kSlots] = {false, false, false, false};
+    int next = 0;
+  } sizes_ring;
+
   // Row-sharded encode state (himg_hip_shard_*).
   struct {
     bool valid = false;
@@ -250,6 +263,10 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->side) hipStreamDestroy(ctx->side);
+  for (int k = 0; k < himg_hip_ctx::SizeRing::kSlots; ++k) {
+    if (ctx->sizes_ring.ev[k]) hipEventDestroy(ctx->sizes_ring.ev[k]);
+    if (ctx->sizes_ring.h[k]) hipHostFree(ctx->sizes_ring.h[k]);
+  }
   ctx->prof.collect();
   if (ctx->pipe.ready) {
     for (int k = 0; k < 2; ++k) {
@@ -328,8 +345,37 @@ static int build_static(const Geom &g, int quality, StaticChunks *sc, ShiftTable
 // ---------------------------------------------------------------------------
 // Workspaces.
 // ---------------------------------------------------------------------------
+// Copy `n` packed sizes into the next pinned slot and start the H2D copy from there.
+static int stage_sizes(himg_hip_ctx *ctx, const uint32_t *src, int n, hipStream_t s) {
+  auto &r = ctx->sizes_ring;
+  const int k = r.next;
+  r.next = (k + 1) % himg_hip_ctx::SizeRing::kSlots;
+  if (!r.ev[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&r.ev[k], hipEventDisableTiming));
+  if (r.busy[k]) HIP_TRY(ctx, hipEventSynchronize(r.ev[k]));
+  if (r.cap[k] < (size_t)n) {
+    if (r.h[k]) hipHostFree(r.h[k]);
+    r.h[k] = nullptr;
+    r.cap[k] = 0;
+    const size_t want = (size_t)n < 64 ? 64 : (size_t)n;
+    HIP_TRY(ctx, hipHostMalloc((void **)&r.h[k], want * 4, hipHostMallocDefault));
+    r.cap[k] = want;
+  }
+  memcpy(r.h[k], src, (size_t)n * 4);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, r.h[k], (size_t)n * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipEventRecord(r.ev[k], s));
+  r.busy[k] = true;
+  return HIMG_OK;
+}
+
 static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   EncWs &w = ctx->enc_ws;
+  // A row-sharded encode in progress belongs to the geometry it was started with.
+  {
+    const Geom &o = ctx->shard.g;
+    if (ctx->shard.valid && (batch != 1 || o.W != g.W || o.H != g.H || o.C != g.C || o.stride != g.stride ||
+                             o.ycbcr != g.ycbcr))
+      ctx->shard.valid = false;
+  }
   const size_t plane = round_up((size_t)g.C * g.rows * g.cols, 256);
   const size_t lres = round_up((size_t)g.lres_size + 16, 256);
   const size_t fres = round_up((size_t)g.fres_size + 16, 256);
@@ -524,7 +570,8 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   ctx->last_stream = s;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, h_sizes, (size_t)batch * 4, hipMemcpyHostToDevice, s));
+  rc = stage_sizes(ctx, h_sizes, batch, s);
+  if (rc) return rc;
   launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
                 (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof,
                 ctx->allow_fused, ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, 0,
@@ -554,7 +601,8 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   ctx->last_stream = s;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_sizes.p, &packed_size, 4, hipMemcpyHostToDevice, s));
+  rc = stage_sizes(ctx, &packed_size, 1, s);
+  if (rc) return rc;
   // The kernels address pixel rows of the whole frame; hand them a virtual frame
   // base so that block row row0 lands at the start of d_out_rows.
   uint8_t *base = (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C;
@@ -643,8 +691,10 @@ extern "C" int himg_hip_fetch_last(himg_hip_ctx *ctx, uint8_t *dst, size_t dst_c
 // Geometry from the FRMT chunk (decoder.cpp:144-200).  Returns nullptr or the
 // reference's message for the failing check.
 static const char *parse_header(const uint8_t *packed, size_t packed_size, int *W, int *H, int *C) {
+  // decoder.cpp:144-166: the RIFF size field must match the buffer exactly.
   if (packed_size < 12 || packed_size > 0x7fffffffu || memcmp(packed, "RIFF", 4) != 0 ||
-      memcmp(packed + 8, "HIMG", 4) != 0)
+      memcmp(packed + 8, "HIMG", 4) != 0 ||
+      (size_t)(packed[4] | (packed[5] << 8) | (packed[6] << 16) | ((uint32_t)packed[7] << 24)) + 8 != packed_size)
     return "Not a RIFF HIMG file.\n";
   size_t idx = 12;
   for (;;) {
@@ -670,6 +720,10 @@ extern "C" int himg_hip_peek(const uint8_t *packed, size_t packed_size, int *wid
   if (!packed || !width || !height || !num_channels) return HIMG_ERR_ARG;
   int W = 0, H = 0, C = 0;
   if (parse_header(packed, packed_size, &W, &H, &C)) return HIMG_ERR_FORMAT;
+  // The FRMT fields are untrusted: callers size their output from them, so apply
+  // the engine's limits (make_geom) before anybody allocates.
+  Geom g;
+  if (!make_geom(W, H, C, C, 1, &g)) return HIMG_ERR_UNSUPPORTED;
   *width = W; *height = H; *num_channels = C;
   return HIMG_OK;
 }
@@ -888,7 +942,9 @@ extern "C" int himg_hip_shard_stats(himg_hip_ctx *ctx, const void *d_frame_base,
   Geom g;
   if (!make_geom(width, height, pixel_stride, num_channels, use_ycbcr, &g))
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
-  if (row0 < 0 || row1 > g.rows || row0 >= row1 || g.rows > 65535)
+  // row0 == row1: a rank without rows (more ranks than low-res macro rows) still
+  // takes part in every phase; it contributes an all-zero histogram.
+  if (row0 < 0 || row1 > g.rows || row0 > row1 || g.rows > 65535)
     return fail(ctx, HIMG_ERR_ARG, "bad block-row range");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ensure_enc_ws(ctx, g, 1);
@@ -898,8 +954,13 @@ extern "C" int himg_hip_shard_stats(himg_hip_ctx *ctx, const void *d_frame_base,
   if (rc) return fail(ctx, rc, "unsupported table configuration");
   sh.g = g; sh.r0 = row0; sh.r1 = row1; sh.valid = true;
   hipStream_t s = (hipStream_t)stream;
-  launch_shard_stats(g, ctx->enc_ws, (const uint8_t *)d_frame_base, sh.st,
-                     (const uint8_t *)ctx->fmap_lut.p, row0, row1, s, &ctx->prof);
+  if (row1 > row0) {
+    launch_shard_stats(g, ctx->enc_ws, (const uint8_t *)d_frame_base, sh.st,
+                       (const uint8_t *)ctx->fmap_lut.p, row0, row1, s, &ctx->prof);
+  } else {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->enc_ws.hist, 0, 2 * kHistStride * sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->enc_ws.status, 0, sizeof(int32_t), s));
+  }
   HIP_TRY(ctx, hipMemcpyAsync(d_fres_hist, ctx->enc_ws.hist + kHistStride, kNumSym * sizeof(uint32_t),
                               hipMemcpyDeviceToDevice, s));
   const size_t n = (size_t)(row1 - row0) * g.cols;

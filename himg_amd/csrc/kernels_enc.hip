@@ -1091,7 +1091,11 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
   }
   const unsigned long long total = pos;
   const uint32_t fres_bytes = (uint32_t)(total - fres_base);
-  const bool fits = total <= out_stride && total < 0x7fffffffull;
+  // The LRES span edges are OR-ed into a region pre-zeroed for lres_size + kTreeStride
+  // + 64 bytes from kHeadLen & ~3 (launch_encode); a payload beyond it (more than
+  // 8 bits per symbol on average) would be OR-ed onto stale bytes.
+  const bool lres_fits = fres_rel || (unsigned long long)lres_bytes + 8ull <= (unsigned long long)g.lres_size + kTreeStride + 64ull;
+  const bool fits = total <= out_stride && total < 0x7fffffffull && lres_fits;
   if (tid == 0) {
     if (!fits) atomicMax(&ws.status[f], 5);
     sizes[f] = (fits && ws.status[f] == 0) ? (uint32_t)total : 0u;
@@ -1574,15 +1578,17 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
 void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
                            hipStream_t stream, Profiler *prof) {
   HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(64), ws, 1);
-  HIMG_LAUNCH(k_row_bits, dim3((r1 - r0 + 255) / 256), dim3(256), g, ws, r0, r1 - r0, d_bits_out);
+  if (r1 > r0)
+    HIMG_LAUNCH(k_row_bits, dim3((r1 - r0 + 255) / 256), dim3(256), g, ws, r0, r1 - r0, d_bits_out);
 }
 
 void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
                        const uint32_t *d_all_row_bits, uint8_t *d_rel, size_t rel_cap,
                        uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof) {
   HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1);
-  HIMG_LAUNCH(k_emit, dim3(r1 - r0, 1), dim3(256), g, ws, d_rel, rel_cap, d_rel_size,
-              g.lres_spans + r0);
+  if (r1 > r0)
+    HIMG_LAUNCH(k_emit, dim3(r1 - r0, 1), dim3(256), g, ws, d_rel, rel_cap, d_rel_size,
+                g.lres_spans + r0);
 }
 
 void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &sc,

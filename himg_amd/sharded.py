@@ -23,13 +23,17 @@ import numpy as np
 
 def shard_rows(rows, world):
     """Split `rows` block rows over `world` ranks in multiples of 16 rows (a
-    low-res macro-block row never straddles two ranks).  Ranks may get nothing."""
+    low-res macro-block row never straddles two ranks).  The macro rows are dealt
+    out as evenly as possible with the larger shares first, so ranks that get
+    nothing (more ranks than macro rows) are at the TAIL and rank 0, which
+    assembles the stream, always owns rows."""
     macro = (rows + 15) // 16
-    out = []
+    base, rem = divmod(macro, world)
+    out, m0 = [], 0
     for r in range(world):
-        m0 = macro * r // world
-        m1 = macro * (r + 1) // world
+        m1 = m0 + base + (1 if r < rem else 0)
         out.append((min(16 * m0, rows), min(16 * m1, rows)))
+        m0 = m1
     return out
 
 
@@ -152,10 +156,11 @@ class EngineBackend:
         self.r0, self.r1 = r0, r1
         hist = torch.zeros(264, dtype=torch.int32, device=self.dev)
         low = torch.zeros(max(1, self.C * (r1 - r0) * self.cols), dtype=torch.uint8, device=self.dev)
-        if r1 > r0:
-            base = self.d_frame.data_ptr() - self.y_first * self.W * 4   # virtual frame base
-            self.eng.shard_stats(base, self.W, self.H, 4, 4, self.q, self.ycbcr, r0, r1, hist, low,
-                                 self.stream)
+        # Called for an empty share too: it sets up the per-frame state every later
+        # phase (and rank 0's assemble) relies on.
+        base = self.d_frame.data_ptr() - self.y_first * self.W * 4   # virtual frame base
+        self.eng.shard_stats(base, self.W, self.H, 4, 4, self.q, self.ycbcr, r0, r1, hist, low,
+                             self.stream)
         torch.cuda.synchronize(self.dev)
         h64 = (hist[:261].to(torch.int64) & 0xFFFFFFFF)
         return self._to_comm(h64), self._to_comm(low[: self.C * (r1 - r0) * self.cols])
@@ -164,11 +169,10 @@ class EngineBackend:
         import torch
         n = self.r1 - self.r0
         bits = torch.zeros(max(1, n), dtype=torch.int32, device=self.dev)
-        if n > 0:
-            h32 = torch.zeros(264, dtype=torch.int32, device=self.dev)
-            h32[:261] = hist_global.to(self.dev).to(torch.int32)
-            self.eng.shard_row_bits(h32, bits, self.stream)
-            torch.cuda.synchronize(self.dev)
+        h32 = torch.zeros(264, dtype=torch.int32, device=self.dev)
+        h32[:261] = hist_global.to(self.dev).to(torch.int32)
+        self.eng.shard_row_bits(h32, bits, self.stream)   # every rank builds the (identical) tree
+        torch.cuda.synchronize(self.dev)
         return self._to_comm(bits[:n])
 
     def emit(self, all_bits, start, end):

@@ -23,7 +23,10 @@ def test_shard_rows_is_a_16_aligned_partition():
             assert parts[0][0] == 0 and parts[-1][1] == rows
             for (a0, a1), (b0, b1) in zip(parts, parts[1:]):
                 assert a1 == b0 and a0 <= a1
-            assert all(a % 16 == 0 for a, _ in parts)
+            assert all(a % 16 == 0 for a, b in parts if b > a)
+            # empty shares (more ranks than macro rows) sit at the tail; rank 0 owns rows
+            sizes = [b - a for a, b in parts]
+            assert sizes[0] > 0 and all(not (x == 0 and y > 0) for x, y in zip(sizes, sizes[1:]))
     assert sharded.shard_rows(512, 8) == [(64 * i, 64 * i + 64) for i in range(8)]
 
 
@@ -81,7 +84,8 @@ def test_sharded_orchestration_gloo_cpu(tmp_path, world, w, h):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,w,h,q,parts", [
     ("randtile", 256, 512, 50, 2), ("randtile", 512, 1024, 50, 4), ("gradn", 256, 264, 90, 3),
-    ("rand", 128, 512, 50, 2), ("randtile", 2048, 2048, 50, 8)])
+    ("rand", 128, 512, 50, 2), ("randtile", 2048, 2048, 50, 8),
+    ("randtile", 256, 800, 50, 8), ("gradn", 128, 128, 50, 2)])   # more ranks than macro rows: empty shares
 def test_sharded_device_phases_simulated_ranks(kind, w, h, q, parts):
     """All ranks simulated in one process (one engine context per rank): the
     exchanges are done by hand exactly as encode_sharded does them."""
