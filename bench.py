@@ -11,10 +11,15 @@ i.e. N*batch*W*H*K / wall time, whole job.  Frame 0 of rank 0 is the golden
 input: its stream and decoded pixels are checked against the hashes recorded
 from the real reference, so a fast-but-wrong run cannot report a number.
 
-For N > 1 the driver launches one rank per GPU (torch.distributed, backend
-"nccl" = RCCL).  Frames are independent objects, so they are sharded over the
-ranks with no data-path collective (weak scaling: fixed per-GPU batch); only
-the barrier and the max-over-ranks timing use the process group.
+For N > 1 there is one rank per GPU (torch.distributed, backend "nccl" = RCCL):
+either the driver launches the ranks (torch.distributed.run) or, run as a plain
+`python bench.py --gpus N`, this script spawns them itself BEFORE it touches the
+GPU and waits for them.  Frames are independent objects, so they are sharded
+over the ranks with no data-path collective (weak scaling: fixed per-GPU batch);
+only the barrier and the max-over-ranks timing use the process group.  The same
+line carries a `rows` object: BASELINE config 4, ONE 16384x16384 frame whose
+block rows are sharded over the N ranks with the RCCL exchanges of
+himg_amd/sharded.py, golden-checked (strong scaling).
 
 Extra objects on the JSON line:
   roofline     dominant kernel, algorithmic bytes per launch / its mean duration
@@ -57,6 +62,11 @@ def parse_args():
                     help="frames: independent frames sharded over ranks (default, the headline "
                          "metric); rows: ONE frame (default 16384x16384, BASELINE config 4) sharded by "
                          "block rows with RCCL all-reduce / all-gather / gather (encode only)")
+    ap.add_argument("--no-rows", action="store_true",
+                    help="skip the row-sharded 16384x16384 leg (the `rows` object of the frames line)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY (1-GPU box): every rank uses cuda:0 and the collectives run over gloo with "
+                         "CPU staging, to exercise the launcher and the N > 1 orchestration; not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (copy ceiling, latency, host API): profile runs")
@@ -64,10 +74,21 @@ def parse_args():
     return ap.parse_args()
 
 
+def _mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
 def cpu_baseline(frame, quality, budget_s):
-    """Time the reference CPU path on this node's host cores (rank 0, N=1 only).
-    Test-infrastructure use of oracle/: it is the thing timed here, never the
-    product path."""
+    """Time the reference CPU path on this node's host cores (rank 0, N=1 only),
+    protocol of benchmark.cpp:21,111-154 (30 iterations, min / max / average) bounded
+    by `budget_s`.  Test-infrastructure use of oracle/: it is the thing timed here,
+    never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     h, w = frame.shape[:2]
@@ -77,39 +98,44 @@ def cpu_baseline(frame, quality, budget_s):
         kind, enc, dec = "reference", ol.ref_encode, ol.ref_decode
     else:
         kind, enc, dec = "port", ol.oracle_encode, ol.oracle_decode
+
+    def series(fn, max_n, budget):
+        ts = []
+        while len(ts) < 2 or (sum(ts) < budget and len(ts) < max_n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return ts, r
     # Encode: single thread by design (reference encoder.cpp:258-335).
-    t_enc, n_enc, packed = 0.0, 0, None
-    while n_enc < 1 or (t_enc < budget_s * 0.6 and n_enc < 8):
-        t0 = time.perf_counter()
-        packed = enc(frame, quality, True)
-        t_enc += time.perf_counter() - t0
-        n_enc += 1
+    te, packed = series(lambda: enc(frame, quality, True), 30, budget_s * 0.5)
     # Decode: Decoder(0) = all hardware threads (decoder.cpp:79-85); first call warms up.
     dec(packed, 0)
-    t_dec, n_dec = 0.0, 0
-    while n_dec < 2 or (t_dec < budget_s * 0.25 and n_dec < 30):
-        t0 = time.perf_counter()
-        rc, _ = dec(packed, 0)
-        t_dec += time.perf_counter() - t0
-        n_dec += 1
-        assert rc == 0
+    td, (rc, _) = series(lambda: dec(packed, 0), 30, budget_s * 0.25)
+    assert rc == 0
     t0 = time.perf_counter()
     dec(packed, 1)
     t_dec1 = time.perf_counter() - t0
-    e, d = t_enc / n_enc, t_dec / n_dec
-    # Node-level encode: one independent single-threaded encoder per worker thread on
-    # the same frame (ctypes releases the GIL); bounded to 32 workers (~250 MB each).
+    e, d = sum(te) / len(te), sum(td) / len(td)
+    # Node-level encode (SURVEY.md 8d iii): one independent single-threaded encoder per
+    # core on the same frame (ctypes releases the GIL).  An encoder holds ~0.3 GB for
+    # a 4096x4096 frame, so the worker count is the core count unless the node's free
+    # memory says otherwise.
     from concurrent.futures import ThreadPoolExecutor
-    nw = max(1, min(32, cores))
+    per_worker = 5 * frame.nbytes
+    mem = _mem_available_bytes()
+    nw = cores if not mem else max(1, min(cores, int(0.5 * mem / per_worker)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(nw) as pool:
         list(pool.map(lambda _: enc(frame, quality, True), range(nw)))
     t_node = time.perf_counter() - t0
+    ms = lambda ts: {"n": len(ts), "min": round(min(ts) * 1e3, 2), "mean": round(sum(ts) / len(ts) * 1e3, 2),
+                     "max": round(max(ts) * 1e3, 2)}
     return {
         "value": round(mpx / (e + d), 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
         "sample": "%dx%d RGBA %s q=%d: %d encodes on 1 thread (%.3f s each) + %d decodes on %d threads "
-                  "(%.4f s each); same frame as the GPU run" % (w, h, "randtile", quality, n_enc, e,
-                                                                n_dec, cores, d),
+                  "(%.4f s each); same frame as the GPU run" % (w, h, "randtile", quality, len(te), e,
+                                                                len(td), cores, d),
+        "encode_ms_1thread": ms(te), "decode_ms_allthreads": ms(td),
         "encode_mpx_s_1thread": round(mpx / e, 3),
         "decode_mpx_s_allthreads": round(mpx / d, 3),
         "decode_mpx_s_1thread": round(mpx / t_dec1, 3),
@@ -185,33 +211,38 @@ def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, 
 GOLDEN_16384 = {"packed_size": 275620945, "stream_fnv": "5bdcdb7a140df481", "decoded_fnv": "08fb9dc8e25c2fae"}
 
 
-def bench_rows(args, rank, local_rank, world, dev):
+def rows_leg(args, rank, local_rank, world, dev, steps, warmup):
     """BASELINE config 4: one large frame, block rows sharded over the ranks, FRES
     histogram all-reduced, row sizes all-gathered, packed rows gathered to rank 0
-    over RCCL/xGMI (himg_amd/sharded.py).  Strong scaling: the frame is fixed."""
+    over RCCL/xGMI (himg_amd/sharded.py); then the row-sharded decode of the same
+    stream.  Strong scaling: the frame is fixed.  Returns the result object on rank
+    0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
     import himg_amd
     from himg_amd import sharded
 
-    W = args.width or 16384
-    H = args.height or 16384
-    Q = args.quality
+    if args.mode == "rows":   # on its own: the geometry can be chosen
+        W, H, Q, kind = args.width or 16384, args.height or 16384, args.quality, args.kind
+    else:                     # as the `rows` object of the frames line: config 4 as BASELINE.json states it
+        W, H, Q, kind = 16384, 16384, 50, "randtile"
     rows, cols = (H + 7) // 8, (W + 7) // 8
-    img = himg_amd.synth(args.kind, 0, W, H)          # every rank generates, then keeps its shard
+    img = himg_amd.synth(kind, 0, W, H)               # every rank generates, then keeps its shard
     r0, r1 = sharded.shard_rows(rows, world)[rank]
     y0, y1 = max(0, 8 * r0 - 11), min(H, 8 * r1 + 5)
     if r1 <= r0:
         y0, y1 = 0, 1
     d_shard = torch.from_numpy(np.ascontiguousarray(img[y0:y1])).to(dev)
     want = None
-    if rank == 0 and not (W == 16384 and H == 16384 and Q == 50 and args.kind == "randtile"):
+    golden = (W, H, Q, kind) == (16384, 16384, 50, "randtile")
+    if rank == 0 and not golden:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
         want = ol.oracle_encode(img, Q, True)
     del img
     eng = himg_amd.Engine(local_rank)
-    backend = sharded.EngineBackend(eng, d_shard, y0, W, H, Q, True)
+    comm = "cpu" if args.oversubscribe else None
+    backend = sharded.EngineBackend(eng, d_shard, y0, W, H, Q, True, comm_device=comm)
 
     def step():
         # The stream stays in rank 0's HBM (like the frames metric); the one host
@@ -219,11 +250,10 @@ def bench_rows(args, rank, local_rank, world, dev):
         return sharded.encode_sharded(backend, rows, cols, 4, rows > 1, host=False)
 
     out = step()
-    if rank == 0:
-        out = out.cpu().numpy()
     verified = "n/a"
     if rank == 0:
-        if want is None:
+        out = out.cpu().numpy()
+        if golden:
             assert out.size == GOLDEN_16384["packed_size"], out.size
             assert himg_amd.fnv1a64(out) == GOLDEN_16384["stream_fnv"], "stream differs from the reference"
             verified = "golden"
@@ -236,24 +266,36 @@ def bench_rows(args, rank, local_rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_steps(fn):
+        """K steps inside one barrier bracket (the rate) + the per-step spread."""
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        total = time.perf_counter() - t0
+        per = []
+        for _ in range(steps):
+            barrier()
+            t = time.perf_counter()
+            fn()
+            barrier()
+            per.append(time.perf_counter() - t)
+        return total, per
 
-    # Row-sharded decode of the same stream (not part of `value`): every rank
-    # decodes LRES + its own block rows, pixels stay sharded; the gathered image is
-    # hashed once against the golden outside the timed region.
+    dt, per_enc = timed_steps(step)
+
+    # Row-sharded decode of the same stream: every rank decodes its own block rows,
+    # pixels stay sharded; the gathered image is hashed once against the golden
+    # outside the timed region.
     d_packed = torch.from_numpy(out).to(dev) if rank == 0 else None
-    ok, pix = sharded.decode_sharded(eng, d_packed, W, H, 4, gather=True, device=dev)
+    ok, pix = sharded.decode_sharded(eng, d_packed, W, H, 4, gather=True, device=dev, comm_device=comm)
     dec_verified = "n/a"
     if rank == 0:
         assert ok, "sharded decode rejected the stream"
-        if want is None:
+        if golden:
             assert himg_amd.fnv1a64(pix) == GOLDEN_16384["decoded_fnv"], "pixels differ from the reference"
             dec_verified = "golden"
         else:
@@ -261,56 +303,96 @@ def bench_rows(args, rank, local_rank, world, dev):
             assert rc == 0 and np.array_equal(pix.ravel(), ref.ravel()), "pixels differ from the oracle"
             dec_verified = "oracle"
     del pix
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        sharded.decode_sharded(eng, d_packed, W, H, 4, gather=False, device=dev)
-    barrier()
-    dt_dec = time.perf_counter() - t1
+    dt_dec, per_dec = timed_steps(lambda: sharded.decode_sharded(eng, d_packed, W, H, 4, gather=False, device=dev,
+                                                                   comm_device=comm))
     if world > 1:
-        t = torch.tensor([dt, dt_dec], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_dec] + per_enc + per_dec, dtype=torch.float64, device="cpu" if args.oversubscribe else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_dec = float(t.cpu()[0]), float(t.cpu()[1])
+        t = [float(x) for x in t.cpu()]
+        dt, dt_dec, per_enc, per_dec = t[0], t[1], t[2:2 + steps], t[2 + steps:]
+    eng.close()
+    if rank != 0:
+        return None
+    spread = lambda per: {"min": round(min(per) * 1e3, 3), "mean": round(sum(per) / len(per) * 1e3, 3),
+                          "max": round(max(per) * 1e3, 3)}
+    enc_v, dec_v = W * H * steps / dt / 1e6, W * H * steps / dt_dec / 1e6
+    return {
+        "workload": "%dx%d RGBA %s q=%d: ONE frame, block rows sharded over %d rank(s); encode = RCCL all-reduce "
+                    "(261-bin histogram) + all-gather (row bits) + gather (low-res rows, packed rows) to rank 0, "
+                    "stream left in rank 0's HBM; decode = broadcast of the stream, every rank its own block rows, "
+                    "pixels stay sharded" % (W, H, kind, Q, world),
+        "scaling": "strong", "n_gpus": world, "steps": steps,
+        "encode_mpx_s": round(enc_v, 2), "decode_mpx_s": round(dec_v, 2),
+        "encode_decode_mpx_s": round(W * H * steps / (dt + dt_dec) / 1e6, 2),
+        "encode_ms": spread(per_enc), "decode_ms": spread(per_dec),
+        "bit_exact": {"stream": verified, "pixels": dec_verified},
+    }
+
+
+def bench_rows(args, rank, local_rank, world, dev):
+    """--mode rows: the row-sharded leg on its own, as the line's metric."""
+    import torch.distributed as dist
+    r = rows_leg(args, rank, local_rank, world, dev, args.steps, args.warmup)
     if rank == 0:
-        value = W * H * args.steps / dt / 1e6
         print(json.dumps({
-            "decode_mpx_s": round(W * H * args.steps / dt_dec / 1e6, 2),
-            "decode_note": "row-sharded decode incl. broadcast of the stream; pixels stay sharded; bit_exact " + dec_verified,
-            "metric": "Mpixels/s encode, one RGBA frame row-sharded over the GPUs, q=%d" % Q,
-            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "metric": "Mpixels/s encode+decode, one RGBA frame row-sharded over the GPUs, q=%d" % args.quality,
+            "value": r["encode_decode_mpx_s"], "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(r["encode_ms"]["mean"] + r["decode_ms"]["mean"], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8/i16/i32 integer", "data": "synthetic",
-            "config": {"workload": "%dx%d RGBA %s q=%d, encode, block rows sharded over %d rank(s), "
-                                   "host-orchestrated collectives (all-reduce 261xi64, all-gather row "
-                                   "bits, gather low-res rows and packed rows to rank 0), the stream stays in "
-                                   "rank 0's HBM" % (W, H, args.kind, Q, world),
-                       "bit_exact": verified}}), flush=True)
+            "config": {"workload": r["workload"], "bit_exact": r["bit_exact"]}, "rows": r}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` run as a plain command: start one child per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, like
+    torch.distributed.run) and wait.  This parent never touches the GPU -- it has
+    not even imported torch -- so nothing that has initialised HIP is ever
+    re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def main():
     args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: be the launcher (no GPU call in this process).
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
     import himg_amd
 
+    if args.oversubscribe:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.oversubscribe:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.mode == "rows":
         return bench_rows(args, rank, local_rank, world, dev)
@@ -364,21 +446,32 @@ def main():
     torch.cuda.synchronize()
     assert not d_st_d.cpu().numpy().any(), "decode failed: %s" % d_st_d.cpu().numpy()
 
-    # Parity gate before any timing counts.
+    # Parity gate before any timing counts: EVERY frame of this rank's batch, stream
+    # and decoded pixels, against the table recorded from the real reference
+    # (tests/golden/batch_4096x4096_q50.json, seeds 0..255 = 8 ranks x 32 frames).
     verified = "n/a"
-    if rank == 0:
-        s0 = d_out[0, : int(h_sizes[0])].cpu().numpy()
-        p0 = d_pix[0].cpu().numpy()
-        if (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
-            assert int(h_sizes[0]) == GOLDEN_4096["packed_size"], h_sizes[0]
-            assert himg_amd.fnv1a64(s0) == GOLDEN_4096["stream_fnv"], "stream differs from the reference"
-            assert himg_amd.fnv1a64(p0) == GOLDEN_4096["decoded_fnv"], "pixels differ from the reference"
-            verified = "golden"
-        else:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as ol
-            assert np.array_equal(s0, ol.oracle_encode(frames[0], Q, True))
-            verified = "oracle"
+    table = None
+    tpath = os.path.join(ROOT, "tests", "golden", "batch_%dx%d_q%d.json" % (W, H, Q))
+    if args.kind == "randtile" and os.path.exists(tpath):
+        table = json.load(open(tpath))["seeds"]
+    if table is not None and (rank + 1) * B <= len(table):
+        for i in range(B):
+            want_size, want_s, want_p = table[rank * B + i]
+            assert int(h_sizes[i]) == want_size, (rank, i, int(h_sizes[i]), want_size)
+            assert himg_amd.fnv1a64(d_out[i, :want_size].cpu().numpy()) == want_s, \
+                "stream of frame %d (rank %d) differs from the reference" % (i, rank)
+            assert himg_amd.fnv1a64(d_pix[i].cpu().numpy()) == want_p, \
+                "pixels of frame %d (rank %d) differ from the reference" % (i, rank)
+        verified = "golden, all %d frames of every rank (stream + pixels)" % B
+    elif rank == 0:
+        # Other geometries / qualities: frame 0 against the oracle (CPU seconds per frame).
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        want = ol.oracle_encode(frames[0], Q, True)
+        assert np.array_equal(d_out[0, : int(h_sizes[0])].cpu().numpy(), want), "stream differs from the oracle"
+        rc, ref = ol.oracle_decode(want)
+        assert rc == 0 and np.array_equal(d_pix[0].cpu().numpy().ravel(), ref.ravel()), "pixels differ from the oracle"
+        verified = "oracle, frame 0 (stream + pixels)"
 
     def barrier():
         if world > 1:
@@ -402,6 +495,16 @@ def main():
         for k, v in e.profile_read().items():  # stage -> (total ms, launches), HIP events on its stream
             a = prof.get(k, (0.0, 0))
             prof[k] = (a[0] + v[0], a[1] + v[1])
+
+    # Per-step spread (benchmark.cpp:151-154 reports Min / Max / Average over 30
+    # iterations): the same step, synchronised after each one, >= 30 times.
+    per_step = []
+    for _ in range(max(30, args.steps)):
+        barrier()
+        t = time.perf_counter()
+        step()
+        barrier()
+        per_step.append(time.perf_counter() - t)
 
     # Encode-only and decode-only rates (same protocol, not part of `value`).
     def timed(fn, n):
@@ -435,10 +538,12 @@ def main():
         iso = {k: v[0] / max(v[1], 1) for k, v in e0.profile_read().items()}
 
     if world > 1:
-        t = torch.tensor([dt, t_enc, t_dec], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, t_enc, t_dec] + per_step, dtype=torch.float64, device="cpu" if args.oversubscribe else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, t_enc, t_dec = (float(x) for x in t.cpu())
+        t = [float(x) for x in t.cpu()]
+        dt, t_enc, t_dec, per_step = t[0], t[1], t[2], t[3:]
 
+    out = None
     if rank == 0:
         px_step = float(world) * B * W * H
         ms_step = dt / args.steps * 1e3
@@ -455,34 +560,34 @@ def main():
         roofline = None
         if dom:
             ach = alg_bytes_launch / (stages[dom]["ms"] * 1e-3) / 1e9
-            # HBM bytes per launch from the committed PMC measurement (per frame, same
-            # workload; tools/profile_pmc.sh) -- null when the workload differs.
-            traffic = None
+            # HBM bytes per launch: NOT measured in this run -- rocprofv3 cannot wrap its
+            # own host.  They come from the committed PMC passes of the same workload
+            # (tools/profile_pmc.sh -> profiles/traffic.json, which names the commit it was
+            # measured at); null when the workload differs.
+            traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
-                per_frame = {k.split("<")[0]: v for k, v in
-                             json.load(open(tpath)).get("bytes_per_frame", {}).items()}
-                key = dom.strip("()").split("<")[0]
+            std = (W, H, Q, args.kind) == (4096, 4096, 50, "randtile")
+            key = dom.strip("()").split("<")[0]
+            pmc = {}
+            if os.path.exists(tpath) and std:
+                tj = json.load(open(tpath))
+                per_frame = {k.split("<")[0]: v for k, v in tj.get("bytes_per_frame", {}).items()}
                 if key in per_frame:
                     traffic = per_frame[key] * G
-            # VALU-issue utilisation of that kernel from the committed PMC summary
-            # (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration)): these kernels are
-            # instruction-bound, the HBM fraction is an upper bound on what is left.
+                    traffic_src = "profiles/traffic.json (PMC passes at commit %s, not this run)" % tj.get("git_sha", "?")
+                pmc = tj.get("valu", {})
+            # VALU issue of that kernel from the same PMC passes: wave-instructions per
+            # symbol and the fraction of the chip's issue peak (256 CUs x 1 wave-instruction
+            # per cycle x 2.4 GHz = 6.1e11 /s) -- what actually bounds these kernels.
             valu_busy = None
-            import glob
-            import re
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")),
-                           key=lambda q: [int(x) for x in re.findall(r"\d+", os.path.basename(q))])
-            ppath = cands[-1] if cands else ""   # the newest committed PMC summary
-            if ppath and (W, H, Q, args.kind) == (4096, 4096, 50, "randtile"):
-                for k, v in json.load(open(ppath)).items():
-                    if k.split("<")[0] == dom.strip("()").split("<")[0] and v.get("dur_us"):
-                        valu_busy = round(v.get("SQ_INSTS_VALU", 0) * 4 / (1024 * v["dur_us"] * 1e-6 * 2.4e9), 3)
+            for k, v in pmc.items():
+                if k.split("<")[0] == key:
+                    valu_busy = v.get("issue_frac")
             roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom.strip("()").split("<")[0] in enc_stages else "decode",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": alg_bytes_launch, "frames_per_launch": G,
-                        "kernel_ms": round(stages[dom]["ms"], 4), "valu_busy_frac_pmc": valu_busy}
+                        "kernel_ms": round(stages[dom]["ms"], 4), "valu_issue_frac_pmc": valu_busy}
             if dom in iso and iso[dom] > 0:
                 a_iso = alg_bytes_launch / (iso[dom] * 1e-3) / 1e9
                 roofline["isolated"] = {"kernel_ms": round(iso[dom], 4), "achieved": round(a_iso, 1),
@@ -491,7 +596,11 @@ def main():
         out = {
             "metric": "Mpixels/s encode+decode, 4K RGBA q=50", "value": round(value, 2),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3),
+            "step_ms": {"n": len(per_step), "min": round(min(per_step) * 1e3, 3),
+                        "mean": round(sum(per_step) / len(per_step) * 1e3, 3), "max": round(max(per_step) * 1e3, 3),
+                        "note": "each step synchronised on its own (not the timed region of `value`)"},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i16/i32 integer", "data": "synthetic",
             "config": {"workload": "%dx%d RGBA %s q=%d, encode+decode, batch %d frames/GPU resident in HBM, "
                                    "%d stream(s) x %d frames per launch" % (W, H, args.kind, Q, B, S, G),
@@ -506,6 +615,7 @@ def main():
                 "encode_frac": round(alg_bytes_side / t_enc / 1e9 / HBM_PEAK_GBS, 4),
                 "decode_frac": round(alg_bytes_side / t_dec / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roofline,
+            "roofline_valu": ({"peak_wave_insts_per_s": 6.144e11, "source": traffic_src, "kernels": pmc} if pmc else None),
             "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_extras:
@@ -513,12 +623,21 @@ def main():
                                            d_st_d, d_pix, h_sizes, frames[0], W, H, Q, cap)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], Q, args.cpu_seconds)
+    for e in engines:
+        e.close()
+    # BASELINE config 4 on the same ranks: one 16384x16384 frame, block rows sharded
+    # over them, the RCCL exchanges of himg_amd/sharded.py (every rank takes part).
+    if not args.no_rows:
+        del d_frames, d_out, d_pix, frames
+        torch.cuda.empty_cache()
+        rows_obj = rows_leg(args, rank, local_rank, world, dev, max(5, min(args.steps, 10)), 2)
+        if rank == 0:
+            out["rows"] = rows_obj
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for e in engines:
-        e.close()
 
 
 if __name__ == "__main__":

@@ -1,13 +1,36 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from a tools/profile_pmc.sh summary (bytes per frame)."""
+"""profiles/traffic.json from a tools/profile_pmc.sh summary: HBM bytes per frame and
+VALU issue per symbol, per kernel, stamped with the commit they were measured at.
+Usage: make_traffic_json.py <summary.json> <frames_per_launch> <out.json> [git_sha]"""
 import json
+import subprocess
 import sys
 
 summary, frames_per_launch, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+sha = sys.argv[4] if len(sys.argv) > 4 else ""
+if not sha:
+    try:
+        sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        sha = "?"
 d = json.load(open(summary))
+SYMBOLS_PER_FRAME = 4096 * 4096 * 4
 t = {k: round((v.get("hbm_read_MB_corrected", 0) + v.get("hbm_write_MB", 0)) * 1e6 / frames_per_launch)
      for k, v in d.items()}
-json.dump({"note": "HBM bytes per 4096x4096 RGBA q50 randtile frame per kernel launch: rocprofv3 --pmc "
-                   "FETCH_SIZE (x2, gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, separate passes, "
-                   "%d frames per launch, tools/profile_pmc.sh" % frames_per_launch,
-           "bytes_per_frame": t}, open(out, "w"), indent=1)
+raw = {k: round((v.get("hbm_read_MB_raw", 0) + v.get("hbm_write_MB", 0)) * 1e6 / frames_per_launch) for k, v in d.items()}
+x2 = {k: round((v.get("hbm_read_MB_x2", 0) + v.get("hbm_write_MB", 0)) * 1e6 / frames_per_launch) for k, v in d.items()}
+valu = {}
+for k, v in d.items():
+    if v.get("SQ_INSTS_VALU") and v.get("dur_us"):
+        valu[k] = {"wave_insts_per_symbol": round(v["SQ_INSTS_VALU"] / (SYMBOLS_PER_FRAME * frames_per_launch), 4),
+                   "issue_frac": round(v["SQ_INSTS_VALU"] / (v["dur_us"] * 1e-6 * 6.144e11), 3),
+                   "lds_conflict_frac": (round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 3)
+                                         if v.get("SQ_LDS_IDX_ACTIVE") else None),
+                   "dur_us": round(v["dur_us"], 1)}
+json.dump({"note": "HBM bytes per 4096x4096 RGBA q50 randtile frame per kernel launch: rocprofv3 --pmc FETCH_SIZE "
+                   "(x2 only for the 16-byte-per-lane streaming kernels, the gfx950 correction of MI355X_MICROARCH.md; "
+                   "raw and x2 figures beside it) + WRITE_SIZE, separate passes, %d frames per launch, "
+                   "tools/profile_pmc.sh.  valu: SQ_INSTS_VALU per symbol and as a fraction of the chip's issue peak "
+                   "(256 CUs x 2.4 GHz)." % frames_per_launch,
+           "git_sha": sha, "bytes_per_frame": t, "bytes_per_frame_fetch_raw": raw, "bytes_per_frame_fetch_x2": x2,
+           "valu": valu}, open(out, "w"), indent=1)

@@ -25,6 +25,9 @@ def kname(full):
             return n[:i]
     return n
 
+# Kernels that read their input as 16-byte-per-lane coalesced streams.
+STREAMING = {"k_lowres_avg", "k_tile_fwd_pk", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_m", "k_lres_summary"}
+
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 dur = collections.defaultdict(lambda: [0.0, 0])
 for path in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
@@ -45,9 +48,16 @@ for k in sorted(acc, key=lambda k: -dur[k][0]):
         continue
     row = {c: v[0] / max(v[1], 1) for c, v in acc[k].items()}
     row["dur_us"] = dur[k][0] / max(dur[k][1], 1)
-    # MI355X_MICROARCH.md: FETCH_SIZE reads half the bytes of wide coalesced reads on gfx950.
+    # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads HALF the bytes of wide coalesced
+    # streaming reads (16 B per lane); other access widths are uncalibrated.  So the x2
+    # is applied only to the kernels whose reads are 16-byte-per-lane streams
+    # (STREAMING below); for the others the raw figure is reported, with the x2 value
+    # beside it as an upper bound.
     if "FETCH_SIZE" in row:
-        row["hbm_read_MB_corrected"] = row["FETCH_SIZE"] * 1024 * 2 / 1e6
+        raw = row["FETCH_SIZE"] * 1024 / 1e6
+        row["hbm_read_MB_raw"] = raw
+        row["hbm_read_MB_x2"] = 2 * raw
+        row["hbm_read_MB_corrected"] = 2 * raw if k.split("<")[0] in STREAMING else raw
     if "WRITE_SIZE" in row:
         row["hbm_write_MB"] = row["WRITE_SIZE"] * 1024 / 1e6
     out[k] = row
