@@ -17,6 +17,8 @@
 // Wavefront = 64 lanes everywhere; no MFMA (there is no dense contraction).
 #include "himg_dev.h"
 
+#include <utility>
+
 namespace himg_dev {
 
 // L-shell coefficient scan order (reference common.cpp:13-22; part of the format).
@@ -517,6 +519,225 @@ __global__ __launch_bounds__(kTileThreads, 3) void k_tile_fwd_pk(Geom g, const u
 }
 
 // ---------------------------------------------------------------------------
+// k_pix_fwd: the pixel stage of the BASELINE shapes (full tiles, packed RGBA8,
+// cols a multiple of 16) in its round-2 form.  Lane = tile, a wavefront = 64
+// adjacent tiles of one block row, like k_tile_fwd_pk, but
+//   * the tile's 64 pixels are loaded ONCE (sixteen 16-byte loads) and stay in
+//     registers for both channel pairs -- the kernel runs at two waves per SIMD,
+//     which costs this ALU-dense code a few per cent and saves a second pass
+//     over the pixels;
+//   * the pairs are chosen so that the colour lift is packed arithmetic:
+//     (R,B) = px & 0x00ff00ff gives (Cr,Cb) = ((R,B) + 256 - (G,G)) >> 1 in three
+//     packed ops, Y = v_dot4_u32_u8(px, {1,2,1,0}) + 2 >> 2; so pair 0 = (Cr, Cb)
+//     (both use the chroma shifts) and pair 1 = (Y, A) (both luma) -- one shift
+//     amount per coefficient for both halves (ycbcr.cpp:32-37, encoder.cpp:284);
+//   * the bilinear low-res block (downsampled.cpp:116-169) is built four rows per
+//     register with v_lerp_u8 ((a + b + 1) >> 1 per byte), 29 instructions per
+//     channel instead of 8 x 7 x 3;
+//   * the sign-magnitude rounding shift (quantize.cpp:135-148) is branch free:
+//     -((-x + r) >> s) == (x + r - 1) >> s (arithmetic) for x < 0, s >= 1, so
+//     q = (x + r + (sign & [s > 0])) >> s for either sign; the companding map
+//     (mapper.cpp:159-182) is the identity up to 50, so the byte is the low byte
+//     of q unless some |q| > 50 -- tracked with one packed max per coefficient
+//     and redone with the LUT for the (rare) tile that needs it;
+//   * the non-zero MASKS of the symbols are a by-product: for every channel and
+//     coefficient one ballot = 64 consecutive symbols of the stream
+//     (encoder.cpp:320-323 layout); lane i keeps the word of coefficient i
+//     (v_writelane) and the wave stores 512 contiguous bytes per channel.  The
+//     entropy kernels read these 8 MB per frame instead of scanning 64 MiB of
+//     symbols for zeros.
+// Mask layout: word (c, i, wv) -- symbols (c*64 + i)*cols + 64*wv .. + 63 of the
+// block row -- is at mask[((v*C + c)*nw + wv)*64 + i], nw = ceil(cols / 64); bits
+// beyond the row's last tile are 0.
+// ---------------------------------------------------------------------------
+template <class F, int... I>
+__device__ __forceinline__ void for_seq_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void for_seq(F &&f) { for_seq_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int I>
+__device__ __forceinline__ uint32_t writelane(uint32_t v, uint32_t s) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(I));
+  return v;
+}
+
+// lerp tree of downsampled.cpp:116-169 on four packed bytes.
+__device__ __forceinline__ void interp9_u8x4e(uint32_t a[9]) {
+  const uint32_t rnd = 0x01010101u;
+  a[4] = __builtin_amdgcn_lerp(a[0], a[8], rnd);
+  a[2] = __builtin_amdgcn_lerp(a[0], a[4], rnd);
+  a[6] = __builtin_amdgcn_lerp(a[4], a[8], rnd);
+  a[1] = __builtin_amdgcn_lerp(a[0], a[2], rnd);
+  a[3] = __builtin_amdgcn_lerp(a[2], a[4], rnd);
+  a[5] = __builtin_amdgcn_lerp(a[4], a[6], rnd);
+  a[7] = __builtin_amdgcn_lerp(a[6], a[8], rnd);
+}
+
+// Low-res block of one channel: LQ[q][x] = bytes of rows 4q..4q+3 at column x.
+// lr0 / lr8: (left, right) low-res samples of this and the next block row in bytes 0, 1.
+__device__ __forceinline__ void lowres_quads_e(uint32_t lr0, uint32_t lr8, uint32_t LQ[2][8]) {
+  uint32_t lr[9];
+  lr[0] = lr0; lr[8] = lr8;
+  interp9_u8x4e(lr);   // bytes 0,1 = left,right of rows 0..7
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t p01 = __builtin_amdgcn_perm(lr[4 * q + 1], lr[4 * q], 0x05010400u);      // L0 L1 R0 R1
+    const uint32_t p23 = __builtin_amdgcn_perm(lr[4 * q + 3], lr[4 * q + 2], 0x05010400u);  // L2 L3 R2 R3
+    uint32_t a[9];
+    a[0] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+    a[8] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+    interp9_u8x4e(a);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) LQ[q][x] = a[x];
+  }
+}
+
+// The two channel values of pair PAIR of one pixel as packed int16.
+//   YCBCR: pair 0 = (Cr, Cb) = channels (2, 1), pair 1 = (Y, A) = channels (0, 3)
+//   else : pair 0 = channels (0, 2),            pair 1 = channels (1, 3)
+template <bool YCBCR, int PAIR>
+__device__ __forceinline__ pk16 pix_pair(uint32_t px) {
+  if (!YCBCR) {
+    const uint32_t v = PAIR == 0 ? (px & 0x00ff00ffu) : ((px >> 8) & 0x00ff00ffu);
+    return __builtin_bit_cast(pk16, v);
+  }
+  if (PAIR == 0) {
+    const uint32_t rb = (px & 0x00ff00ffu) | 0x01000100u;                 // (R + 256, B + 256)
+    const uint32_t gg = __builtin_amdgcn_perm(px, px, 0x0c010c01u);       // (G, G)
+    const upk16 d = __builtin_bit_cast(upk16, (pk16)(__builtin_bit_cast(pk16, rb) - __builtin_bit_cast(pk16, gg)));
+    const upk16 one = {1, 1};
+    return __builtin_bit_cast(pk16, (upk16)(d >> one));                   // (Cr, Cb)
+  }
+  const uint32_t y = __builtin_amdgcn_udot4(px, 0x00010201u, 2u, false) >> 2;   // (R + 2G + B + 2) >> 2
+  return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(px, y, 0x0c070c00u));    // (Y, A)
+}
+
+constexpr int kPixThreads = 256;
+constexpr int kPixLut = 8192;
+
+template <bool YCBCR, int COLS>
+__global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_t *frames,
+                                                            const uint8_t *low, size_t plane_stride,
+                                                            uint8_t *fres_sym, size_t fres_stride,
+                                                            unsigned long long *fres_mask, size_t mask_stride,
+                                                            const uint8_t *__restrict__ fmap_lut,
+                                                            ShiftTables st, int v0) {
+  // Companding LUT for magnitudes below kPixLut (every larger one maps to 127:
+  // the full-res table tops out at 8039, mapper.cpp:54-71,159-182).
+  __shared__ __attribute__((aligned(16))) uint8_t s_lut[kPixLut];
+  for (int k = threadIdx.x; k < kPixLut / 16; k += kPixThreads)
+    reinterpret_cast<uint4 *>(s_lut)[k] = reinterpret_cast<const uint4 *>(fmap_lut)[k];
+  __syncthreads();
+  const int cols = COLS ? COLS : g.cols;
+  const int u = blockIdx.x * kPixThreads + threadIdx.x;
+  const int v = blockIdx.y + v0, f = blockIdx.z;
+  if ((int)(blockIdx.x * kPixThreads + (threadIdx.x & ~63)) >= cols) return;   // the whole wave is beyond the row
+  const bool valid = u < cols;
+  const int uc = valid ? u : cols - 1;
+  const uint8_t *img = frames + (long long)f * g.frame_bytes;
+  const int u2 = min(uc + 1, cols - 1), v2 = min(v + 1, g.rows - 1);
+  uint8_t *dst_row = fres_sym + (size_t)f * fres_stride + (size_t)v * g.row_block + uc;
+  const uint8_t *row0 = img + ((long long)(8 * v) * g.W + 8 * uc) * 4;
+  const size_t pitch = (size_t)g.W * 4;
+
+  // The tile: 8 rows x 8 pixels, one pass over HBM.
+  uint32_t px[64];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const uint4 *rp = reinterpret_cast<const uint4 *>(row0 + (size_t)y * pitch);
+    const uint4 q0 = rp[0], q1 = rp[1];
+    px[y * 8 + 0] = q0.x; px[y * 8 + 1] = q0.y; px[y * 8 + 2] = q0.z; px[y * 8 + 3] = q0.w;
+    px[y * 8 + 4] = q1.x; px[y * 8 + 5] = q1.y; px[y * 8 + 6] = q1.z; px[y * 8 + 7] = q1.w;
+  }
+  // Low-res corners of the four channels: (left, right) of block rows v and v + 1.
+  uint32_t lr0[4], lr8[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint8_t *m = low + (size_t)f * plane_stride + (size_t)c * g.rows * cols;
+    lr0[c] = (uint32_t)m[(size_t)v * cols + uc] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
+    lr8[c] = (uint32_t)m[(size_t)v2 * cols + uc] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
+  }
+  const int wv = u >> 6, nw = (cols + 63) >> 6;
+  unsigned long long *mrow = fres_mask + (size_t)f * mask_stride + ((size_t)v * g.C * nw + wv) * 64 + (threadIdx.x & 63);
+
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    // Channels in the low / high half of this pair, and their shift table.
+    const int cA = YCBCR ? (pr == 0 ? 2 : 0) : (pr == 0 ? 0 : 1);
+    const int cB = YCBCR ? (pr == 0 ? 1 : 3) : (pr == 0 ? 2 : 3);
+    const uint8_t *sh = st.s[(YCBCR && pr == 0) ? 1 : 0];
+
+    pk16 b[64];
+    {
+      uint32_t LA[2][8], LB[2][8];
+      lowres_quads_e(lr0[cA], lr8[cA], LA);
+      lowres_quads_e(lr0[cB], lr8[cB], LB);
+#pragma unroll
+      for (int y = 0; y < 8; ++y)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          // (low A, low B) of this pixel, zero-extended to the two halves.
+          const uint32_t sel = 0x0c000c00u | (uint32_t)(y & 3) | ((uint32_t)(4 + (y & 3)) << 16);
+          const pk16 lo = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(LB[y >> 2][x], LA[y >> 2][x], sel));
+          const pk16 pv = pr == 0 ? pix_pair<YCBCR, 0>(px[y * 8 + x]) : pix_pair<YCBCR, 1>(px[y * 8 + x]);
+          b[y * 8 + x] = pv - lo;
+        }
+    }
+    // Forward 2-D WHT: rows, then columns (hadamard.cpp:78-88).
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+      wht8_pk(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
+              b[y * 8 + 6], b[y * 8 + 7]);
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+      wht8_pk(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
+
+    uint8_t *dstA = dst_row + (size_t)cA * 64 * cols;
+    uint8_t *dstB = dst_row + (size_t)cB * 64 * cols;
+    uint32_t mA_lo = 0, mA_hi = 0, mB_lo = 0, mB_hi = 0;
+    for_seq<64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int pos = kScan[i];
+      const int s = sh[pos];                                  // wave-uniform
+      const short r = (short)(s ? (1 << (s - 1)) : 0);
+      const short adj = (short)(s ? -1 : 0);
+      const pk16 x = b[pos];
+      const pk16 fifteen = {15, 15};
+      const pk16 sign = x >> fifteen;                         // 0 or -1 per half
+      const pk16 rr = {r, r}, aa = {adj, adj}, ss = {(short)s, (short)s};
+      pk16 q = (x + rr + (sign & aa)) >> ss;                  // sign * ((|x| + r) >> s)
+      // Companding (mapper.cpp:159-182): the identity while |q| <= 50.  t = q + 50 as
+      // unsigned is <= 100 exactly then; the saturating subtract leaves a non-zero
+      // dword iff a half is beyond -- one wave-uniform branch per coefficient, taken
+      // for the few low-frequency coefficients of high-contrast tiles.
+      const upk16 fifty = {50, 50}, hundred = {100, 100};
+      const upk16 over = __builtin_elementwise_sub_sat((upk16)(__builtin_bit_cast(upk16, q) + fifty), hundred);
+      if (__builtin_expect(__any(__builtin_bit_cast(uint32_t, over) != 0u), 0)) {
+        const pk16 mag = (q ^ sign) - sign;
+        const uint32_t ma = min((uint32_t)(uint16_t)mag.x, (uint32_t)(kPixLut - 1));
+        const uint32_t mb = min((uint32_t)(uint16_t)mag.y, (uint32_t)(kPixLut - 1));
+        pk16 code;                                            // the LUT is the identity below 51
+        code.x = (short)s_lut[ma];
+        code.y = (short)s_lut[mb];
+        q = (code ^ sign) - sign;
+      }
+      if (valid) {
+        dstA[(size_t)i * cols] = (uint8_t)q.x;
+        dstB[(size_t)i * cols] = (uint8_t)q.y;
+      }
+      const unsigned long long bA = __ballot(valid && q.x != 0);
+      const unsigned long long bB = __ballot(valid && q.y != 0);
+      mA_lo = writelane<i>(mA_lo, (uint32_t)bA); mA_hi = writelane<i>(mA_hi, (uint32_t)(bA >> 32));
+      mB_lo = writelane<i>(mB_lo, (uint32_t)bB); mB_hi = writelane<i>(mB_hi, (uint32_t)(bB >> 32));
+    });
+    mrow[(size_t)cA * nw * 64] = ((unsigned long long)mA_hi << 32) | mA_lo;
+    mrow[(size_t)cB * nw * 64] = ((unsigned long long)mB_hi << 32) | mB_lo;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Entropy coder helpers.
 // ---------------------------------------------------------------------------
 
@@ -846,6 +1067,104 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
                             : ws.span_hist_f + ((size_t)f * g.rows + (sp - g.lres_spans)) * kHistStride);
   uint32_t *gh = ws.hist + ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
   for (int k = threadIdx.x; k < kHistStride; k += 256) {
+    const uint32_t c = hist[k];
+    sh[k] = c;
+    if (c && k < kNumSym) atomicAdd(&gh[k], c);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_tok_hist_m: token histogram of one FRES block row from the non-zero masks
+// k_pix_fwd left behind (huffman_enc.cpp:98-144).  A lane takes one 64-symbol
+// word of the stream per iteration: its zero-run summary comes from the mask
+// alone (no SWAR scan of the symbols), the symbols are fetched only where the
+// word has a non-zero at all, and the scan / barrier cost is paid once per 64
+// symbols per lane instead of once per 32.  Counting is k_tok_hist's: one LDS
+// atomic per (run < 7, symbol) pair, exact run-length bins above.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tok_hist_m(Geom g, EncWs ws, int r0) {
+  __shared__ uint32_t hist[kHistStride];
+  __shared__ uint32_t hist2[kPairRuns][256];
+  __shared__ uint32_t hrun[kRunTab + 1];
+  __shared__ uint32_t s_sym[256 * 17];   // a lane's 64 symbols at a stride of 17 dwords (conflict-free dword stores)
+  __shared__ ZR sm[4];
+  const int r = blockIdx.x + r0, f = blockIdx.y, tid = threadIdx.x;
+  for (int k = tid; k < kHistStride; k += 256) hist[k] = 0;
+  for (int k = tid; k < kPairRuns * 256; k += 256) (&hist2[0][0])[k] = 0;
+  for (int k = tid; k < kRunTab + 1; k += 256) hrun[k] = 0;
+  const int cols = g.cols, nw = (cols + 63) >> 6, nwords = g.C * 64 * nw;
+  const uint8_t *sym = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
+  const unsigned long long *mrow = ws.fres_mask + (size_t)f * ws.mask_stride + (size_t)r * g.C * nw * 64;
+  ZR carry;
+  carry.tz = 0; carry.az = 0;   // runs never cross a block row (huffman_enc.cpp:105-106)
+  __syncthreads();
+  auto one = [&](int s, int, int) { atomicAdd(&hist[s], 1u); };
+  const uint8_t *mysym = reinterpret_cast<const uint8_t *>(s_sym) + tid * 68;
+  for (int base = 0; base < nwords; base += 256) {
+    const int W = base + tid;
+    const bool active = W < nwords;
+    const int seg = active ? W / nw : 0, wv = active ? W - seg * nw : 0;
+    const int nvalid = active ? min(64, cols - 64 * wv) : 0;
+    unsigned long long m = 0;
+    if (active) m = mrow[((size_t)(seg >> 6) * nw + wv) * 64 + (seg & 63)];
+    if (m) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(sym + (size_t)seg * cols + 64 * wv);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q * 16 < nvalid) {
+          const uint4 w = p[q];
+          uint32_t *d = s_sym + tid * 17 + 4 * q;
+          d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+        }
+    }
+    ZR mine;
+    mine.tz = m ? nvalid - (64 - __clzll(m)) : nvalid;
+    mine.az = m ? 0 : 1;
+    ZR total;
+    const ZR ex = block_scan_zr(mine, carry, sm, &total);
+    carry = total;
+    carry.az = 0;
+    int prev = -1 - ex.tz;   // position of the last non-zero before this word, relative to it
+    while (m) {
+      const int k = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int run = k - prev - 1;
+      const int sy = mysym[k];
+      prev = k;
+      if (__builtin_expect(run < kPairRuns, 1)) {
+        atomicAdd(&hist2[run][sy], 1u);
+      } else {
+        if (run < kRunTab) atomicAdd(&hrun[run], 1u);
+        else emit_run(run, one);
+        atomicAdd(&hist[sy], 1u);
+      }
+    }
+    if (active && W == nwords - 1) {   // the row's trailing zeros
+      const int run = nvalid - 1 - prev;
+      if (run) emit_run(run, one);
+    }
+  }
+  __syncthreads();
+  {
+    const int sy = tid;   // 256 threads = 256 literal values
+    uint32_t lit = 0, r1 = hist2[1][sy], r2 = hist2[2][sy], r3 = 0;
+#pragma unroll
+    for (int q = 0; q < kPairRuns; ++q) lit += hist2[q][sy];
+#pragma unroll
+    for (int q = 3; q < kPairRuns; ++q) r3 += hist2[q][sy];
+    if (lit) atomicAdd(&hist[sy], lit);
+    if (r1) atomicAdd(&hist[0], r1);
+    if (r2) atomicAdd(&hist[256], r2);
+    if (r3) atomicAdd(&hist[257], r3);
+  }
+  for (int q = kPairRuns + tid; q < kRunTab; q += 256) {   // 7..22 -> 258, 23..278 -> 259
+    const uint32_t c = hrun[q];
+    if (c) atomicAdd(&hist[q <= 22 ? 258 : 259], c);
+  }
+  __syncthreads();
+  uint32_t *sh = ws.span_hist_f + ((size_t)f * g.rows + r) * kHistStride;
+  uint32_t *gh = ws.hist + ((size_t)f * 2 + 1) * kHistStride;
+  for (int k = tid; k < kHistStride; k += 256) {
     const uint32_t c = hist[k];
     sh[k] = c;
     if (c && k < kNumSym) atomicAdd(&gh[k], c);
@@ -1489,6 +1808,25 @@ __global__ __launch_bounds__(256) void k_place_fres(Geom g, EncWs ws, const uint
     prof_end(prof, stream);                                    \
   } while (0)
 
+// The round-2 pixel stage (k_pix_fwd + masks) serves full tiles of packed RGBA8
+// whose rows are a multiple of 16 tiles (16-byte aligned symbol segments).
+static bool use_pix_path(const Geom &g) {
+  return g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4 && g.cols % 16 == 0;
+}
+
+static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, const ShiftTables &st,
+                       const uint8_t *d_fmap_lut, int r0, int n, int batch, hipStream_t stream,
+                       Profiler *prof) {
+  const unsigned gxt = (unsigned)((g.cols + kPixThreads - 1) / kPixThreads);
+  const dim3 grid(gxt, n, batch), block(kPixThreads);
+#define HIMG_PIX(Y, COLS)                                                                        \
+  HIMG_LAUNCH((k_pix_fwd<Y, COLS>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
+              ws.fres_stride, ws.fres_mask, ws.mask_stride, d_fmap_lut, st, r0)
+  if (g.ycbcr) { if (g.cols == 512) HIMG_PIX(true, 512); else HIMG_PIX(true, 0); }
+  else { if (g.cols == 512) HIMG_PIX(false, 512); else HIMG_PIX(false, 0); }
+#undef HIMG_PIX
+}
+
 // Full tiles of packed RGBA8: the packed-int16 kernel, block rows [r0, r0 + n).
 static void launch_tile_pk(const Geom &g, const EncWs &ws, const uint8_t *d_frames,
                            const ShiftTables &st, const uint8_t *d_fmap_lut, int r0, int n, int batch,
@@ -1529,14 +1867,22 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws.low,
               ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
-  if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
+  const bool pix = use_pix_path(g);
+  if (pix) {
+    launch_pix(g, ws, d_frames, st, d_fmap_lut, 0, g.rows, batch, stream, prof);
+  } else if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
     launch_tile_pk(g, ws, d_frames, st, d_fmap_lut, 0, g.rows, batch, stream, prof);
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
-  HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
+  if (pix) {
+    HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, batch), b256, g, ws, 0);   // LRES spans
+    HIMG_LAUNCH(k_tok_hist_m, dim3(g.rows, batch), b256, g, ws, 0);       // FRES rows, from the masks
+  } else {
+    HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
+  }
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
@@ -1551,7 +1897,9 @@ static void launch_tile_rows(const Geom &g, const EncWs &ws, const uint8_t *d_fr
                              const ShiftTables &st, const uint8_t *d_fmap_lut, int r0, int n,
                              hipStream_t stream, Profiler *prof) {
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
-  if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
+  if (use_pix_path(g)) {
+    launch_pix(g, ws, d_frame_base, st, d_fmap_lut, r0, n, 1, stream, prof);
+  } else if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
     launch_tile_pk(g, ws, d_frame_base, st, d_fmap_lut, r0, n, 1, stream, prof);
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, n, 1), dim3(kTileThreads), g, d_frame_base,
@@ -1572,7 +1920,8 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, a1 - a0, 1), b256, g, d_frame_base, ws.avg, ws.plane_stride, a0);
   HIMG_LAUNCH(k_lowres_blend, dim3(gx, l1 - r0, g.C), b256, g, ws.avg, ws.low, ws.plane_stride, r0);
   launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
-  HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
+  if (use_pix_path(g)) HIMG_LAUNCH(k_tok_hist_m, dim3(r1 - r0, 1), b256, g, ws, r0);
+  else HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
 }
 
 void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
