@@ -43,7 +43,6 @@ struct EncWs {
   uint8_t *avg, *low;        size_t plane_stride;  // C*rows*cols (padded)
   uint8_t *lres_sym;         size_t lres_stride;
   uint8_t *fres_sym;         size_t fres_stride;
-  unsigned long long *fres_mask; size_t mask_stride;  // [f][rows][C][nw][64] non-zero masks (k_pix_fwd), stride in words
   uint32_t *hist;            // [f][2][kHistStride]      0 = LRES, 1 = FRES
   uint32_t *span_hist_l;     // [f][lres_spans][kHistStride]
   uint32_t *span_hist_f;     // [f][rows][kHistStride]

@@ -122,7 +122,7 @@ struct himg_hip_ctx {
   } pipe;
 
   // Encoder workspace.
-  DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist, e_mask;
+  DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist;
   Geom enc_geom{};
   EncWs enc_ws{};
   int enc_batch = 0;
@@ -277,7 +277,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
     hipHostFree(ctx->pipe.h_meta);
   }
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
-                   &ctx->e_spanhist, &ctx->e_mask, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
+                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
   for (DevBuf *b : all) b->release();
@@ -380,9 +380,8 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   const size_t lres = round_up((size_t)g.lres_size + 16, 256);
   const size_t fres = round_up((size_t)g.fres_size + 16, 256);
   const int nsp = g.lres_spans + g.rows;
-  const size_t mask_words = round_up((size_t)g.rows * g.C * ((g.cols + 63) / 64) * 64, 32);
   if (!ctx->e_planes.reserve(2 * plane * batch) || !ctx->e_lres.reserve(lres * batch) ||
-      !ctx->e_fres.reserve(fres * batch) || !ctx->e_mask.reserve(mask_words * 8 * batch))
+      !ctx->e_fres.reserve(fres * batch))
     return fail(ctx, HIMG_ERR_HIP, "encoder workspace allocation failed");
   // Small per-frame arrays, carved from one allocation.
   size_t off = 0;
@@ -405,7 +404,6 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.plane_stride = plane;
   w.lres_sym = (uint8_t *)ctx->e_lres.p; w.lres_stride = lres;
   w.fres_sym = (uint8_t *)ctx->e_fres.p; w.fres_stride = fres;
-  w.fres_mask = (unsigned long long *)ctx->e_mask.p; w.mask_stride = mask_words;
   w.hist = (uint32_t *)(sm + o_hist);
   w.codes = (uint64_t *)(sm + o_codes);
   w.lens = (uint32_t *)(sm + o_lens);

@@ -540,15 +540,14 @@ __global__ __launch_bounds__(kTileThreads, 3) void k_tile_fwd_pk(Geom g, const u
 //     (mapper.cpp:159-182) is the identity up to 50, so the byte is the low byte
 //     of q unless some |q| > 50 -- tracked with one packed max per coefficient
 //     and redone with the LUT for the (rare) tile that needs it;
-//   * the non-zero MASKS of the symbols are a by-product: for every channel and
-//     coefficient one ballot = 64 consecutive symbols of the stream
-//     (encoder.cpp:320-323 layout); lane i keeps the word of coefficient i
-//     (v_writelane) and the wave stores 512 contiguous bytes per channel.  The
-//     entropy kernels read these 8 MB per frame instead of scanning 64 MiB of
-//     symbols for zeros.
-// Mask layout: word (c, i, wv) -- symbols (c*64 + i)*cols + 64*wv .. + 63 of the
-// block row -- is at mask[((v*C + c)*nw + wv)*64 + i], nw = ceil(cols / 64); bits
-// beyond the row's last tile are 0.
+//   * the symbol bytes leave through buffer_store_byte with the lane offset in a
+//     VGPR and the coefficient row's offset in an SGPR: no 64-bit address adds.
+// Tried and measured, not kept: having this kernel also leave the non-zero masks
+// of the symbol stream (one ballot per channel and coefficient, lane i keeping the
+// word of coefficient i through v_writelane) for the entropy kernels to tokenise
+// from: +0.05 ms here per 8 frames, and the mask-driven histogram kernel was no
+// faster than k_tok_hist (0.305 vs 0.295 ms) -- the per-token walk, not the search
+// for the zeros, is what those kernels spend their time on.
 // ---------------------------------------------------------------------------
 template <class F, int... I>
 __device__ __forceinline__ void for_seq_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -556,12 +555,6 @@ __device__ __forceinline__ void for_seq_impl(F &&f, std::integer_sequence<int, I
 }
 template <int N, class F>
 __device__ __forceinline__ void for_seq(F &&f) { for_seq_impl(f, std::make_integer_sequence<int, N>{}); }
-
-template <int I>
-__device__ __forceinline__ uint32_t writelane(uint32_t v, uint32_t s) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(I));
-  return v;
-}
 
 // lerp tree of downsampled.cpp:116-169 on four packed bytes.
 __device__ __forceinline__ void interp9_u8x4e(uint32_t a[9]) {
@@ -617,11 +610,10 @@ __device__ __forceinline__ pk16 pix_pair(uint32_t px) {
 constexpr int kPixThreads = 256;
 constexpr int kPixLut = 8192;
 
-template <bool YCBCR, int COLS>
+template <bool YCBCR, int COLS, bool FULL>
 __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_t *frames,
                                                             const uint8_t *low, size_t plane_stride,
                                                             uint8_t *fres_sym, size_t fres_stride,
-                                                            unsigned long long *fres_mask, size_t mask_stride,
                                                             const uint8_t *__restrict__ fmap_lut,
                                                             ShiftTables st, int v0) {
   // Companding LUT for magnitudes below kPixLut (every larger one maps to 127:
@@ -634,11 +626,20 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
   const int u = blockIdx.x * kPixThreads + threadIdx.x;
   const int v = blockIdx.y + v0, f = blockIdx.z;
   if ((int)(blockIdx.x * kPixThreads + (threadIdx.x & ~63)) >= cols) return;   // the whole wave is beyond the row
-  const bool valid = u < cols;
+  // FULL: cols is a multiple of 64, every lane of a live wave owns a tile.
+  const bool valid = FULL || u < cols;
   const int uc = valid ? u : cols - 1;
   const uint8_t *img = frames + (long long)f * g.frame_bytes;
   const int u2 = min(uc + 1, cols - 1), v2 = min(v + 1, g.rows - 1);
-  uint8_t *dst_row = fres_sym + (size_t)f * fres_stride + (size_t)v * g.row_block + uc;
+  // Wave-uniform base + 32-bit lane offset: the stores take the scalar-base form and
+  // the per-coefficient stride is scalar arithmetic, not 64-bit adds per lane.
+  // The symbol stores go through a buffer descriptor of the frame's symbol plane:
+  // buffer_store_byte takes the lane offset in a VGPR and the (wave-uniform) offset of
+  // the coefficient row in an SGPR -- no address arithmetic on the vector unit.
+  const __amdgpu_buffer_rsrc_t sym_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      fres_sym + (size_t)f * fres_stride, 0, (int)g.fres_size, 0x00020000);
+  const uint32_t row_off = (uint32_t)v * (uint32_t)g.row_block;
+  const uint32_t lane_off = (uint32_t)uc;
   const uint8_t *row0 = img + ((long long)(8 * v) * g.W + 8 * uc) * 4;
   const size_t pitch = (size_t)g.W * 4;
 
@@ -659,8 +660,6 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
     lr0[c] = (uint32_t)m[(size_t)v * cols + uc] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
     lr8[c] = (uint32_t)m[(size_t)v2 * cols + uc] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
   }
-  const int wv = u >> 6, nw = (cols + 63) >> 6;
-  unsigned long long *mrow = fres_mask + (size_t)f * mask_stride + ((size_t)v * g.C * nw + wv) * 64 + (threadIdx.x & 63);
 
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr) {
@@ -694,9 +693,7 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
     for (int x = 0; x < 8; ++x)
       wht8_pk(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
 
-    uint8_t *dstA = dst_row + (size_t)cA * 64 * cols;
-    uint8_t *dstB = dst_row + (size_t)cB * 64 * cols;
-    uint32_t mA_lo = 0, mA_hi = 0, mB_lo = 0, mB_hi = 0;
+    const uint32_t offA = row_off + (uint32_t)(cA * 64 * cols), offB = row_off + (uint32_t)(cB * 64 * cols);
     for_seq<64>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       constexpr int pos = kScan[i];
@@ -724,16 +721,10 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
         q = (code ^ sign) - sign;
       }
       if (valid) {
-        dstA[(size_t)i * cols] = (uint8_t)q.x;
-        dstB[(size_t)i * cols] = (uint8_t)q.y;
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q.x, sym_rsrc, lane_off, offA + (uint32_t)(i * cols), 0);
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q.y, sym_rsrc, lane_off, offB + (uint32_t)(i * cols), 0);
       }
-      const unsigned long long bA = __ballot(valid && q.x != 0);
-      const unsigned long long bB = __ballot(valid && q.y != 0);
-      mA_lo = writelane<i>(mA_lo, (uint32_t)bA); mA_hi = writelane<i>(mA_hi, (uint32_t)(bA >> 32));
-      mB_lo = writelane<i>(mB_lo, (uint32_t)bB); mB_hi = writelane<i>(mB_hi, (uint32_t)(bB >> 32));
     });
-    mrow[(size_t)cA * nw * 64] = ((unsigned long long)mA_hi << 32) | mA_lo;
-    mrow[(size_t)cB * nw * 64] = ((unsigned long long)mB_hi << 32) | mB_lo;
   }
 }
 
@@ -1067,104 +1058,6 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
                             : ws.span_hist_f + ((size_t)f * g.rows + (sp - g.lres_spans)) * kHistStride);
   uint32_t *gh = ws.hist + ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
   for (int k = threadIdx.x; k < kHistStride; k += 256) {
-    const uint32_t c = hist[k];
-    sh[k] = c;
-    if (c && k < kNumSym) atomicAdd(&gh[k], c);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_tok_hist_m: token histogram of one FRES block row from the non-zero masks
-// k_pix_fwd left behind (huffman_enc.cpp:98-144).  A lane takes one 64-symbol
-// word of the stream per iteration: its zero-run summary comes from the mask
-// alone (no SWAR scan of the symbols), the symbols are fetched only where the
-// word has a non-zero at all, and the scan / barrier cost is paid once per 64
-// symbols per lane instead of once per 32.  Counting is k_tok_hist's: one LDS
-// atomic per (run < 7, symbol) pair, exact run-length bins above.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tok_hist_m(Geom g, EncWs ws, int r0) {
-  __shared__ uint32_t hist[kHistStride];
-  __shared__ uint32_t hist2[kPairRuns][256];
-  __shared__ uint32_t hrun[kRunTab + 1];
-  __shared__ uint32_t s_sym[256 * 17];   // a lane's 64 symbols at a stride of 17 dwords (conflict-free dword stores)
-  __shared__ ZR sm[4];
-  const int r = blockIdx.x + r0, f = blockIdx.y, tid = threadIdx.x;
-  for (int k = tid; k < kHistStride; k += 256) hist[k] = 0;
-  for (int k = tid; k < kPairRuns * 256; k += 256) (&hist2[0][0])[k] = 0;
-  for (int k = tid; k < kRunTab + 1; k += 256) hrun[k] = 0;
-  const int cols = g.cols, nw = (cols + 63) >> 6, nwords = g.C * 64 * nw;
-  const uint8_t *sym = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
-  const unsigned long long *mrow = ws.fres_mask + (size_t)f * ws.mask_stride + (size_t)r * g.C * nw * 64;
-  ZR carry;
-  carry.tz = 0; carry.az = 0;   // runs never cross a block row (huffman_enc.cpp:105-106)
-  __syncthreads();
-  auto one = [&](int s, int, int) { atomicAdd(&hist[s], 1u); };
-  const uint8_t *mysym = reinterpret_cast<const uint8_t *>(s_sym) + tid * 68;
-  for (int base = 0; base < nwords; base += 256) {
-    const int W = base + tid;
-    const bool active = W < nwords;
-    const int seg = active ? W / nw : 0, wv = active ? W - seg * nw : 0;
-    const int nvalid = active ? min(64, cols - 64 * wv) : 0;
-    unsigned long long m = 0;
-    if (active) m = mrow[((size_t)(seg >> 6) * nw + wv) * 64 + (seg & 63)];
-    if (m) {
-      const uint4 *p = reinterpret_cast<const uint4 *>(sym + (size_t)seg * cols + 64 * wv);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (q * 16 < nvalid) {
-          const uint4 w = p[q];
-          uint32_t *d = s_sym + tid * 17 + 4 * q;
-          d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-        }
-    }
-    ZR mine;
-    mine.tz = m ? nvalid - (64 - __clzll(m)) : nvalid;
-    mine.az = m ? 0 : 1;
-    ZR total;
-    const ZR ex = block_scan_zr(mine, carry, sm, &total);
-    carry = total;
-    carry.az = 0;
-    int prev = -1 - ex.tz;   // position of the last non-zero before this word, relative to it
-    while (m) {
-      const int k = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int run = k - prev - 1;
-      const int sy = mysym[k];
-      prev = k;
-      if (__builtin_expect(run < kPairRuns, 1)) {
-        atomicAdd(&hist2[run][sy], 1u);
-      } else {
-        if (run < kRunTab) atomicAdd(&hrun[run], 1u);
-        else emit_run(run, one);
-        atomicAdd(&hist[sy], 1u);
-      }
-    }
-    if (active && W == nwords - 1) {   // the row's trailing zeros
-      const int run = nvalid - 1 - prev;
-      if (run) emit_run(run, one);
-    }
-  }
-  __syncthreads();
-  {
-    const int sy = tid;   // 256 threads = 256 literal values
-    uint32_t lit = 0, r1 = hist2[1][sy], r2 = hist2[2][sy], r3 = 0;
-#pragma unroll
-    for (int q = 0; q < kPairRuns; ++q) lit += hist2[q][sy];
-#pragma unroll
-    for (int q = 3; q < kPairRuns; ++q) r3 += hist2[q][sy];
-    if (lit) atomicAdd(&hist[sy], lit);
-    if (r1) atomicAdd(&hist[0], r1);
-    if (r2) atomicAdd(&hist[256], r2);
-    if (r3) atomicAdd(&hist[257], r3);
-  }
-  for (int q = kPairRuns + tid; q < kRunTab; q += 256) {   // 7..22 -> 258, 23..278 -> 259
-    const uint32_t c = hrun[q];
-    if (c) atomicAdd(&hist[q <= 22 ? 258 : 259], c);
-  }
-  __syncthreads();
-  uint32_t *sh = ws.span_hist_f + ((size_t)f * g.rows + r) * kHistStride;
-  uint32_t *gh = ws.hist + ((size_t)f * 2 + 1) * kHistStride;
-  for (int k = tid; k < kHistStride; k += 256) {
     const uint32_t c = hist[k];
     sh[k] = c;
     if (c && k < kNumSym) atomicAdd(&gh[k], c);
@@ -1808,10 +1701,9 @@ __global__ __launch_bounds__(256) void k_place_fres(Geom g, EncWs ws, const uint
     prof_end(prof, stream);                                    \
   } while (0)
 
-// The round-2 pixel stage (k_pix_fwd + masks) serves full tiles of packed RGBA8
-// whose rows are a multiple of 16 tiles (16-byte aligned symbol segments).
+// The round-2 pixel stage (k_pix_fwd) serves full tiles of packed RGBA8.
 static bool use_pix_path(const Geom &g) {
-  return g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4 && g.cols % 16 == 0;
+  return g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4;
 }
 
 static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, const ShiftTables &st,
@@ -1819,11 +1711,12 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
                        Profiler *prof) {
   const unsigned gxt = (unsigned)((g.cols + kPixThreads - 1) / kPixThreads);
   const dim3 grid(gxt, n, batch), block(kPixThreads);
-#define HIMG_PIX(Y, COLS)                                                                        \
-  HIMG_LAUNCH((k_pix_fwd<Y, COLS>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
-              ws.fres_stride, ws.fres_mask, ws.mask_stride, d_fmap_lut, st, r0)
-  if (g.ycbcr) { if (g.cols == 512) HIMG_PIX(true, 512); else HIMG_PIX(true, 0); }
-  else { if (g.cols == 512) HIMG_PIX(false, 512); else HIMG_PIX(false, 0); }
+#define HIMG_PIX(Y, COLS, FULL)                                                                  \
+  HIMG_LAUNCH((k_pix_fwd<Y, COLS, FULL>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
+              ws.fres_stride, d_fmap_lut, st, r0)
+  const bool full = g.cols % 64 == 0;
+  if (g.ycbcr) { if (g.cols == 512) HIMG_PIX(true, 512, true); else if (full) HIMG_PIX(true, 0, true); else HIMG_PIX(true, 0, false); }
+  else { if (full) HIMG_PIX(false, 0, true); else HIMG_PIX(false, 0, false); }
 #undef HIMG_PIX
 }
 
@@ -1877,12 +1770,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
-  if (pix) {
-    HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, batch), b256, g, ws, 0);   // LRES spans
-    HIMG_LAUNCH(k_tok_hist_m, dim3(g.rows, batch), b256, g, ws, 0);       // FRES rows, from the masks
-  } else {
-    HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
-  }
+  HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
@@ -1920,8 +1808,7 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, a1 - a0, 1), b256, g, d_frame_base, ws.avg, ws.plane_stride, a0);
   HIMG_LAUNCH(k_lowres_blend, dim3(gx, l1 - r0, g.C), b256, g, ws.avg, ws.low, ws.plane_stride, r0);
   launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
-  if (use_pix_path(g)) HIMG_LAUNCH(k_tok_hist_m, dim3(r1 - r0, 1), b256, g, ws, r0);
-  else HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
+  HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
 }
 
 void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
