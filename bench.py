@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams (one engine context each) the batch is split over, so the short "
                          "serial kernels of one group overlap the wide kernels of the other")
+    ap.add_argument("--stagger", type=int, default=1,
+                    help="1: odd groups run decode-then-encode so that the groups are in opposite phases")
     ap.add_argument("--width", type=int, default=None, help="default 4096 (frames) / 16384 (rows)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--quality", type=int, default=50)
@@ -434,13 +436,24 @@ def main():
                             st.cuda_stream)
 
     def step():
-        # Group i's encode and decode are ordered on its own stream; groups overlap.
+        # Every group is encoded once and decoded once per step, each group on its own
+        # stream; groups overlap.  Odd groups run decode-then-encode (they decode the
+        # streams their previous step's encode left in d_out -- the same bytes, the
+        # frames do not change): the groups are then in opposite phases, so the short
+        # serial kernels of one (tree build, container parse, LRES chain) run beside the
+        # wide kernels of the other instead of beside its own twins.
         for i, (e, st) in enumerate(zip(engines, streams)):
             sl = slice(i * G, (i + 1) * G)
-            e.encode_device(d_frames[sl], G, W, H, 4, 4, Q, True, d_out[sl], cap, d_sizes[sl],
-                            d_st_e[sl], st.cuda_stream)
-            e.decode_device(d_out[sl], cap, h_sizes[sl], G, W, H, 4, d_pix[sl], d_st_d[sl],
-                            st.cuda_stream)
+            if args.stagger and (i & 1):
+                e.decode_device(d_out[sl], cap, h_sizes[sl], G, W, H, 4, d_pix[sl], d_st_d[sl],
+                                st.cuda_stream)
+                e.encode_device(d_frames[sl], G, W, H, 4, 4, Q, True, d_out[sl], cap, d_sizes[sl],
+                                d_st_e[sl], st.cuda_stream)
+            else:
+                e.encode_device(d_frames[sl], G, W, H, 4, 4, Q, True, d_out[sl], cap, d_sizes[sl],
+                                d_st_e[sl], st.cuda_stream)
+                e.decode_device(d_out[sl], cap, h_sizes[sl], G, W, H, 4, d_pix[sl], d_st_d[sl],
+                                st.cuda_stream)
 
     decode()
     torch.cuda.synchronize()

@@ -99,6 +99,7 @@ struct DecWs {
   DecFrame *frames;          // [f]
   int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
   uint2 *grp;                // [f][2][1<<kLutBits] group table (kernels_dec.hip GrpTables)
+  uint32_t *gyc;             // [f][2][1<<kLutBits] step words of the count-only groups (no four-byte limit)
   uint32_t *sub;             // [f][2][kSubEntries] second-level entries for codes longer than kLutBits
   uint32_t *row_off;         // [f][rows] payload byte offset of each FRES row
   uint32_t *row_len;         // [f][rows]
@@ -111,6 +112,7 @@ struct DecWs {
   uint32_t *lane_off;        // [f][rows][kDecThreads + 4]: offsets, then total, chain end (bits), valid flag
   uint32_t *parse_stats;     // [f][4] k_dec_parse phase cycles / 16
   uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
+  uint32_t *rc_stats;        // [f][rows][8] k_row_count phase cycles / 16 (slowest wave)
   // Parallel LRES decode (k_lres_spec / verify / write).
   int lres_chunks;           // chunk slots per frame (upper bound from lres_size)
   uint32_t *spec_start;      // [f][lres_chunks][1024] lane start, bits from the chunk's nominal start

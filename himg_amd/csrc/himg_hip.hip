@@ -129,7 +129,7 @@ struct himg_hip_ctx {
   bool enc_valid = false;
 
   // Decoder workspace.
-  DevBuf d_frames, d_nodes, d_grp, d_sub, d_lane, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
+  DevBuf d_frames, d_nodes, d_grp, d_gyc, d_sub, d_lane, d_rows, d_lres, d_fres, d_planes, d_sizes, d_stats, d_spec;
   Geom dec_geom{};
   DecWs dec_ws{};
   int dec_batch = 0;
@@ -277,7 +277,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
     hipHostFree(ctx->pipe.h_meta);
   }
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
-                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
+                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_gyc, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
   for (DevBuf *b : all) b->release();
@@ -429,16 +429,18 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   if (!ctx->d_frames.reserve(sizeof(DecFrame) * batch) ||
       !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 3 * 4) ||
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
+      !ctx->d_gyc.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
       !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 4) ||
       !ctx->d_lane.reserve((size_t)batch * g.rows * (2 * kDecThreads + 4) * 4) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
       !ctx->d_sizes.reserve((size_t)batch * 4) ||
-      !ctx->d_stats.reserve(((size_t)batch * (g.rows + 1) * 8 + (size_t)batch * 4) * 4))
+      !ctx->d_stats.reserve(((size_t)batch * (g.rows + 1) * 8 + (size_t)batch * 4 + (size_t)batch * g.rows * 8) * 4))
     return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
   w.frames = (DecFrame *)ctx->d_frames.p;
   w.nodes = (int32_t *)ctx->d_nodes.p;
   w.grp = (uint2 *)ctx->d_grp.p;
+  w.gyc = (uint32_t *)ctx->d_gyc.p;
   w.sub = (uint32_t *)ctx->d_sub.p;
   w.lane_start = (uint32_t *)ctx->d_lane.p;
   w.lane_off = w.lane_start + (size_t)batch * g.rows * kDecThreads;
@@ -449,6 +451,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.low = (uint8_t *)ctx->d_planes.p; w.plane_stride = plane;
   w.stats = (uint32_t *)ctx->d_stats.p;
   w.parse_stats = w.stats + (size_t)batch * (g.rows + 1) * 8;
+  w.rc_stats = w.parse_stats + (size_t)batch * 4;
   {
     // LRES payload <= lres_size + tree bytes (huffman_enc.cpp:242-244).
     const size_t max_bits = 8ull * ((size_t)g.lres_size + kTreeStride);
@@ -1069,6 +1072,7 @@ extern "C" int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void 
       case HIMG_DBG_FRES_SYM: src = w.fres_sym + frame * w.fres_stride; n = (size_t)g.fres_size; break;
       case HIMG_DBG_DEC_STATS: src = w.stats + (size_t)frame * (g.rows + 1) * 8; n = (size_t)(g.rows + 1) * 32; break;
       case HIMG_DBG_PARSE_STATS: src = w.parse_stats + (size_t)frame * 4; n = 16; break;
+      case HIMG_DBG_ROWCOUNT_STATS: src = w.rc_stats + (size_t)frame * g.rows * 8; n = (size_t)g.rows * 32; break;
       default: return HIMG_ERR_ARG;
     }
   }

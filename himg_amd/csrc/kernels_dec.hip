@@ -18,6 +18,8 @@
 // One entropy-decode engine serves all of them: see "Entropy decoding" below.
 #include "himg_dev.h"
 
+#include <cstdlib>
+
 namespace himg_dev {
 
 __device__ static constexpr uint8_t kScanD[64] = {
@@ -142,6 +144,24 @@ __device__ __forceinline__ uint32_t lut_leaf(int sym, int bits) {
 }
 __device__ __forceinline__ uint32_t lut_node(int node, int bits) {
   return 512u | ((uint32_t)bits << 10) | ((uint32_t)node << 20);
+}
+// Step word of the decoder (see "Entropy decoding" below): [4:0] code bits to
+// consume, [9:5] extra bits that follow, [18:10] symbols produced before the
+// extra-bits value is added, [22:19] code bits / [25:23] class of the group's first
+// token, [31:27] = [4:0] + [9:5].
+__device__ __forceinline__ uint32_t grp_y(uint32_t tb, uint32_t eb, uint32_t cb, uint32_t s_tb, uint32_t s_class) {
+  return tb | (eb << 5) | (cb << 10) | (s_tb << 19) | (s_class << 23) | ((tb + eb) << 27);
+}
+// Second-level entry of a token whose code is longer than kLutBits (the first
+// kLutBits bits are consumed before it is read): [4:0] the remaining code bits (>= 1,
+// which tells it from a node reference), [9:5] extra bits, [18:10] run base / 1,
+// [26:19] the literal byte.
+__device__ __forceinline__ uint32_t sub_leaf(int sym, uint32_t rest_bits) {
+  const uint32_t c = sym < 256 ? 0u : (uint32_t)sym - 255u;
+  const uint32_t eb = (0xE84200u >> (4u * c)) & 15u;
+  const unsigned long long kBases = 1ull | (2ull << 9) | (3ull << 18) | (7ull << 27) | (23ull << 36) | (279ull << 45);
+  const uint32_t cb = (uint32_t)(kBases >> (9u * c)) & 511u;
+  return rest_bits | (eb << 5) | (cb << 10) | ((sym < 256 ? (uint32_t)sym : 0u) << 19);
 }
 
 // ---------------------------------------------------------------------------
@@ -375,8 +395,10 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
       const int sym = nodes[3 * k + 2];
       if (m == 0 || d > m) continue;
       if (sym >= 0) {
-        for (uint32_t i = 0; i < (1u << (m - d)); ++i)
-          s_sub[s][off + ((i << d) | rel)] = lut_leaf(sym, depth) | ((uint32_t)k << 20);
+        // A valid leaf: the token resolved in the decoder's step format.  A symbol the
+        // reference rejects stays a node reference: the walk ends on it and flags it.
+        const uint32_t e = sym <= 260 ? sub_leaf(sym, d) : lut_node(k, depth);
+        for (uint32_t i = 0; i < (1u << (m - d)); ++i) s_sub[s][off + ((i << d) | rel)] = e;
       } else if (d == m) {
         s_sub[s][off + rel] = lut_node(k, depth);
       }
@@ -419,7 +441,7 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
       uint2 r;
       if (ntok) {
         r.x = bytes;
-        r.y = used | (g_eb << 4) | (nout << 8) | (s_tb << 17) | (s_class << 21);
+        r.y = grp_y(used, g_eb, nout, s_tb, s_class);
       } else {
         // The first code is longer than the table: .x says where to continue --
         // bit 31 set: sub-table (offset << 8 | index bits); else the tree walk
@@ -432,6 +454,27 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
         r.y = 0;
       }
       grp[idx] = r;
+      // The same greedy group WITHOUT the four-byte limit, for the passes that only
+      // count (k_row_count, lead-ins): as many tokens as have their codes inside the
+      // kLutBits known bits -- more bits per step where zeros and short literals
+      // alternate.
+      uint32_t yc = 0;
+      if (ntok) {
+        uint32_t u2 = 0, n2 = 0, eb2 = 0;
+        for (;;) {
+          const uint32_t e = s_lut[s][(idx >> u2) & ((1u << kLutBits) - 1)];
+          const uint32_t len = (e >> 10) & 63u, sym = e & 511u;
+          if ((e & 512u) || len == 0 || sym > 260 || u2 + len > (uint32_t)kLutBits) break;
+          u2 += len;
+          if (sym <= 256) { n2 += sym == 256 ? 2u : 1u; continue; }
+          const uint32_t cls = sym - 255u;
+          n2 += cls == 2 ? 3u : cls == 3 ? 7u : cls == 4 ? 23u : 279u;
+          eb2 = cls == 2 ? 2u : cls == 3 ? 4u : cls == 4 ? 8u : 14u;
+          break;
+        }
+        yc = grp_y(u2, eb2, n2, s_tb, s_class);
+      }
+      ws.gyc[((size_t)f * 2 + s) * (1u << kLutBits) + idx] = yc;
     }
   }
   if (lane == 0) {   // phase cycles / 16 for tools/dec_stats.py (after the memset of stats)
@@ -502,18 +545,27 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
 //
 // Group table entry (uint2), indexed by the next kLutBits stream bits:
 //   .x  the first 4 output bytes of the group (0 where the output is a zero)
-//   .y  [3:0]   code bits of the whole group   [7:4]   extra bits that follow them
-//       [16:8]  symbols it produces, before the extra-bits value is added
-//       [20:17] code bits of its first token    [23:21] class of the first token:
+//   .y  [4:0]   code bits of the whole group   [9:5]   extra bits that follow them
+//       [18:10] symbols it produces, before the extra-bits value is added
+//       [22:19] code bits of its first token    [25:23] class of the first token:
 //               0 literal / single zero, 1 two zeros, 2..5 zero runs 257..260
-//   .y == 0: the first code is longer than the table; .x = node | depth << 16
-//            is where the tree walk continues.
+//       [31:27] [4:0] + [9:5]: the bits the step consumes
+//       (so the extra-bits value is v_bfe_u32(window, y, y >> 5) -- the hardware
+//       takes the low five bits of either operand -- and the step is five
+//       instructions from the table word to the new window)
+//   .y == 0: the first code is longer than the table; .x says where to continue:
+//            bit 31 set: second-level table (offset << 8 | index bits), whose
+//            entries are step words of ONE token (sub_leaf) or node references;
+//            else node | depth << 16 for the tree walk.
 // A lane owns the tokens that START in [start, lim): the whole group is taken
 // while pos + kLutBits <= lim (every token of it then starts before lim), the
 // first token alone otherwise.
 // ---------------------------------------------------------------------------
 constexpr int kWinBytes = 32768;  // output window in LDS (streams that go to HBM)
 constexpr uint32_t kMinSubBits = 128;  // shortest sub-sequence a lane decodes (short rows: more lanes busy)
+constexpr int kPayWords = 9216 + 8;     // k_row_count: LDS words for a row's payload
+constexpr uint32_t kPayPad = 4;         // dwords past the payload the reader may touch (window look-ahead)
+constexpr uint32_t kJoinBits = 64;     // a moved lane re-joins its earlier decode this far past its nominal start
 
 struct GrpTables {
   const uint2 *grp;           // LDS, 1 << kLutBits entries
@@ -553,14 +605,16 @@ struct StreamShared {            // small LDS state of the stream decoder
   unsigned long long endbit;     // bits consumed when the output became complete
   int flag;
   int err;
+  uint32_t dbg[2];               // diagnostics: lanes that re-joined / re-decoded in rounds >= 2
 };
 
 // Bit window over the stream's dwords in global memory.  Word indices are
 // clamped to the dword that holds the stream's last byte: bits past the end of
 // the stream repeat that dword, which only a token that overruns the payload can
 // see -- and such a stream is rejected whatever those bits are.
-struct GReader {
-  const uint32_t *w;   // dword-aligned window base
+template <class PTR>
+struct ReaderT {
+  PTR w;               // dword-aligned window base (global memory, or LDS for a staged payload)
   uint32_t jmax;       // index of the stream's last dword
   unsigned long long win;
   int nb;              // valid bits in win
@@ -574,7 +628,7 @@ struct GReader {
   __device__ __forceinline__ uint32_t attach(const uint8_t *p, uint32_t stream_size,
                                              unsigned long long abs_bit) {
     const uint32_t gb = (uint32_t)(abs_bit >> 5) * 4u;
-    w = reinterpret_cast<const uint32_t *>(p + gb);
+    w = (PTR)reinterpret_cast<const uint32_t *>(p + gb);
     jmax = ((stream_size - 1u) >> 2) - (gb >> 2);
     return (uint32_t)(abs_bit - 8ull * gb);
   }
@@ -596,6 +650,8 @@ struct GReader {
   }
   __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
 };
+typedef ReaderT<const uint32_t *> GReader;                                        // payload in place (L2)
+typedef ReaderT<const __attribute__((address_space(3))) uint32_t *> LReader;      // payload staged in LDS
 
 // Extra bits and run base per token class (huffman_common.h:24-28).
 __device__ __forceinline__ uint32_t class_eb(uint32_t c) { return (0xE84200u >> (4u * c)) & 15u; }
@@ -604,87 +660,116 @@ __device__ __forceinline__ uint32_t class_base(uint32_t c) {
   return (uint32_t)(kBases >> (9u * c)) & 511u;
 }
 
-// One decode step.  Reads the table at the window, resolves group / first token
-// / long code, consumes the bits and returns what the step produced.  The common
-// case is branch free; `single` is true only in a lane's last kLutBits bits, and
-// codes longer than the table are rare.  bad is set (never cleared) on symbols
-// the reference rejects (huffman_dec.cpp:349-352).
-template <bool WANT_BYTES, bool SOA = false>
-__device__ __forceinline__ void lean_step(GReader &rd, const GrpTables &t, bool single,
+// The step word of a group entry reduced to its FIRST token (a lane's last
+// kLutBits bits: it owns the tokens that START in its range).
+__device__ __forceinline__ uint32_t first_token_word(uint32_t y) {
+  const uint32_t c = (y >> 23) & 7u, tb = (y >> 19) & 15u, eb = class_eb(c);
+  return tb | (eb << 5) | (class_base(c) << 10) | ((tb + eb) << 27);
+}
+
+// A token whose code is longer than the first-level table (huffman_dec.cpp:291-328):
+// out of line of the hot loops, it resolves ONE token -- second-level table, the
+// tree below it for whatever is deeper still --, consumes the code bits and returns
+// a step word whose code-bit count is 0 (only the extra bits are left to take).
+// *pre = code bits consumed, *byte = the literal (0 for runs).  bad is set (never
+// cleared) on symbols the reference rejects (huffman_dec.cpp:349-352).
+template <bool SOA, class RD>
+__device__ __forceinline__ uint32_t long_token(RD &rd, const GrpTables &t, uint32_t idx, uint32_t *pre,
+                                            uint32_t *byte, bool *bad) {
+  const uint32_t ex = SOA ? t.gx[idx] : t.grp[idx].x;
+  int node = (int)(ex & 0xffffu), len = (int)((ex >> 16) & 0x7fffu), base = 0;
+  if (ex >> 31) {
+    rd.consume(kLutBits);
+    rd.refill();
+    base = kLutBits;
+    const uint32_t e2 = t.sub[((ex >> 8) & 0xffffu) + __builtin_amdgcn_ubfe((uint32_t)rd.win, 0, ex & 255u)];
+    if (e2 & 31u) {   // resolved: the common case by far
+      const uint32_t rest = e2 & 31u, eb = (e2 >> 5) & 31u;
+      rd.consume((int)rest);
+      rd.refill();
+      *pre = kLutBits + rest;
+      *byte = (e2 >> 19) & 255u;
+      return (e2 & 0x0007ffe0u) | (eb << 27);
+    }
+    node = (int)(e2 >> 20);
+    len = (int)((e2 >> 10) & 63u);
+    if (e2 == 0) len = 0;   // nothing there: flagged below
+  }
+  while (len >= base && t.sy[node] < 0 && len < kMaxDepth) {
+    node = ((rd.win >> (len - base)) & 1ull) ? t.cb[node] : t.ca[node];
+    ++len;
+  }
+  const int sym = t.sy[node];
+  const bool ok = sym >= 0 && sym <= 260 && len > base;
+  if (!ok) *bad = true;
+  if (len <= base) len = base + 1;  // keep moving on a degenerate tree
+  rd.consume(len - base);
+  rd.refill();
+  *pre = (uint32_t)len;
+  const uint32_t c = !ok ? 0u : (sym < 256 ? 0u : (uint32_t)sym - 255u);
+  const uint32_t eb = class_eb(c);
+  *byte = (ok && sym < 256) ? (uint32_t)sym : 0u;
+  return (eb << 5) | ((ok ? class_base(c) : 0u) << 10) | (eb << 27);
+}
+
+// One decode step in its general form (the tails and the exact paths; the hot
+// loops below inline the same thing without the `single` test).
+template <bool WANT_BYTES, bool SOA = false, class RD = GReader>
+__device__ __forceinline__ void lean_step(RD &rd, const GrpTables &t, bool single,
                                           uint32_t *nbits, uint32_t *count, uint32_t *bytes,
                                           bool *bad) {
   rd.refill();
   const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
-  uint32_t y, bx = 0;
-  if (WANT_BYTES) { const uint2 e = t.grp[idx]; bx = e.x; y = e.y; }
+  uint32_t y, by = 0, pre = 0;
+  if (WANT_BYTES) { const uint2 e = t.grp[idx]; by = e.x; y = e.y; }
   else if (SOA) y = t.gy[idx];
   else y = reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
-  uint32_t tb = y & 15u, eb = (y >> 4) & 15u, cb = (y >> 8) & 511u, pre = 0, by = bx;
-  if (single) {
-    // (The empty asm has "side effects", which makes the compiler keep a real
-    // branch around this block instead of predicating it into every step: lanes
-    // are `single` in their last few steps only.)
-    asm volatile("" ::: "memory");
-    {
-      const uint32_t c = (y >> 21) & 7u;
-      tb = (y >> 17) & 15u;
-      eb = class_eb(c);
-      cb = class_base(c);
-      by &= 255u;
-    }
+  if (__builtin_expect(y == 0, 0)) {
+    y = long_token<SOA>(rd, t, idx, &pre, &by, bad);
+  } else if (single) {
+    y = first_token_word(y);
+    by &= 255u;
   }
-  if (__builtin_expect(tb == 0, 0)) {
-    // Code longer than the table (huffman_dec.cpp:291-328): the second-level
-    // table resolves it with one more read; whatever is deeper still walks the
-    // tree from the node found there.
-    const uint32_t ex = WANT_BYTES ? bx : (SOA ? t.gx[idx] : t.grp[idx].x);
-    int node = (int)(ex & 0xffffu), len = (int)((ex >> 16) & 0x7fffu);
-    if (ex >> 31) {
-      const uint32_t e2 = t.sub[((ex >> 8) & 0xffffu) +
-                                __builtin_amdgcn_ubfe((uint32_t)(rd.win >> kLutBits), 0, ex & 255u)];
-      node = (int)(e2 >> 20);
-      len = (int)((e2 >> 10) & 63u);
-    }
-    while (t.sy[node] < 0 && len < kMaxDepth) {
-      node = ((rd.win >> len) & 1ull) ? t.cb[node] : t.ca[node];
-      ++len;
-    }
-    const int sym = t.sy[node];
-    const bool ok = sym >= 0 && sym <= 260 && len > 0;
-    if (!ok) *bad = true;
-    if (len == 0) len = 1;  // keep moving on a degenerate tree
-    rd.consume(len);
-    rd.refill();
-    pre = (uint32_t)len;
-    const uint32_t c = !ok ? 0u : (sym < 256 ? 0u : (uint32_t)sym - 255u);
-    eb = class_eb(c);
-    cb = ok ? class_base(c) : 0u;
-    by = (ok && sym < 256) ? (uint32_t)sym : 0u;
-  }
-  const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, tb, eb);
-  const uint32_t n = tb + eb;
+  const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);   // the hardware takes [4:0] of either
+  const uint32_t n = y >> 27;
   rd.consume((int)n);
   *nbits = pre + n;
-  *count = cb + extra;
+  *count = ((y >> 10) & 511u) + extra;
   *bytes = by;
 }
 
 // Count pass: the tokens that start in [pos, lim).  Returns where the last one
-// ends and how many symbols they produce.
-template <bool SOA = false>
-__device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint32_t pos,
-                                           uint32_t lim, uint32_t *endpos, uint32_t *count) {
+// ends and how many symbols they produce.  Two loops: whole groups while every
+// token of a group is sure to start before lim (pos + kLutBits <= lim), single
+// tokens for the last few bits -- so that the hot loop carries no `single` test.
+// cont: the reader already stands at pos (a previous call ended there).
+template <bool SOA = false, class RD = GReader>
+__device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t pos,
+                                           uint32_t lim, uint32_t *endpos, uint32_t *count,
+                                           bool cont = false) {
   uint32_t c = 0;
   if (pos < lim) {
-    rd.init(pos);
+    if (!cont) rd.init(pos);
     const int limk = (int)lim - kLutBits;
     bool bad = false;
-    do {
+    while ((int)pos <= limk) {
+      rd.refill();
+      const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
+      uint32_t y = SOA ? t.gy[idx] : reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
+      uint32_t pre = 0, by;
+      if (__builtin_expect(y == 0, 0)) y = long_token<SOA>(rd, t, idx, &pre, &by, &bad);
+      const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
+      const uint32_t n = y >> 27;
+      rd.consume((int)n);
+      pos += pre + n;
+      c += ((y >> 10) & 511u) + extra;
+    }
+    while (pos < lim) {
       uint32_t nbits, cnt, by;
-      lean_step<false, SOA>(rd, t, (int)pos > limk, &nbits, &cnt, &by, &bad);
+      lean_step<false, SOA>(rd, t, true, &nbits, &cnt, &by, &bad);
       pos += nbits;
       c += cnt;
-    } while (pos < lim);
+    }
   }
   *endpos = pos;
   *count = c;
@@ -698,15 +783,17 @@ __device__ __forceinline__ void lean_count(GReader &rd, const GrpTables &t, uint
 // lanes whose start changes decode again.
 // Lanes whose range lies beyond the payload (`active` false) own nothing and stay
 // out of it: passing the chain's end along them would cost one round per lane.
-template <bool SOA = false>
-__device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, StreamShared *sh,
+template <bool SOA = false, class RD = GReader>
+__device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, StreamShared *sh,
                                               uint32_t first, bool active, uint32_t lim,
                                               uint32_t *start_io, uint32_t *endpos_io,
                                               uint32_t *cnt_io, uint32_t *rounds, bool warm,
-                                              uint32_t lead_bits, long long *c_first = nullptr) {
+                                              uint32_t lead_bits, long long *c_first = nullptr,
+                                              long long *c_phase = nullptr) {
   const int tid = threadIdx.x;
   const long long t_in = clock64();
   uint32_t start = *start_io, endpos = *endpos_io, cnt = *cnt_io;
+  const uint32_t nominal = start;   // cold: the lane's nominal boundary
   bool dirty = active;
   if (tid == 0 && !warm) start = first;
   // Lead-in: instead of starting blind at its nominal boundary, a lane decodes the
@@ -721,15 +808,42 @@ __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, 
     lean_count<SOA>(rd, tb, from, start, &guess, &none);
     start = guess;
   }
+  if (c_phase) c_phase[0] = clock64() - t_in;   // lead-in (this wave)
   if (warm) {
     dirty = (tid == 0) && (first != start);
     if (dirty) start = first;
   }
+  // Re-join: a lane's decode is cut at T = nominal start + kJoinBits.  It remembers
+  // the first token boundary at or past T (canonical: whatever the grouping, the
+  // group that crosses T ends with a token that started before T) and the symbols
+  // up to it.  When its start moves in a later round it decodes up to T again; if it
+  // arrives at the same boundary, everything behind is what it already has -- the
+  // end stays, the count is adjusted -- and the round costs kJoinBits instead of the
+  // whole sub-sequence (codes resynchronise within a few tokens, so almost every
+  // moved lane re-joins).
+  uint32_t T = nominal + kJoinBits;
+  if (T > lim || T < nominal) T = lim;
+  uint32_t posT = ~0u, cT = 0;
   for (;;) {
-    if (dirty) lean_count<SOA>(rd, tb, start, lim, &endpos, &cnt);
+    if (dirty) {
+      uint32_t p1, c1;
+      lean_count<SOA>(rd, tb, start, T, &p1, &c1);
+      if (p1 == posT) {
+        cnt = c1 + (cnt - cT);
+        if (*rounds) atomicAdd(&sh->dbg[0], 1u);
+      } else {
+        if (*rounds) atomicAdd(&sh->dbg[1], 1u);
+        uint32_t c2;
+        lean_count<SOA>(rd, tb, p1, lim, &endpos, &c2, start < T);
+        cnt = c1 + c2;
+      }
+      posT = p1;
+      cT = c1;
+    }
     sh->nxt[tid + 1] = endpos;
     __syncthreads();
     if (c_first && *c_first == 0) *c_first = clock64() - t_in;
+    if (c_phase && c_phase[1] == 0) c_phase[1] = clock64() - t_in;   // end of round 1 (after its barrier)
     const uint32_t ns = tid == 0 ? first : sh->nxt[tid];
     dirty = active && (ns != start);
     if (active) start = ns;
@@ -745,7 +859,7 @@ __device__ __forceinline__ void lean_fixpoint(GReader &rd, const GrpTables &tb, 
 // go to lds_out (pre-zeroed) from offset op.  The group's bytes are OR-ed in with
 // two aligned ds_or (the bytes past the group are zeros, so neighbours are never
 // disturbed).  The caller guarantees that all of the lane's symbols lie strictly
-// inside the block.
+// inside the block.  Same two loops as lean_count.
 __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint32_t bp,
                                            uint32_t lim, uint32_t op, uint8_t *lds_out) {
   bool bad = false;
@@ -753,15 +867,28 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
     rd.init(bp);
     const int limk = (int)lim - kLutBits;
     uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
-    do {
-      uint32_t nbits, cnt, by;
-      lean_step<true>(rd, t, (int)bp > limk, &nbits, &cnt, &by, &bad);
+    while ((int)bp <= limk) {
+      rd.refill();
+      const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
+      const uint2 e = t.grp[idx];
+      uint32_t y = e.y, by = e.x, pre = 0;
+      if (__builtin_expect(y == 0, 0)) y = long_token<false>(rd, t, idx, &pre, &by, &bad);
+      const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
+      const uint32_t n = y >> 27;
+      rd.consume((int)n);
       const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
       atomicOr(&o32[op >> 2], (uint32_t)v);
       atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      op += ((y >> 10) & 511u) + extra;
+      bp += pre + n;
+    }
+    while (bp < lim) {
+      uint32_t nbits, cnt, by;
+      lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
+      if (by) lds_out[op] = (uint8_t)by;
       op += cnt;
       bp += nbits;
-    } while (bp < lim);
+    }
   }
   return !bad;
 }
@@ -846,6 +973,41 @@ __device__ __forceinline__ void lean_write_windows(GReader &rd, const GrpTables 
     }
     __syncthreads();
   }
+}
+
+// Write pass straight to PRE-ZEROED global memory (the LRES symbols: 1/64 of the
+// frame, L2 resident): lane t decodes the tokens that start in [bp, lim) and stores
+// the non-zero literal bytes of every group at their final positions from op; zero
+// runs and literal zeros need no store.  No LDS window, no barrier: the kernel that
+// calls this keeps only the decode tables in LDS and lasts as long as one lane's 256
+// bits.  `exact` marks the lane in whose range the block completes (token by token
+// there, with the reference's end-of-block checks, huffman_dec.cpp:353-354,361-417).
+__device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &tb, StreamShared *sh,
+                                                  uint32_t bp, uint32_t lim, unsigned long long op,
+                                                  bool exact, uint32_t out_size,
+                                                  unsigned long long endbit_base, uint32_t rel0,
+                                                  uint8_t *gout) {
+  if (!(bp < lim) || op >= out_size) return;
+  rd.init(bp);
+  const int limk = (int)lim - kLutBits;
+  bool bad = false;
+  for (;;) {
+    uint32_t nbits, cnt, by;
+    lean_step<true>(rd, tb, exact || (int)bp > limk, &nbits, &cnt, &by, &bad);
+    if (exact && (bad || op + cnt > out_size)) { bad = true; break; }
+    // A group never produces more than cnt symbols, so its (at most 4) explicit
+    // bytes lie inside [op, op + cnt).
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t b = (by >> (8 * j)) & 255u;
+      if (b) gout[op + j] = (uint8_t)b;
+    }
+    op += cnt;
+    bp += nbits;
+    if (exact && op >= out_size) { sh->endbit = endbit_base + (bp - rel0); break; }
+    if (!(bp < lim)) break;
+  }
+  if (bad) sh->err = 1;
 }
 
 // Decode one whole stream with one workgroup, chunk after chunk (each chunk's
@@ -1161,14 +1323,16 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_verify(Geom g, DecWs ws) {
 
 __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, const uint8_t *packed,
                                                             size_t in_stride, const uint32_t *sizes) {
-  __shared__ uint32_t win[kWinBytes / 4 + 1];
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
   __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
-  if (df->status || !ws.ver_ok[f]) return;
+  // One read for the whole workgroup (other kernels may flag the frame meanwhile).
+  if (tid == 0) sh.flag = (df->status || !ws.ver_ok[f]) ? 1 : 0;
+  __syncthreads();
+  if (sh.flag) return;
   const uint32_t pay_off = df->s[0].payload_off;
   const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
   const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
@@ -1192,11 +1356,11 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   __syncthreads();
   unsigned long long tot;
   const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
-  const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
   const unsigned long long opl = O0 + off;
   const bool exact = !(opl + cnt < out_size) && opl < out_size;
-  lean_write_windows(rd, tb, &sh, start, lim, opl, exact, O0, O1, out_size, cur, rel0, win,
-                     ws.lres_sym + (size_t)f * ws.lres_stride);
+  // The symbols were zeroed by launch_decode: only non-zero literals are stored.
+  lean_write_global(rd, tb, &sh, start, lim, opl, exact, out_size, cur, rel0,
+                    ws.lres_sym + (size_t)f * ws.lres_stride);
   __syncthreads();
   if (tid == 0) {
     if (sh.err) atomicMax(&df->status, fmt_err(4, 1));
@@ -1722,18 +1886,91 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 
 // ---------------------------------------------------------------------------
 // k_row_count: the fixpoint rounds of every FRES block row, on their own.  They
-// need no symbol storage (28 KiB of tables instead of the row's 128 KiB of LDS),
-// so two workgroups share a CU at 8 waves per SIMD -- the rounds are latency
-// bound and run 1.7x faster per row than inside k_dec_row_fused at 4 waves per
-// SIMD.  Output per lane: its first owned token and the exclusive prefix of the
-// symbol counts; the fused kernel then goes straight to its write pass.
+// need no symbol storage (tables + the row's payload instead of the row's 128 KiB
+// of symbols), so two workgroups share a CU at 8 waves per SIMD.  Output per lane:
+// its first owned token and the exclusive prefix of the symbol counts; the fused
+// kernel then goes straight to its write pass.
+//   * a workgroup walks kRowsPerCount consecutive rows of one frame: the 28 KiB of
+//     decode tables are loaded once for all of them (they were 17 % of a
+//     one-row workgroup's cycles);
+//   * the row's payload is staged in LDS (coalesced 4-byte loads) and the lanes'
+//     bit windows refill from there;
+//   * nothing is fenced at the end: the consumer is a later kernel.  (The
+//     release fence + barrier that used to close the kernel wrote back L2 and cost
+//     20 % of its duration.)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, const uint8_t *packed,
+constexpr int kRowsPerCount = 4;
+
+// Exclusive scan of a 32-bit value over the 1024-thread workgroup (DPP-free:
+// 6 shuffles + one LDS exchange).
+__device__ __forceinline__ uint32_t block_scan_u32d(uint32_t v, uint32_t *sm, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) sm[wave] = incl;
+  __syncthreads();
+  uint32_t pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kDecThreads / 64; ++w) {
+    const uint32_t x = sm[w];
+    if (w < wave) pre += x;
+    tot += x;
+  }
+  *total = tot;
+  return pre + incl - v;
+}
+
+template <class RD>
+__device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, StreamShared *sh, uint32_t *sm32,
+                                              uint32_t rel0, uint32_t rem, uint32_t sb, uint32_t lead_bits,
+                                              uint32_t *l_start, uint32_t *l_off, uint32_t *rc, long long c_in) {
+  const int tid = threadIdx.x;
+  const uint32_t rel_end = rel0 + rem;
+  const uint32_t my_b0 = rel0 + (uint32_t)tid * sb;
+  uint32_t lim = my_b0 + sb;
+  if (lim > rel_end) lim = rel_end;
+  const bool active = my_b0 < rel_end;
+  const int last_active = (int)((rel_end - rel0 - 1u) / sb);
+  uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
+  long long c_phase[2] = {0, 0};
+  const long long c_fix0 = clock64();
+  lean_fixpoint<true>(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, lead_bits, nullptr, c_phase);
+  const long long c_fix1 = clock64();
+  // 32-bit scan: a lane's count is clamped to 2^22 - 1, more than a whole row holds
+  // (the caller only comes here for rows below 2^22 symbols), so 1024 of them cannot
+  // wrap, valid streams are exact, and a lane that claims more still overruns the
+  // block in the write pass and is rejected there like before.
+  uint32_t tot;
+  const uint32_t off = block_scan_u32d(min(cnt, 0x3fffffu), sm32, &tot);
+  l_start[tid] = start - rel0;
+  l_off[tid] = off;
+  if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
+  if (tid == 0) {
+    l_off[kDecThreads] = tot;
+    l_off[kDecThreads + 3] = rounds | (min(sh->dbg[0], 4095u) << 8) | (min(sh->dbg[1], 4095u) << 20);
+    l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
+  }
+  if ((tid & 63) == 0 && rc) {   // cycles / 16, slowest wave of the workgroup
+    atomicMax(&rc[0], (uint32_t)((c_fix0 - c_in) >> 4));            // tables / payload staging
+    atomicMax(&rc[1], (uint32_t)(c_phase[0] >> 4));                 // lead-in
+    atomicMax(&rc[2], (uint32_t)(c_phase[1] >> 4));                 // ... to the end of round 1
+    atomicMax(&rc[3], (uint32_t)((c_fix1 - c_fix0) >> 4));          // the whole fixpoint
+    atomicMax(&rc[4], (uint32_t)((clock64() - c_in) >> 4));         // the row
+  }
+}
+
+__global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, const uint8_t *packed,
                                                            size_t in_stride, const uint32_t *sizes,
-                                                           int r0) {
+                                                           int r0, int r1, int rows_per_wg) {
   __shared__ __attribute__((aligned(16))) uint32_t gx[1 << kLutBits], gy[1 << kLutBits];
+  __shared__ uint32_t s_pay[kPayWords];   // the row's payload (rows of up to 36 KiB)
   __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ uint32_t sm32[kDecThreads / 64];
   __shared__ StreamShared sh;
   const int f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
@@ -1742,59 +1979,52 @@ __global__ __launch_bounds__(kDecThreads) void k_row_count(Geom g, DecWs ws, con
   if (tid == 0) sh.flag = df->status;
   __syncthreads();
   const int failed = sh.flag;
-  if (!failed) {   // load_dec_tables with the group table split into its two halves
+  if (!failed) {   // load_dec_tables with the count-only step words next to the long-code descriptors
     const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
     const int nn = df->s[1].num_nodes;
     for (int k = tid; k < nn; k += kDecThreads) {
       ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
     }
     const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    const uint2 *gc = reinterpret_cast<const uint2 *>(ws.gyc + ((size_t)f * 2 + 1) * (1u << kLutBits));
     for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
       const uint4 q = gg[k];
-      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);
-      reinterpret_cast<uint2 *>(gy)[k] = make_uint2(q.y, q.w);
+      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);   // long-code descriptors
+      reinterpret_cast<uint2 *>(gy)[k] = gc[k];                  // count-only step words
     }
     const uint32_t *gs = ws.sub + ((size_t)f * 2 + 1) * kSubEntries;
     for (int k = tid; k < kSubEntries; k += kDecThreads) sub[k] = gs[k];
   }
-  __syncthreads();
   GrpTables tb;
   tb.grp = nullptr; tb.gx = gx; tb.gy = gy; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  const int r = r0 + (int)blockIdx.x;
-  {
+  const int rb = r0 + (int)blockIdx.x * rows_per_wg;
+  for (int r = rb; r < min(rb + rows_per_wg, r1); ++r) {
+    const long long c_in = clock64();
     uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
     uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
-    if (tid == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
+    uint32_t *rc = ws.rc_stats ? ws.rc_stats + ((size_t)f * g.rows + r) * 8 : nullptr;
+    if (tid == 0) { l_off[kDecThreads + 2] = 0; sh.dbg[0] = sh.dbg[1] = 0; }   // not usable until proven otherwise
     const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
     const unsigned long long rem = 8ull * pay_len;
     uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
     sb = (sb + 31u) & ~31u;
     sb = sb < kMinSubBits ? kMinSubBits : sb;
     // More than one chunk: the fused kernel does it all.
-    if (!failed && sb <= (uint32_t)g.max_sub && rem != 0) {
-      GReader rd;
-      const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
-      const uint32_t rel_end = rel0 + (uint32_t)rem;
-      const uint32_t my_b0 = rel0 + (uint32_t)tid * sb;
-      uint32_t lim = my_b0 + sb;
-      if (lim > rel_end) lim = rel_end;
-      const bool active = my_b0 < rel_end;
-      const int last_active = (int)((rel_end - rel0 - 1u) / sb);
-      uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
-      lean_fixpoint<true>(rd, tb, &sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, (uint32_t)g.lead_bits);
-      unsigned long long tot;
-      const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
-      l_start[tid] = start - rel0;
-      l_off[tid] = off < 0xffffffffull ? (uint32_t)off : 0xffffffffu;
-      if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
-      if (tid == 0) {
-        l_off[kDecThreads] = tot < 0xffffffffull ? (uint32_t)tot : 0xffffffffu;
-        l_off[kDecThreads + 3] = rounds;
-      }
-      __syncthreads();
-      if (tid == 0) { __threadfence(); l_off[kDecThreads + 2] = 1; }
-    }
+    if (failed || sb > (uint32_t)g.max_sub || rem == 0 || g.row_block >= (1 << 22)) continue;
+    GReader rd;
+    const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
+    const uint32_t nd = (rel0 + (uint32_t)rem + 31u) / 32u;   // dwords that hold payload bits
+    if (nd + kPayPad > (uint32_t)kPayWords) continue;
+    __syncthreads();   // the previous row's readers are done with s_pay (and the tables are in)
+    // (A payload beyond the staging buffer -- rows above 36 KiB, sub-sequences longer
+    // than 288 bits -- was left to the row kernels above, like a row of several chunks.)
+    for (uint32_t k = tid; k < nd + kPayPad; k += kDecThreads) s_pay[k] = rd.ld(k);
+    __syncthreads();
+    LReader lr;
+    lr.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
+    lr.jmax = nd + kPayPad - 1u;
+    row_count_one(lr, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
   }
 }
 
@@ -1818,6 +2048,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // Block rows [r0, r1) only (row-sharded decode: every rank decodes the small
   // LRES stream and walks all row headers, then its own FRES rows).
   const int nrows = r1 - r0;
+  static const int rpc_env = [] { const char *e = getenv("HIMG_ROWS_PER_COUNT"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+  const int rpc = rpc_env ? rpc_env : kRowsPerCount;   // rows per k_row_count workgroup (tuning knob)
   const unsigned gx = (unsigned)((((g.cols + 31) / 32) * 64 + 255) / 256);   // k_tile_inv: two lanes per tile, 32 tiles per wave
   // Fused row kernel when the row's symbols and the decode tables fit the 160 KiB
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
@@ -1837,8 +2069,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     // they fill the CUs the latency-bound LRES kernels leave idle.
     if (nrows > 0) {
       prof_begin(prof, "k_row_count", side);
-      hipLaunchKernelGGL(k_row_count, dim3(nrows, batch), dim3(kDecThreads), 0, side, g, ws, d_packed,
-                         in_stride, d_sizes, r0);
+      hipLaunchKernelGGL(k_row_count, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), 0,
+                         side, g, ws, d_packed, in_stride, d_sizes, r0, r1, rpc);
       prof_end(prof, side);
     }
     (void)hipEventRecord(ev_join, side);
@@ -1847,6 +2079,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   }
   // LRES: every chunk in parallel, chain verified, serial fallback if not.
   (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
+  if (ws.rc_stats) (void)hipMemsetAsync(ws.rc_stats, 0, (size_t)batch * g.rows * 8 * sizeof(uint32_t), stream);
+  // k_lres_write stores the non-zero symbols only.
+  (void)hipMemsetAsync(ws.lres_sym, 0, (size_t)batch * ws.lres_stride, stream);
   HIMG_LAUNCH(k_lres_chain<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
               d_packed, in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_chain<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
@@ -1861,8 +2096,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (!side && nrows > 0)
-      HIMG_LAUNCH(k_row_count, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, r0);
+      HIMG_LAUNCH(k_row_count, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
+                  d_packed, in_stride, d_sizes, r0, r1, rpc);
     const uint32_t lds = fused_layout(g.row_block).total;
     prof_begin(prof, "k_dec_row_fused", stream);
 #define HIMG_FUSED_LAUNCH(COLS)                                                                 \
@@ -1883,8 +2118,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                 d_sizes, 0, 1, 0);  // LRES serial fallback (no-op when verified)
     if (!side && nrows > 0)
-      HIMG_LAUNCH(k_row_count, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, r0);
+      HIMG_LAUNCH(k_row_count, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
+                  d_packed, in_stride, d_sizes, r0, r1, rpc);
     if (nrows > 0)   // write pass only: the rounds were k_row_count's, at twice the occupancy
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, 1 + r0, 1, 1);

@@ -219,7 +219,8 @@ enum {
   HIMG_DBG_FRES_CODE = 9,  /* u64 [261]                                        */
   HIMG_DBG_FRES_ROW_BYTES = 10, /* u32 [rows] payload bytes per block row      */
   HIMG_DBG_DEC_STATS = 11, /* decoder only: u32 [rows+1][8] entropy-decode counters   */
-  HIMG_DBG_PARSE_STATS = 12 /* decoder only: u32 [4] container-parse phase cycles / 16 */
+  HIMG_DBG_PARSE_STATS = 12, /* decoder only: u32 [4] container-parse phase cycles / 16 */
+  HIMG_DBG_ROWCOUNT_STATS = 13 /* decoder only: u32 [rows][8] k_row_count phase cycles / 16 */
 };
 int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void *host_dst,
                         size_t dst_bytes, size_t *bytes_written);

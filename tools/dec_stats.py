@@ -17,6 +17,11 @@ names = ["chunks", "rounds", "clk_transform/16, slowest wave (lres: fix chunks)"
 print("LRES: chunks %d, fixpoint rounds %d (slowest chunk %d); corrected chunks %d, rounds %d (slowest %d)" % (st[0][0], st[0][1], st[0][4], st[0][2], st[0][3], st[0][5]))
 ps = eng.debug_read("parse_stats", 0, 16, np.uint32, decoder=True)
 print("k_dec_parse cycles: serial %d, lut %d, sub %d, grp %d" % tuple((ps.astype(np.int64) * 16).tolist()))
+rc = eng.debug_read("rowcount_stats", 0, rows * 32, np.uint32, decoder=True).reshape(rows, 8).astype(np.float64) * 16
+print("k_row_count cycles (slowest wave): tables+staging %.0f, lead-in %.0f, to end of round 1 %.0f, fixpoint %.0f, workgroup %.0f" % tuple(rc[:, :5].mean(axis=0)))
+rr = st[1:, 1].astype(np.int64)
+print("FRES per row: rounds mean %.2f, lanes re-joined in rounds>=2 mean %.1f, lanes fully re-decoded mean %.1f max %d" % (
+    (rr & 255).mean(), ((rr >> 8) & 4095).mean(), ((rr >> 20) & 4095).mean(), ((rr >> 20) & 4095).max()))
 fr = st[1:].astype(np.float64)
 for i, n in enumerate(names):
     print("FRES %-14s mean %.1f min %.0f max %.0f" % (n, fr[:, i].mean(), fr[:, i].min(), fr[:, i].max()))

@@ -36,3 +36,5 @@ names = ["chunks", "rounds", "clk_transform/16 (slowest wave)", "clk_workgroup/1
 fr = st[1:].astype(np.float64)
 for i, n in enumerate(names):
     print("FRES %-32s mean %.1f min %.0f max %.0f" % (n, fr[:, i].mean(), fr[:, i].min(), fr[:, i].max()))
+rc = eng.debug_read("rowcount_stats", 0, rows * 32, np.uint32, decoder=True).reshape(rows, 8).astype(np.float64) * 16
+print("k_row_count cycles per row (slowest wave, frame 0): tables/staging %.0f, lead-in %.0f, to end of round 1 %.0f, fixpoint %.0f, row %.0f" % tuple(rc[:, :5].mean(axis=0)))
