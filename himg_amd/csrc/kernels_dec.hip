@@ -986,7 +986,7 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
                                                   uint32_t bp, uint32_t lim, unsigned long long op,
                                                   bool exact, uint32_t out_size,
                                                   unsigned long long endbit_base, uint32_t rel0,
-                                                  uint8_t *gout) {
+                                                  uint8_t *gout, unsigned long long op_end) {
   if (!(bp < lim) || op >= out_size) return;
   rd.init(bp);
   const int limk = (int)lim - kLutBits;
@@ -995,12 +995,21 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
     uint32_t nbits, cnt, by;
     lean_step<true>(rd, tb, exact || (int)bp > limk, &nbits, &cnt, &by, &bad);
     if (exact && (bad || op + cnt > out_size)) { bad = true; break; }
-    // A group never produces more than cnt symbols, so its (at most 4) explicit
-    // bytes lie inside [op, op + cnt).
+    // A group's (at most 4) explicit bytes lie inside [op, op + cnt); the bytes of the
+    // dword beyond them are zeros of its run or belong to this lane's NEXT groups,
+    // which are stored later and in order -- so while the dword stays inside the
+    // lane's own output range [.., op_end) it goes out as one (unaligned) dword store,
+    // and not at all when it is zero.  Near the end of the range: byte by byte.
+    if (by) {
+      if (op + 4 <= op_end) {
+        asm volatile("global_store_dword %0, %1, %2" :: "v"((uint32_t)op), "v"(by), "s"(gout) : "memory");
+      } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t b = (by >> (8 * j)) & 255u;
-      if (b) gout[op + j] = (uint8_t)b;
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t b = (by >> (8 * j)) & 255u;
+          if (b) gout[op + j] = (uint8_t)b;
+        }
+      }
     }
     op += cnt;
     bp += nbits;
@@ -1171,6 +1180,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     if (use_row_count) {
       pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
       pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+      // use_row_count == 2: rows with a usable fixpoint were written by k_row_write_g.
+      if (use_row_count == 2 && pre_off[kDecThreads + 2] != 0) return;
     }
   }
   load_dec_tables(ws, df, f, strm, grp, sub, ca, cb, sy);
@@ -1360,7 +1371,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const bool exact = !(opl + cnt < out_size) && opl < out_size;
   // The symbols were zeroed by launch_decode: only non-zero literals are stored.
   lean_write_global(rd, tb, &sh, start, lim, opl, exact, out_size, cur, rel0,
-                    ws.lres_sym + (size_t)f * ws.lres_stride);
+                    ws.lres_sym + (size_t)f * ws.lres_stride, exact ? opl : opl + cnt);
   __syncthreads();
   if (tid == 0) {
     if (sh.err) atomicMax(&df->status, fmt_err(4, 1));
@@ -1963,11 +1974,15 @@ __device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, Strea
   }
 }
 
+// LDSPAY: the row's payload is staged in LDS (rows of up to 36 KiB -- every shape
+// the fused row kernel serves); otherwise (wide rows, generic path) the lanes read
+// it in place.
+template <bool LDSPAY>
 __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, const uint8_t *packed,
                                                            size_t in_stride, const uint32_t *sizes,
                                                            int r0, int r1, int rows_per_wg) {
   __shared__ __attribute__((aligned(16))) uint32_t gx[1 << kLutBits], gy[1 << kLutBits];
-  __shared__ uint32_t s_pay[kPayWords];   // the row's payload (rows of up to 36 KiB)
+  __shared__ uint32_t s_pay[LDSPAY ? kPayWords : 1];   // the row's payload
   __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ uint32_t sm32[kDecThreads / 64];
@@ -2014,17 +2029,76 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
     if (failed || sb > (uint32_t)g.max_sub || rem == 0 || g.row_block >= (1 << 22)) continue;
     GReader rd;
     const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
-    const uint32_t nd = (rel0 + (uint32_t)rem + 31u) / 32u;   // dwords that hold payload bits
-    if (nd + kPayPad > (uint32_t)kPayWords) continue;
-    __syncthreads();   // the previous row's readers are done with s_pay (and the tables are in)
-    // (A payload beyond the staging buffer -- rows above 36 KiB, sub-sequences longer
-    // than 288 bits -- was left to the row kernels above, like a row of several chunks.)
-    for (uint32_t k = tid; k < nd + kPayPad; k += kDecThreads) s_pay[k] = rd.ld(k);
-    __syncthreads();
-    LReader lr;
-    lr.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
-    lr.jmax = nd + kPayPad - 1u;
-    row_count_one(lr, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
+    if (LDSPAY) {
+      const uint32_t nd = (rel0 + (uint32_t)rem + 31u) / 32u;   // dwords that hold payload bits
+      // A payload beyond the staging buffer is left to the row kernels, like a row of
+      // several chunks.
+      if (nd + kPayPad > (uint32_t)kPayWords) continue;
+      __syncthreads();   // the previous row's readers are done with s_pay (and the tables are in)
+      for (uint32_t k = tid; k < nd + kPayPad; k += kDecThreads) s_pay[k] = rd.ld(k);
+      __syncthreads();
+      LReader lr;
+      lr.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
+      lr.jmax = nd + kPayPad - 1u;
+      row_count_one(lr, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
+    } else {
+      __syncthreads();   // the tables are in / the previous row is done with the exchange slots
+      row_count_one(rd, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_row_write_g: write pass of the generic path (rows whose symbols do not fit the
+// LDS: wider than 4224 pixels) straight to the PRE-ZEROED symbol plane in HBM, from
+// k_row_count's lane starts and offsets.  No LDS window, no barrier in the pass: a
+// lane stores the non-zero literal bytes of its groups, zeros are the fill.  (The
+// window path, k_dec_huff, took 4x as long per row: sixteen 32 KiB windows with
+// three barriers each for a 16384-pixel row.)  Rows k_row_count left alone (several
+// chunks) are skipped here and taken by k_dec_huff.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, const uint8_t *packed,
+                                                             size_t in_stride, const uint32_t *sizes, int r0) {
+  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ uint32_t sub[kSubEntries];
+  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ StreamShared sh;
+  const int r = r0 + (int)blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  const uint32_t *pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+  const uint32_t *pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+  if (tid == 0) { sh.flag = (df->status || pre_off[kDecThreads + 2] == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
+  __syncthreads();
+  if (sh.flag) return;   // frame failed, or the row is k_dec_huff's
+  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
+  GrpTables tb;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
+  const uint32_t out_size = (uint32_t)g.row_block;
+  const unsigned long long P1 = 8ull * pay_len;
+  uint32_t sb = (uint32_t)((P1 + kDecThreads - 1) / kDecThreads);
+  sb = (sb + 31u) & ~31u;
+  sb = sb < kMinSubBits ? kMinSubBits : sb;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off);
+  const uint32_t rel_end = rel0 + (uint32_t)P1;
+  uint32_t lim = rel0 + (uint32_t)(tid + 1) * sb;
+  if (lim > rel_end) lim = rel_end;
+  const uint32_t start = rel0 + pre_start[tid];
+  const uint32_t off = pre_off[tid], cnt = pre_off[tid + 1] - off;   // [kDecThreads] holds the total
+  const uint32_t tot = pre_off[kDecThreads];
+  const bool exact = !(off + cnt < out_size) && off < out_size;
+  __syncthreads();
+  lean_write_global(rd, tb, &sh, start, lim, off, exact, out_size, 0ull, rel0,
+                    ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block,
+                    exact ? off : off + cnt);
+  __syncthreads();
+  if (tid == 0) {   // accept / reject like UncompressStream (huffman_dec.cpp:361-417)
+    int bad = sh.err;
+    if (tot < out_size) bad = 1;   // ran out of payload before the block was full
+    const unsigned long long E = sh.endbit;
+    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+    if (bad) atomicMax(&df->status, fmt_err(7, 1));
   }
 }
 
@@ -2069,8 +2143,12 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     // they fill the CUs the latency-bound LRES kernels leave idle.
     if (nrows > 0) {
       prof_begin(prof, "k_row_count", side);
-      hipLaunchKernelGGL(k_row_count, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), 0,
-                         side, g, ws, d_packed, in_stride, d_sizes, r0, r1, rpc);
+      if (wps)
+        hipLaunchKernelGGL(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), 0,
+                           side, g, ws, d_packed, in_stride, d_sizes, r0, r1, rpc);
+      else
+        hipLaunchKernelGGL(k_row_count<false>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), 0,
+                           side, g, ws, d_packed, in_stride, d_sizes, r0, r1, rpc);
       prof_end(prof, side);
     }
     (void)hipEventRecord(ev_join, side);
@@ -2096,7 +2174,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (!side && nrows > 0)
-      HIMG_LAUNCH(k_row_count, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
+      HIMG_LAUNCH(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
                   d_packed, in_stride, d_sizes, r0, r1, rpc);
     const uint32_t lds = fused_layout(g.row_block).total;
     prof_begin(prof, "k_dec_row_fused", stream);
@@ -2118,11 +2196,20 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                 d_sizes, 0, 1, 0);  // LRES serial fallback (no-op when verified)
     if (!side && nrows > 0)
-      HIMG_LAUNCH(k_row_count, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
+      HIMG_LAUNCH(k_row_count<false>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
                   d_packed, in_stride, d_sizes, r0, r1, rpc);
-    if (nrows > 0)   // write pass only: the rounds were k_row_count's, at twice the occupancy
+    if (nrows > 0) {
+      // Symbols through HBM: the write pass stores the non-zero literals into the
+      // zeroed plane; rows without a usable fixpoint (several chunks) take the window
+      // path of k_dec_huff, which skips the others.
+      prof_begin(prof, "memset", stream);
+      (void)hipMemset2DAsync(ws.fres_sym + (size_t)r0 * g.row_block, ws.fres_stride, 0,
+                             (size_t)nrows * g.row_block, (size_t)batch, stream);
+      prof_end(prof, stream);
+      HIMG_LAUNCH(k_row_write_g, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, r0);
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, 1 + r0, 1, 1);
+                  d_sizes, 1 + r0, 1, 2);
+    }
     HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
     if (nrows > 0) HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
   }

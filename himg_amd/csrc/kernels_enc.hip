@@ -1686,7 +1686,19 @@ __global__ __launch_bounds__(256) void k_place_fres(Geom g, EncWs ws, const uint
   const uint32_t n0 = (b0 + 7) >> 3;
   const uint32_t hdr0 = g.use_blocks ? (n0 <= 0x7fffu ? 2u : 4u) : 0u;
   uint8_t *dst = out + (ws.span_bit0[g.lres_spans] >> 3) - hdr0;
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < rel_bytes;
+  // 16 bytes per thread: aligned loads (rel is 16-byte aligned), stores at whatever
+  // alignment the LRES size left the destination with (the hardware takes unaligned
+  // global stores); the last few bytes one by one.
+  const size_t n16 = rel_bytes >> 4;
+  const uint4 *src16 = reinterpret_cast<const uint4 *>(rel);
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint4 q = src16[k];
+    const u32x4 v = {q.x, q.y, q.z, q.w};
+    uint8_t *d = dst + 16 * k;
+    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(d), "v"(v) : "memory");
+  }
+  for (size_t k = (n16 << 4) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < rel_bytes;
        k += (size_t)gridDim.x * blockDim.x)
     dst[k] = rel[k];
 }

@@ -136,72 +136,83 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=T
 class EngineBackend:
     """Device phases on the HIP engine.  `d_frame` is this rank's view of the
     frame: a CUDA uint8 tensor holding pixel rows [y_first, y_first + n) of the
-    W x H image (at least rows 8*r0-11 .. 8*r1+4 clipped to the image)."""
+    W x H image (at least rows 8*r0-11 .. 8*r1+4 clipped to the image).
+
+    Every buffer the phases touch is allocated once, here; the phases only launch
+    kernels on the (torch current = null) stream, so the collectives that follow
+    them are ordered behind them without a host synchronisation.  The one value the
+    host needs per frame is the row layout (rows x 4 bytes, for the sizes of the
+    pieces that travel to rank 0)."""
 
     def __init__(self, engine, d_frame, y_first, width, height, quality=50, use_ycbcr=True,
                  comm_device=None, stream=0):
         import torch
+        import himg_amd
         self.eng, self.W, self.H, self.q, self.ycbcr = engine, width, height, quality, use_ycbcr
         self.d_frame, self.y_first, self.stream = d_frame, y_first, stream
         self.dev = d_frame.device
         self.comm = torch.device(comm_device) if comm_device is not None else self.dev
         self.rows, self.cols, self.C = (height + 7) // 8, (width + 7) // 8, 4
         self.r0 = self.r1 = 0
+        dev = self.dev
+        self._hist32 = torch.zeros(264, dtype=torch.int32, device=dev)
+        self._hist_g = torch.zeros(264, dtype=torch.int32, device=dev)
+        self._low = None        # sized at the first stats() (depends on the share)
+        self._bits = None
+        self._rel_cap = (self.rows * self.cols * 64 * self.C + 4 * self.rows + 256 + 255) // 256 * 256
+        self._rel = None        # allocated on first emit: only as large as the local rows can get
+        self._size = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._status = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._out = None        # rank 0 only (assemble)
+        self._out_cap = himg_amd.max_packed_size(width, height, self.C)
 
     def _to_comm(self, t):
         return t.to(self.comm) if t.device != self.comm else t
 
     def stats(self, r0, r1):
         import torch
+        if self._low is None or (r0, r1) != (self.r0, self.r1):
+            self._low = torch.zeros(max(1, self.C * (r1 - r0) * self.cols), dtype=torch.uint8, device=self.dev)
+            self._bits = torch.zeros(max(1, r1 - r0), dtype=torch.int32, device=self.dev)
         self.r0, self.r1 = r0, r1
-        hist = torch.zeros(264, dtype=torch.int32, device=self.dev)
-        low = torch.zeros(max(1, self.C * (r1 - r0) * self.cols), dtype=torch.uint8, device=self.dev)
         # Called for an empty share too: it sets up the per-frame state every later
         # phase (and rank 0's assemble) relies on.
         base = self.d_frame.data_ptr() - self.y_first * self.W * 4   # virtual frame base
-        self.eng.shard_stats(base, self.W, self.H, 4, 4, self.q, self.ycbcr, r0, r1, hist, low,
+        self.eng.shard_stats(base, self.W, self.H, 4, 4, self.q, self.ycbcr, r0, r1, self._hist32, self._low,
                              self.stream)
-        torch.cuda.synchronize(self.dev)
-        h64 = (hist[:261].to(torch.int64) & 0xFFFFFFFF)
-        return self._to_comm(h64), self._to_comm(low[: self.C * (r1 - r0) * self.cols])
+        h64 = (self._hist32[:261].to(torch.int64) & 0xFFFFFFFF)    # i64: 8 ranks x 2^31 tokens cannot wrap
+        return self._to_comm(h64), self._to_comm(self._low[: self.C * (r1 - r0) * self.cols])
 
     def row_bits(self, hist_global):
         import torch
         n = self.r1 - self.r0
-        bits = torch.zeros(max(1, n), dtype=torch.int32, device=self.dev)
-        h32 = torch.zeros(264, dtype=torch.int32, device=self.dev)
-        h32[:261] = hist_global.to(self.dev).to(torch.int32)
-        self.eng.shard_row_bits(h32, bits, self.stream)   # every rank builds the (identical) tree
-        torch.cuda.synchronize(self.dev)
-        return self._to_comm(bits[:n])
+        self._hist_g[:261] = hist_global.to(self.dev).to(torch.int32)
+        self.eng.shard_row_bits(self._hist_g, self._bits, self.stream)   # every rank builds the (identical) tree
+        return self._to_comm(self._bits[:n])
 
     def emit(self, all_bits, start, end):
         import torch
         if end <= start:
             return torch.zeros(0, dtype=torch.uint8, device=self.comm)
-        cap = (self.rows * self.cols * 64 * self.C + 4 * self.rows + 256 + 255) // 256 * 256
-        rel = torch.empty(cap, dtype=torch.uint8, device=self.dev)
-        size = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        if self._rel is None:
+            self._rel = torch.empty(self._rel_cap, dtype=torch.uint8, device=self.dev)
         self._all_bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
-        self.eng.shard_emit(self._all_bits_dev, rel, cap, size, self.stream)
-        torch.cuda.synchronize(self.dev)
-        return self._to_comm(rel[start:end])
+        self.eng.shard_emit(self._all_bits_dev, self._rel, self._rel_cap, self._size, self.stream)
+        return self._to_comm(self._rel[start:end])
 
     def assemble(self, low_full, all_bits, rel_full, host=True):
         import torch
         import himg_amd
-        cap = himg_amd.max_packed_size(self.W, self.H, self.C)
-        out = torch.empty(cap, dtype=torch.uint8, device=self.dev)
-        size = torch.zeros(4, dtype=torch.int32, device=self.dev)
-        status = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        if self._out is None:
+            self._out = torch.empty(self._out_cap, dtype=torch.uint8, device=self.dev)
         bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
         rel_dev = rel_full.to(self.dev).contiguous()
         self.eng.shard_assemble(low_full.to(self.dev).contiguous(), bits_dev, rel_dev, rel_dev.numel(),
-                                out, cap, size, status, self.stream)
-        torch.cuda.synchronize(self.dev)
-        if int(status[0]) != 0:
-            raise himg_amd.HimgError(-int(status[0]), "sharded assemble failed")
-        out = out[: int(size[0])]
+                                self._out, self._out_cap, self._size, self._status, self.stream)
+        st = torch.stack([self._size[0], self._status[0]]).cpu()       # the one wait of this phase
+        if int(st[1]) != 0:
+            raise himg_amd.HimgError(-int(st[1]), "sharded assemble failed")
+        out = self._out[: int(st[0])]
         return out.cpu().numpy() if host else out
 
 
