@@ -206,7 +206,27 @@ def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, 
     eng.decode_batch(streams, outs=pouts)
     tdb = (time.perf_counter() - t) / nb
     out["host_batch_api_incl_pcie_mpx_s"] = {"encode": round(W * H / teb / 1e6, 1), "decode": round(W * H / tdb / 1e6, 1),
-                                             "encode_decode": round(W * H / (teb + tdb) / 1e6, 1), "frames_in_flight": nb}
+                                             "encode_decode": round(W * H / (teb + tdb) / 1e6, 1), "frames_in_flight": nb,
+                                             "host_memory": "pageable"}
+    # The same with the caller's buffers page-locked (himg_hip_host_alloc): true
+    # asynchronous DMA both ways.
+    pf = [himg_amd.pinned_empty(W * H * 4) for _ in range(nb)]
+    for b_ in pf:
+        b_[:] = frame0.ravel()
+    pin_e = [himg_amd.pinned_empty(cap) for _ in range(nb)]
+    pin_p = [himg_amd.pinned_empty(W * H * 4) for _ in range(nb)]
+    fr = [b_.reshape(H, W, 4) for b_ in pf]
+    streams = eng.encode_batch(fr, Q, True, outs=pin_e)
+    eng.decode_batch(streams, outs=pin_p)
+    t = time.perf_counter()
+    streams = eng.encode_batch(fr, Q, True, outs=pin_e)
+    teb = (time.perf_counter() - t) / nb
+    t = time.perf_counter()
+    eng.decode_batch(streams, outs=pin_p)
+    tdb = (time.perf_counter() - t) / nb
+    out["host_batch_api_pinned_incl_pcie_mpx_s"] = {"encode": round(W * H / teb / 1e6, 1), "decode": round(W * H / tdb / 1e6, 1),
+                                                    "encode_decode": round(W * H / (teb + tdb) / 1e6, 1),
+                                                    "frames_in_flight": nb, "host_memory": "pinned (himg_hip_host_alloc)"}
     return out
 
 

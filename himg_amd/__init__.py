@@ -77,6 +77,10 @@ def lib():
     L.himg_hip_decode_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.himg_hip_free.argtypes = [vp]
     L.himg_hip_free.restype = None
+    L.himg_hip_host_alloc.argtypes = [sz]
+    L.himg_hip_host_alloc.restype = vp
+    L.himg_hip_host_free.argtypes = [vp]
+    L.himg_hip_host_free.restype = None
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
     L.himg_hip_decode_device.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_decode_rows_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp]
@@ -121,6 +125,33 @@ def fnv1a64(buf):
 
 def max_packed_size(width, height, channels):
     return int(lib().himg_hip_max_packed_size(width, height, channels))
+
+
+class _Pinned:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            lib().himg_hip_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(nbytes):
+    """uint8 numpy array in page-locked host memory (himg_hip_host_alloc): the host
+    API's transfers from / to it are asynchronous DMA.  Freed with the array."""
+    ptr = lib().himg_hip_host_alloc(int(nbytes))
+    if not ptr:
+        raise MemoryError("himg_hip_host_alloc(%d)" % nbytes)
+    owner = _Pinned(ptr)
+    buf = (C.c_uint8 * int(nbytes)).from_address(ptr)
+    a = np.frombuffer(buf, np.uint8)
+    _PIN_OWNERS[a.__array_interface__["data"][0]] = owner   # keep the allocation alive as long as the module
+    return a
+
+
+_PIN_OWNERS = {}
 
 
 def psnr(a, b):

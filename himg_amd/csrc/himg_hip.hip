@@ -290,6 +290,15 @@ extern "C" const char *himg_hip_last_error(const himg_hip_ctx *ctx) {
 
 extern "C" void himg_hip_free(void *p) { std::free(p); }
 
+extern "C" void *himg_hip_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void himg_hip_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value) {
   if (!ctx) return HIMG_ERR_ARG;
   if (option == HIMG_OPT_FIX_T2) { ctx->fix_t2 = value ? 1 : 0; return HIMG_OK; }

@@ -116,6 +116,14 @@ int himg_hip_decode_batch(himg_hip_ctx *ctx, const uint8_t *const *packed, const
                           int n, uint8_t *const *dst, const size_t *dst_cap, int *widths,
                           int *heights, int *channels);
 
+/* Page-locked host memory for the frames / streams handed to the host API: from
+ * pinned buffers the transfers above are true asynchronous DMA at PCIe speed and
+ * overlap the kernels; from pageable memory the runtime stages every copy.  (The
+ * reference's callers own their buffers too: benchmark.cpp:104-105 loads the file
+ * into a std::vector once and decodes it 30 times.)  Returns NULL on failure. */
+void *himg_hip_host_alloc(size_t bytes);
+void himg_hip_host_free(void *p);
+
 /* ---- device-resident batched API (roofline measurements, pipelines) ----- */
 
 /* Encode `batch` frames that already live in HBM.
