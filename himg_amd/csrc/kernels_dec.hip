@@ -1407,11 +1407,15 @@ __device__ __forceinline__ int predict_d(int s1, int s2, int s3, int p) {
 
 __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
   __shared__ uint8_t rec[16][17];
+  __shared__ int16_t s_lmap[128];   // the chain below looks a delta up per step: LDS, not global
   const int mu = blockIdx.x, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
   const int lane = threadIdx.x;
   const DecFrame *df = ws.frames + f;
   if (df->status) return;
+  s_lmap[lane] = df->lmap[lane];
+  s_lmap[lane + 64] = df->lmap[lane + 64];
+  __syncthreads();
   const uint8_t *in = ws.lres_sym + (size_t)f * ws.lres_stride + (size_t)c * g.chan_size;
   uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * g.cols;
   const int u0 = mu * 16, v0 = mv * 16;
@@ -1431,7 +1435,7 @@ __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
       const int predicted = predict_d(s1, s2, s3, pc);
       const int sc = (int8_t)src[dv * bw + du];
       // mapper.h:33-35 with the mirrored table (mapper.cpp:148-154).
-      const int un = sc >= 0 ? df->lmap[sc] : (sc == -128 ? -df->lmap[127] : -df->lmap[-sc]);
+      const int un = sc >= 0 ? s_lmap[sc] : (sc == -128 ? -s_lmap[127] : -s_lmap[-sc]);
       const int val = clamp255d((int)(int16_t)(predicted + un));
       rec[dv][du] = (uint8_t)val;
       m[(size_t)(v0 + dv) * g.cols + u0 + du] = (uint8_t)val;
@@ -1688,7 +1692,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
   const int v2 = min(v + 1, g.rows - 1);
     const int u2 = min(u + 1, cols - 1);
     uint32_t QA[16], QB[16];
-#pragma unroll 1
+#pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int c = 2 * s + cc;
       uint32_t O[16];

@@ -148,9 +148,16 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
                                                      size_t lres_stride, LresTables lt) {
   __shared__ uint8_t mb[16][17];
   __shared__ uint8_t rec[16][17];
+  // The companding tables in LDS: the delta chain below looks them up twice per
+  // step, and out of the kernel-argument segment each lookup is a global load on
+  // the critical path of 31 dependent steps.
+  __shared__ int16_t s_tab[128];
+  __shared__ uint8_t s_code[512];
   const int mu = blockIdx.x, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
   const int lane = threadIdx.x;
+  for (int k = lane; k < 128; k += 64) s_tab[k] = lt.tab[k];
+  for (int k = lane; k < 512; k += 64) s_code[k] = lt.code[k];
   const uint8_t *m = low + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
   const int u0 = mu * 16, v0 = mv * 16;
   const int bw = min(16, g.cols - u0), bh = min(16, g.rows - v0);
@@ -203,9 +210,9 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
       else { s1 = s2 = s3 = 128; }
       const int predicted = predict(s1, s2, s3, pc);
       const int delta = (int)mb[dv][du] - predicted;
-      const uint8_t code = lt.code[delta + 255];
+      const uint8_t code = s_code[delta + 255];
       const int sc = (int8_t)code;
-      const int un = sc >= 0 ? lt.tab[sc] : -lt.tab[-sc];
+      const int un = sc >= 0 ? s_tab[sc] : -s_tab[-sc];
       rec[dv][du] = (uint8_t)clamp255(predicted + un);
       dst[dv * bw + du] = code;
     }
@@ -1077,9 +1084,6 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   __shared__ short s_idx[kNumSym];
   __shared__ short ca[2 * kNumSym], cb[2 * kNumSym], nsym[2 * kNumSym];
   __shared__ uint32_t bits[kTreeStride / 4];
-  __shared__ short stk_node[kNumSym + 8];
-  __shared__ uint8_t stk_bits[kNumSym + 8];
-  __shared__ uint64_t stk_code[kNumSym + 8];
   __shared__ int s_num;
 
   const int strm = blockIdx.x + strm0, f = blockIdx.y, lane = threadIdx.x;
@@ -1168,46 +1172,82 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   __syncthreads();
   next = num > 1 ? 2 * num - 1 : num;
 
+  // Codes and the serialised tree (huffman_enc.cpp:148-180) without a serial walk.
+  // A node's depth, code (LSB first: taking child_b at depth d sets bit d) and bit
+  // position in the pre-order serialisation follow from its parent's; the size of a
+  // subtree (leaf: 1 + 9 bits, branch: 1 + its children) from its children's.  Both
+  // are propagated level by level, all 64 lanes working on the (at most 521) nodes:
+  // a few rounds per tree level instead of some hundred dependent LDS round trips
+  // per NODE -- this walk was most of the kernel's 0.14 ms.
+  __shared__ short s_par[2 * kNumSym];
+  __shared__ uint8_t s_side[2 * kNumSym];
+  __shared__ short s_depth[2 * kNumSym];       // -1: not known yet
+  __shared__ int s_sz[2 * kNumSym];            // subtree size in bits, -1: not known yet
+  __shared__ int s_pos[2 * kNumSym];           // bit position of the node in the serialisation
+  __shared__ unsigned long long s_code[2 * kNumSym];
+  __shared__ int s_changed, s_err;
+  for (int v = lane; v < next; v += 64) { s_par[v] = -1; s_depth[v] = -1; s_sz[v] = nsym[v] >= 0 ? 10 : -1; }
+  if (lane == 0) s_err = 0;
+  __syncthreads();
+  for (int v = num + lane; v < next; v += 64) {   // internal nodes name their children
+    s_par[ca[v]] = (short)v; s_side[ca[v]] = 0;
+    s_par[cb[v]] = (short)v; s_side[cb[v]] = 1;
+  }
+  __syncthreads();
+  // Bottom-up: subtree sizes.
+  for (int round = 0; round < 2 * kNumSym; ++round) {
+    if (lane == 0) s_changed = 0;
+    __syncthreads();
+    for (int v = num + lane; v < next; v += 64)
+      if (s_sz[v] < 0) {
+        const int a = s_sz[ca[v]], b = s_sz[cb[v]];
+        if (a >= 0 && b >= 0) { s_sz[v] = 1 + a + b; s_changed = 1; }
+      }
+    __syncthreads();
+    if (!s_changed) break;
+  }
+  // Top-down: depth, code, position.
+  if (lane == 0 && next > 0) {
+    const int root = next - 1;
+    // A single symbol is one leaf with a 1-bit code 0 (huffman_enc.cpp:231-237).
+    s_depth[root] = (short)(num == 1 ? 1 : 0);
+    s_code[root] = 0;
+    s_pos[root] = 0;
+  }
+  __syncthreads();
+  for (int round = 0; round < 2 * kNumSym; ++round) {
+    if (lane == 0) s_changed = 0;
+    __syncthreads();
+    for (int v = lane; v < next; v += 64) {
+      const int p = s_par[v];
+      if (s_depth[v] < 0 && p >= 0 && s_depth[p] >= 0) {
+        const int d = s_depth[p];
+        s_code[v] = s_code[p] | ((s_side[v] && d < 63) ? (1ull << d) : 0ull);
+        s_pos[v] = s_pos[p] + 1 + (s_side[v] ? s_sz[ca[p]] : 0);
+        s_depth[v] = (short)min(d + 1, 255);
+        s_changed = 1;
+      }
+    }
+    __syncthreads();
+    if (!s_changed) break;
+  }
+  // Leaves: code table entries and their 10 bits of the serialisation (branches are 0 bits).
+  for (int v = lane; v < num; v += 64) {
+    const int sym = nsym[v], d = s_depth[v];
+    codes[sym] = s_code[v];
+    lens[sym] = (uint32_t)d;
+    if (d > kMaxCodeLen) s_err = 1;
+    const uint32_t pos = (uint32_t)s_pos[v];
+    const unsigned long long val = (1ull | ((unsigned long long)sym << 1)) << (pos & 31);
+    atomicOr(&bits[pos >> 5], (uint32_t)val);
+    if (val >> 32) atomicOr(&bits[(pos >> 5) + 1], (uint32_t)(val >> 32));
+  }
+  __syncthreads();
   if (lane == 0) {
-    int err = 0;
-    uint32_t nb = 0;  // bits written
-    unsigned long long acc = 0;  // bits not yet stored (fewer than 32), LSB first
-    auto put = [&](uint32_t v, int n) {  // n <= 10
-      acc |= (unsigned long long)v << (nb & 31);
-      nb += n;
-      if (((nb - n) & 31) + n >= 32) {
-        bits[(nb >> 5) - 1] = (uint32_t)acc;
-        acc >>= 32;
-      }
-    };
-    int sp = 0;
-    if (num == 1) {  // single symbol: one leaf, code 0, length 1 (huffman_enc.cpp:231-237)
-      stk_node[0] = 0; stk_code[0] = 0; stk_bits[0] = 1; sp = 1;
-    } else if (num > 1) {
-      stk_node[0] = (short)(next - 1); stk_code[0] = 0; stk_bits[0] = 0; sp = 1;
-    }
-    while (sp > 0) {
-      --sp;
-      const int n = stk_node[sp];
-      const uint64_t code = stk_code[sp];
-      const int nbits = stk_bits[sp];
-      if (nsym[n] >= 0) {
-        put(1, 1);
-        put((uint32_t)nsym[n], 9);
-        codes[nsym[n]] = code;
-        lens[nsym[n]] = (uint32_t)nbits;
-        if (nbits > kMaxCodeLen) err = 1;
-      } else {
-        put(0, 1);
-        const uint64_t bcode = code + (nbits < 63 ? (1ull << nbits) : 0ull);
-        stk_node[sp] = cb[n]; stk_code[sp] = bcode; stk_bits[sp] = (uint8_t)min(nbits + 1, 255); ++sp;
-        stk_node[sp] = ca[n]; stk_code[sp] = code;  stk_bits[sp] = (uint8_t)min(nbits + 1, 255); ++sp;
-      }
-    }
-    if (nb & 31) bits[nb >> 5] = (uint32_t)acc;
+    const uint32_t nb = next > 0 ? (uint32_t)s_sz[next - 1] : 0u;
     s_num = (int)((nb + 7) >> 3);
     ws.tree_nbytes[(size_t)f * 2 + strm] = (nb + 7) >> 3;
-    if (err) atomicMax(&ws.status[f], 3);  // code longer than 32 bits: outside the built scope
+    if (s_err) atomicMax(&ws.status[f], 3);  // code longer than 32 bits: outside the built scope
   }
   __syncthreads();
   uint8_t *tree = ws.tree + ((size_t)f * 2 + strm) * kTreeStride;
@@ -1624,7 +1664,11 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_padfix(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
                                                 const uint32_t *sizes) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+  // One WAVEFRONT per row: the walk back over earlier rows looks at 64 of them per
+  // step (coalesced read of their bit counts, one ballot) instead of one per
+  // dependent load -- a row longer than all before it used to scan them one by one.
+  const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), f = blockIdx.y;
+  const int lane = threadIdx.x & 63;
   if (r >= g.rows || sizes[f] == 0) return;
   const int nsp = g.lres_spans + g.rows;
   const uint64_t *bit0 = ws.span_bit0 + (size_t)f * nsp + g.lres_spans;
@@ -1636,15 +1680,21 @@ __global__ __launch_bounds__(256) void k_padfix(Geom g, EncWs ws, uint8_t *out, 
   const uint32_t idx = ((bits + 7) >> 3) - 1;  // index of the last byte inside the row
   uint32_t need = 0xffu & ~((1u << valid) - 1u);
   uint32_t acc = 0;
-  for (int q = r - 1; q >= 0 && need; --q) {
-    const uint32_t qb = nbits[q];
-    const uint32_t qn = (qb + 7) >> 3;
-    if (qn <= idx) continue;  // row q never wrote scratch[idx]
-    const uint32_t byte = o[(bit0[q] >> 3) + idx];
+  int q_hi = r - 1;   // the most recent row not yet looked at
+  while (need && q_hi >= 0) {
+    const int q = q_hi - lane;
+    const uint32_t qb = q >= 0 ? nbits[q] : 0u;
+    const unsigned long long hit = __ballot(q >= 0 && ((qb + 7) >> 3) > idx);   // rows that wrote scratch[idx]
+    if (!hit) { q_hi -= 64; continue; }
+    const int l = __ffsll((long long)hit) - 1;   // the most recent of them
+    const int qs = q_hi - l;
+    const uint32_t qbs = (uint32_t)__shfl((int)qb, l);
+    const uint32_t qn = (qbs + 7) >> 3;
+    const uint32_t byte = o[(bit0[qs] >> 3) + idx];
     if (qn - 1 == idx) {
-      // scratch[idx] is row q's own last byte: its valid bits are q's, its pad
+      // scratch[idx] is row qs's own last byte: its valid bits are its own, its pad
       // bits are older still.
-      const uint32_t qv = qb & 7;
+      const uint32_t qv = qbs & 7;
       const uint32_t vmask = qv ? ((1u << qv) - 1u) : 0xffu;
       acc |= byte & vmask & need;
       need &= ~vmask;
@@ -1652,8 +1702,9 @@ __global__ __launch_bounds__(256) void k_padfix(Geom g, EncWs ws, uint8_t *out, 
       acc |= byte & need;
       need = 0;
     }
+    q_hi = qs - 1;
   }
-  if (acc) o[(bit0[r] >> 3) + idx] |= (uint8_t)acc;
+  if (lane == 0 && acc) o[(bit0[r] >> 3) + idx] |= (uint8_t)acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -1787,7 +1838,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
   HIMG_LAUNCH(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes, 0);
-  HIMG_LAUNCH(k_padfix, dim3((g.rows + 255) / 256, batch), b256, g, ws, d_out, out_stride,
+  HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
 }
 
@@ -1859,7 +1910,7 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
   HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0);
   HIMG_LAUNCH(k_emit, dim3(g.lres_spans, 1), b256, g, ws, d_out, out_cap, d_size, 0);
   HIMG_LAUNCH(k_place_fres, dim3(1024), b256, g, ws, d_rel, rel_bytes, d_out, d_size);
-  HIMG_LAUNCH(k_padfix, dim3((g.rows + 255) / 256, 1), b256, g, ws, d_out, out_cap, d_size);
+  HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, 1), b256, g, ws, d_out, out_cap, d_size);
 }
 
 }  // namespace himg_dev
