@@ -17,6 +17,7 @@
 // Wavefront = 64 lanes everywhere; no MFMA (there is no dense contraction).
 #include "himg_dev.h"
 
+#include <cstdlib>
 #include <utility>
 
 namespace himg_dev {
@@ -1764,6 +1765,20 @@ __global__ __launch_bounds__(256) void k_place_fres(Geom g, EncWs ws, const uint
     prof_end(prof, stream);                                    \
   } while (0)
 
+// Occupancy sweeps (BASELINE config 3, tools/occupancy_sweep.py): HIMG_LDS_PAD=<bytes>
+// adds that much unused dynamic LDS to every workgroup of the three wide encode
+// kernels, which lowers the number of workgroups a CU can hold.  0 in production.
+static size_t lds_pad() {
+  static const size_t v = [] { const char *e = getenv("HIMG_LDS_PAD"); const long x = e ? atol(e) : 0; return (size_t)(x > 0 && x <= 150000 ? x : 0); }();
+  return v;
+}
+#define HIMG_LAUNCH_PAD(name, grid, block, ...)                \
+  do {                                                         \
+    prof_begin(prof, #name, stream);                           \
+    hipLaunchKernelGGL(name, grid, block, lds_pad(), stream, __VA_ARGS__); \
+    prof_end(prof, stream);                                    \
+  } while (0)
+
 // The round-2 pixel stage (k_pix_fwd) serves full tiles of packed RGBA8.
 static bool use_pix_path(const Geom &g) {
   return g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4;
@@ -1775,7 +1790,7 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
   const unsigned gxt = (unsigned)((g.cols + kPixThreads - 1) / kPixThreads);
   const dim3 grid(gxt, n, batch), block(kPixThreads);
 #define HIMG_PIX(Y, COLS, FULL)                                                                  \
-  HIMG_LAUNCH((k_pix_fwd<Y, COLS, FULL>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
+  HIMG_LAUNCH_PAD((k_pix_fwd<Y, COLS, FULL>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
               ws.fres_stride, d_fmap_lut, st, r0)
   const bool full = g.cols % 64 == 0;
   if (g.ycbcr) { if (g.cols == 512) HIMG_PIX(true, 512, true); else if (full) HIMG_PIX(true, 0, true); else HIMG_PIX(true, 0, false); }
@@ -1833,11 +1848,11 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
-  HIMG_LAUNCH(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
+  HIMG_LAUNCH_PAD(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
-  HIMG_LAUNCH(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes, 0);
+  HIMG_LAUNCH_PAD(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes, 0);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
 }

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: 256 independent 1920x1080 RGBA frames (randtile seeds 0..255,
+q=50) encoded on one GPU, swept over (a) the LDS a workgroup of the wide encode
+kernels holds -- HIMG_LDS_PAD adds unused dynamic LDS, which lowers the workgroups
+(waves) a CU can hold -- and (b) the frames per launch.  Every point is checked
+against the golden table before it is timed.  Prints one JSON object
+(profiles/rNN_cfg3_sweep.json).  GPU box; each pad value runs in a child process
+(the pad is read once per process)."""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHILD = os.environ.get("HIMG_SWEEP_CHILD")
+
+
+def child():
+    import numpy as np
+    import torch
+    import himg_amd
+    W, H, Q, B = 1920, 1080, 50, 256
+    tab = json.load(open(os.path.join(ROOT, "tests", "golden", "batch_1920x1080_q50.json")))["seeds"]
+    frames = np.stack([himg_amd.synth("randtile", s, W, H) for s in range(B)])
+    d_frames = torch.from_numpy(frames).to("cuda:0")
+    cap = himg_amd.max_packed_size(W, H, 4)
+    d_out = torch.empty((B, cap), dtype=torch.uint8, device="cuda:0")
+    d_sz = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    d_st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    res = []
+    for per_launch in (256, 128, 64, 32):
+        n = B // per_launch
+        engs = [himg_amd.Engine(0) for _ in range(min(n, 2))]
+        streams = [torch.cuda.Stream() for _ in engs]
+
+        def run():
+            for i in range(n):
+                sl = slice(i * per_launch, (i + 1) * per_launch)
+                e, st = engs[i % len(engs)], streams[i % len(engs)]
+                e.encode_device(d_frames[sl], per_launch, W, H, 4, 4, Q, True, d_out[sl], cap, d_sz[sl], d_st[sl],
+                                st.cuda_stream)
+        run(); torch.cuda.synchronize()
+        sizes = d_sz.cpu().numpy()
+        assert not d_st.cpu().numpy().any()
+        for s in (0, 1, 127, 255):
+            assert int(sizes[s]) == tab[s][0] and himg_amd.fnv1a64(d_out[s, :tab[s][0]].cpu().numpy()) == tab[s][1], s
+        for e in engs:
+            e.profile_reset(); e.profile(True)
+        t = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / reps
+        st = {}
+        for e in engs:
+            e.profile(False)
+            for k, v in e.profile_read().items():
+                a = st.get(k, [0.0, 0]); st[k] = [a[0] + v[0], a[1] + v[1]]
+        res.append({"frames_per_launch": per_launch, "launches": n, "streams": len(engs),
+                    "encode_mpx_s": round(B * W * H / dt / 1e6, 1), "ms_per_256_frames": round(dt * 1e3, 3),
+                    "kernel_ms_per_launch": {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(st.items(), key=lambda kv: -kv[1][0])[:6]}})
+        for e in engs:
+            e.close()
+    print(json.dumps(res))
+
+
+def main():
+    out = {"workload": "256 x 1920x1080 RGBA randtile seeds 0..255 q=50, encode, one MI355X, frames resident in HBM; "
+                       "streams of seeds 0, 1, 127, 255 checked against the golden table at every point",
+           "lds_pad_note": "HIMG_LDS_PAD bytes of unused dynamic LDS per workgroup of k_pix_fwd (8 KiB static), k_tok_hist "
+                           "(12 KiB) and k_emit (22 KiB): workgroups per CU = min(waves limit, floor(160 KiB / (static + pad)))",
+           "points": []}
+    for pad in (0, 8192, 16384, 32768, 49152, 65536, 98304):
+        env = dict(os.environ, HIMG_SWEEP_CHILD="1", HIMG_LDS_PAD=str(pad))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
+        line = [l for l in r.stdout.splitlines() if l.startswith("[")]
+        if r.returncode != 0 or not line:
+            out["points"].append({"lds_pad": pad, "error": (r.stderr or r.stdout)[-300:]})
+            continue
+        out["points"].append({"lds_pad": pad, "results": json.loads(line[-1])})
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    child() if CHILD else main()

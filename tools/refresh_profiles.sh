@@ -1,15 +1,22 @@
 #!/bin/bash
 # Everything profiles/ holds for one round, in one GPU-box call (from the repo root):
-#   tools/refresh_profiles.sh <outdir under gpurun_out>
-# kernel stats (default run and one stream), PMC passes, the bench line itself.
+#   tools/refresh_profiles.sh <outdir under gpurun_out> [git sha]
+# the bench line, kernel stats (default run and one stream), PMC passes + traffic,
+# the config-3 occupancy sweep, the config-4 row profile, single-frame latency.
 set -u
 OUT=${1:-gpurun_out/refresh}
+SHA=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err"
+python3 "$ROOT/tools/occupancy_sweep.py" > "$ROOT/$OUT/cfg3_sweep.json" 2> "$ROOT/$OUT/cfg3_sweep.err"
+python3 "$ROOT/tools/rows_profile.py" > "$ROOT/$OUT/cfg4_rows.json" 2> "$ROOT/$OUT/cfg4_rows.err"
+python3 "$ROOT/tools/latency_profile.py" > "$ROOT/$OUT/latency.json" 2> "$ROOT/$OUT/latency.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_default" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$ROOT/$OUT/stats_default.log" 2>&1
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_streams1" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 8 --no-cpu-baseline --no-extras > "$ROOT/$OUT/stats_streams1.log" 2>&1
-cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 8" bash tools/profile_pmc.sh "$OUT/pmc"
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 8 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_streams1.log" 2>&1
+cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 8 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
+python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 8 "$OUT/traffic.json" "$SHA"
+ls "$ROOT/$OUT"
