@@ -133,7 +133,8 @@ struct Profiler;  // host-side, see himg_hip.hip
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
                    uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,
                    const StaticChunks &sc, const ShiftTables &st, const LresTables &lt,
-                   const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof);
+                   const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof,
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,

@@ -246,7 +246,12 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
     delete ctx;
     return HIMG_ERR_HIP;
   }
-  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+  // The side stream carries the wide k_row_count next to the caller's stream's short
+  // LRES kernels: lowest priority, so that those are placed first whenever a slot
+  // frees up (they sit on the critical path of the frame, the counts do not).
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
@@ -550,7 +555,8 @@ extern "C" int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, i
   hipStream_t s = (hipStream_t)stream;
   ctx->last_stream = s;
   launch_encode(g, ctx->enc_ws, batch, (const uint8_t *)d_frames, (uint8_t *)d_out, out_stride,
-                d_sizes, sc, st, lt, (const uint8_t *)ctx->fmap_lut.p, s, &ctx->prof);
+                d_sizes, sc, st, lt, (const uint8_t *)ctx->fmap_lut.p, s, &ctx->prof,
+                ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join);
   if (d_status)
     hipLaunchKernelGGL(k_copy_status, dim3((batch + 63) / 64), dim3(64), 0, s, ctx->enc_ws.status,
                        d_status, batch);

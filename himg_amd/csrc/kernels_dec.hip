@@ -1029,7 +1029,9 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
 // accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
 // pre_start / pre_off (optional): the fixpoint of the stream's single chunk computed
 // beforehand by k_row_count (pre_off[kDecThreads + 2] != 0 says it is usable).
-template <bool FUSED>
+// GLOBAL (with FUSED false): the output goes straight to `gout`, PRE-ZEROED global
+// memory, without the LDS window (win may be nullptr) -- the LRES serial fallback.
+template <bool FUSED, bool GLOBAL = false>
 __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
@@ -1093,6 +1095,9 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
         if (!exact_write(rd, tb, start, lim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
       }
       if (end_bp != ~0u) sh->endbit = cur + (end_bp - rel0);
+      __syncthreads();
+    } else if (GLOBAL) {
+      lean_write_global(rd, tb, sh, start, lim, opl, exact, out_size, cur, rel0, gout, exact ? opl : opl + cnt);
       __syncthreads();
     } else {
       const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
@@ -1341,9 +1346,27 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   // One read for the whole workgroup (other kernels may flag the frame meanwhile).
-  if (tid == 0) sh.flag = (df->status || !ws.ver_ok[f]) ? 1 : 0;
+  if (tid == 0) sh.flag = df->status ? 1 : (ws.ver_ok[f] ? 0 : 2);
   __syncthreads();
-  if (sh.flag) return;
+  if (sh.flag == 1) return;
+  if (sh.flag == 2) {
+    // The chunk chain did not verify (a mis-speculation ran through a whole chunk, or
+    // the test knob): this frame's LRES stream is decoded by ONE workgroup, chunk
+    // after chunk, every chunk starting at the exact end of the one before.
+    if (k != 0) return;
+    load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+    __syncthreads();
+    GrpTables tb0;
+    tb0.grp = grp; tb0.gx = nullptr; tb0.gy = nullptr; tb0.sub = sub; tb0.ca = ca; tb0.cb = cb; tb0.sy = sy;
+    const uint32_t po = df->s[0].payload_off;
+    const int bad = decode_stream<false, true>(packed + (size_t)f * in_stride, sizes[f], po, df->s[0].chunk_end - po,
+                                               (uint32_t)g.lres_size, tb0, &sh, nullptr, nullptr,
+                                               ws.lres_sym + (size_t)f * ws.lres_stride,
+                                               ws.stats + ((size_t)f * (g.rows + 1)) * 8, (uint32_t)g.max_sub,
+                                               (uint32_t)g.lead_bits);
+    if (bad && tid == 0) atomicMax(&df->status, fmt_err(4, 1));
+    return;
+  }
   const uint32_t pay_off = df->s[0].payload_off;
   const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
   const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
@@ -1406,11 +1429,12 @@ __device__ __forceinline__ int predict_d(int s1, int s2, int s3, int p) {
 }
 
 __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
-  __shared__ uint8_t rec[16][17];
+  // Four macro blocks per wavefront, 16 lanes each (see k_lres_predict).
+  __shared__ uint8_t rec[4][16][17];
   __shared__ int16_t s_lmap[128];   // the chain below looks a delta up per step: LDS, not global
-  const int mu = blockIdx.x, mv = blockIdx.y;
+  const int lane = threadIdx.x, b = lane >> 4, dv = lane & 15;
+  const int mu = blockIdx.x * 4 + b, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
-  const int lane = threadIdx.x;
   const DecFrame *df = ws.frames + f;
   if (df->status) return;
   s_lmap[lane] = df->lmap[lane];
@@ -1418,26 +1442,27 @@ __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
   __syncthreads();
   const uint8_t *in = ws.lres_sym + (size_t)f * ws.lres_stride + (size_t)c * g.chan_size;
   uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * g.cols;
+  const bool live = mu < g.mcols;
   const int u0 = mu * 16, v0 = mv * 16;
-  const int bw = min(16, g.cols - u0), bh = min(16, g.rows - v0);
+  const int bw = live ? min(16, g.cols - u0) : 0, bh = min(16, g.rows - v0);
   // DecodePredictor (downsampled.cpp:37-39): uint8 + 2 in int arithmetic, so
   // stored 254/255 come back as 256/257 and fall into PredictSample's default.
-  const int pc = (int)in[mv * g.mcols + mu] + 2;
+  const int pc = live ? (int)in[mv * g.mcols + mu] + 2 : 0;
   const uint8_t *src = in + g.mrows * g.mcols + (size_t)v0 * g.cols + (size_t)bh * u0;
   for (int d = 0; d < 31; ++d) {
-    const int dv = lane, du = d - lane;
-    if (lane < 16 && dv < bh && du >= 0 && du < bw) {
+    const int du = d - dv;
+    if (dv < bh && du >= 0 && du < bw) {
       int s1, s2, s3;
-      if (du > 0 && dv > 0) { s1 = rec[dv - 1][du - 1]; s2 = rec[dv - 1][du]; s3 = rec[dv][du - 1]; }
-      else if (du > 0) { s1 = s2 = s3 = rec[dv][du - 1]; }
-      else if (dv > 0) { s1 = s2 = s3 = rec[dv - 1][du]; }
+      if (du > 0 && dv > 0) { s1 = rec[b][dv - 1][du - 1]; s2 = rec[b][dv - 1][du]; s3 = rec[b][dv][du - 1]; }
+      else if (du > 0) { s1 = s2 = s3 = rec[b][dv][du - 1]; }
+      else if (dv > 0) { s1 = s2 = s3 = rec[b][dv - 1][du]; }
       else { s1 = s2 = s3 = 128; }
       const int predicted = predict_d(s1, s2, s3, pc);
       const int sc = (int8_t)src[dv * bw + du];
       // mapper.h:33-35 with the mirrored table (mapper.cpp:148-154).
       const int un = sc >= 0 ? s_lmap[sc] : (sc == -128 ? -s_lmap[127] : -s_lmap[-sc]);
       const int val = clamp255d((int)(int16_t)(predicted + un));
-      rec[dv][du] = (uint8_t)val;
+      rec[b][dv][du] = (uint8_t)val;
       m[(size_t)(v0 + dv) * g.cols + u0 + du] = (uint8_t)val;
     }
     __syncthreads();
@@ -2173,9 +2198,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
               in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);
   if (wps) {
-    HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                d_sizes, 0, 1, 0);  // LRES serial fallback (no-op when verified)
-    HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
+    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 3) / 4, g.mrows, batch * g.C), dim3(64), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (!side && nrows > 0)
       HIMG_LAUNCH(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
@@ -2197,8 +2220,6 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     prof_end(prof, stream);
   } else {
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-    HIMG_LAUNCH(k_dec_huff, dim3(1, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                d_sizes, 0, 1, 0);  // LRES serial fallback (no-op when verified)
     if (!side && nrows > 0)
       HIMG_LAUNCH(k_row_count<false>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
                   d_packed, in_stride, d_sizes, r0, r1, rpc);
@@ -2214,7 +2235,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, 1 + r0, 1, 2);
     }
-    HIMG_LAUNCH(k_lres_unpredict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws);
+    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 3) / 4, g.mrows, batch * g.C), dim3(64), g, ws);
     if (nrows > 0) HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
   }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);

@@ -147,38 +147,40 @@ __device__ __forceinline__ int predict(int s1, int s2, int s3, int p) {
 __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
                                                      size_t plane_stride, uint8_t *lres_sym,
                                                      size_t lres_stride, LresTables lt) {
-  __shared__ uint8_t mb[16][17];
-  __shared__ uint8_t rec[16][17];
+  // FOUR macro blocks per wavefront, 16 lanes each (lane & 15 = row of the block):
+  // the delta chain only ever has 16 rows to work on, so one block per wave left
+  // three quarters of it idle -- and a 4096x4096 frame is 4096 blocks per channel.
+  __shared__ uint8_t mb[4][16][17];
+  __shared__ uint8_t rec[4][16][17];
   // The companding tables in LDS: the delta chain below looks them up twice per
   // step, and out of the kernel-argument segment each lookup is a global load on
   // the critical path of 31 dependent steps.
   __shared__ int16_t s_tab[128];
   __shared__ uint8_t s_code[512];
-  const int mu = blockIdx.x, mv = blockIdx.y;
+  const int lane = threadIdx.x, b = lane >> 4, dv = lane & 15;
+  const int mu = blockIdx.x * 4 + b, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
-  const int lane = threadIdx.x;
   for (int k = lane; k < 128; k += 64) s_tab[k] = lt.tab[k];
   for (int k = lane; k < 512; k += 64) s_code[k] = lt.code[k];
   const uint8_t *m = low + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
+  const bool live = mu < g.mcols;
   const int u0 = mu * 16, v0 = mv * 16;
-  const int bw = min(16, g.cols - u0), bh = min(16, g.rows - v0);
+  const int bw = live ? min(16, g.cols - u0) : 0, bh = min(16, g.rows - v0);
 
-  for (int k = lane; k < 256; k += 64) {
-    const int dv = k >> 4, du = k & 15;
-    mb[dv][du] = (dv < bh && du < bw) ? m[(size_t)(v0 + dv) * g.cols + u0 + du] : 0;
-  }
+#pragma unroll
+  for (int du = 0; du < 16; ++du)
+    mb[b][dv][du] = (dv < bh && du < bw) ? m[(size_t)(v0 + dv) * g.cols + u0 + du] : 0;
   __syncthreads();
 
   int err[5] = {0, 0, 0, 0, 0};
-  for (int k = lane; k < 256; k += 64) {
-    const int dv = k >> 4, du = k & 15;
-    if (dv < bh && du < bw) {
+  if (dv < bh) {
+    for (int du = 0; du < bw; ++du) {
       int s1, s2, s3;
-      if (du > 0 && dv > 0) { s1 = mb[dv - 1][du - 1]; s2 = mb[dv - 1][du]; s3 = mb[dv][du - 1]; }
-      else if (du > 0) { s1 = s2 = s3 = mb[dv][du - 1]; }
-      else if (dv > 0) { s1 = s2 = s3 = mb[dv - 1][du]; }
+      if (du > 0 && dv > 0) { s1 = mb[b][dv - 1][du - 1]; s2 = mb[b][dv - 1][du]; s3 = mb[b][dv][du - 1]; }
+      else if (du > 0) { s1 = s2 = s3 = mb[b][dv][du - 1]; }
+      else if (dv > 0) { s1 = s2 = s3 = mb[b][dv - 1][du]; }
       else { s1 = s2 = s3 = 128; }
-      const int actual = mb[dv][du];
+      const int actual = mb[b][dv][du];
 #pragma unroll
       for (int p = 0; p < 5; ++p) {
         const int d = actual - predict(s1, s2, s3, p);
@@ -188,33 +190,33 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
   }
 #pragma unroll
   for (int p = 0; p < 5; ++p)
-    for (int d = 32; d >= 1; d >>= 1) err[p] += __shfl_xor(err[p], d);
+    for (int d = 8; d >= 1; d >>= 1) err[p] += __shfl_xor(err[p], d);   // over the block's 16 lanes
   int best = 0, best_err = err[0];
 #pragma unroll
   for (int p = 1; p < 5; ++p)
     if (err[p] < best_err) { best = p; best_err = err[p]; }
 
   uint8_t *out = lres_sym + (size_t)f * lres_stride + (size_t)c * g.chan_size;
-  if (lane == 0) out[mv * g.mcols + mu] = (uint8_t)(best - 2);  // downsampled.cpp:33-35
+  if (live && dv == 0) out[mv * g.mcols + mu] = (uint8_t)(best - 2);  // downsampled.cpp:33-35
   // The stored byte is read back as (uint8 + 2) in int arithmetic
   // (downsampled.cpp:37-39), so selections 0 and 1 both CODE with predictor 0.
   const int pc = best <= 1 ? 0 : best;
 
   uint8_t *dst = out + g.mrows * g.mcols + (size_t)v0 * g.cols + (size_t)bh * u0;
   for (int d = 0; d < 31; ++d) {
-    const int dv = lane, du = d - lane;
-    if (lane < 16 && dv < bh && du >= 0 && du < bw) {
+    const int du = d - dv;
+    if (dv < bh && du >= 0 && du < bw) {
       int s1, s2, s3;
-      if (du > 0 && dv > 0) { s1 = rec[dv - 1][du - 1]; s2 = rec[dv - 1][du]; s3 = rec[dv][du - 1]; }
-      else if (du > 0) { s1 = s2 = s3 = rec[dv][du - 1]; }
-      else if (dv > 0) { s1 = s2 = s3 = rec[dv - 1][du]; }
+      if (du > 0 && dv > 0) { s1 = rec[b][dv - 1][du - 1]; s2 = rec[b][dv - 1][du]; s3 = rec[b][dv][du - 1]; }
+      else if (du > 0) { s1 = s2 = s3 = rec[b][dv][du - 1]; }
+      else if (dv > 0) { s1 = s2 = s3 = rec[b][dv - 1][du]; }
       else { s1 = s2 = s3 = 128; }
       const int predicted = predict(s1, s2, s3, pc);
-      const int delta = (int)mb[dv][du] - predicted;
+      const int delta = (int)mb[b][dv][du] - predicted;
       const uint8_t code = s_code[delta + 255];
       const int sc = (int8_t)code;
       const int un = sc >= 0 ? s_tab[sc] : -s_tab[-sc];
-      rec[dv][du] = (uint8_t)clamp255(predicted + un);
+      rec[b][dv][du] = (uint8_t)clamp255(predicted + un);
       dst[dv * bw + du] = code;
     }
     __syncthreads();
@@ -1815,7 +1817,8 @@ static void launch_tile_pk(const Geom &g, const EncWs &ws, const uint8_t *d_fram
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
                    uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,
                    const StaticChunks &sc, const ShiftTables &st, const LresTables &lt,
-                   const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof) {
+                   const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof,
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const int nsp = g.lres_spans + g.rows;
   const dim3 b256(256);
   const unsigned gx = (unsigned)((g.cols + 255) / 256);
@@ -1835,8 +1838,25 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride, 0);
   HIMG_LAUNCH(k_lowres_blend, dim3(gx, g.rows, batch * g.C), b256, g, ws.avg, ws.low,
               ws.plane_stride, 0);
-  HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, batch * g.C), dim3(64), g, ws.low,
-              ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
+  // The LRES branch (predictor selection + delta chain, zero-run summaries, token
+  // histogram of the LRES spans: 1/64 of the data, latency-bound kernels) forks to the
+  // side stream and runs beside the pixel stage and the FRES histogram; the two
+  // branches join in front of the tree build.  (side == nullptr: in line.)
+  hipStream_t ls = side ? side : stream;
+  if (side) {
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+  }
+  {
+    hipStream_t stream_saved = stream;
+    stream = ls;
+    HIMG_LAUNCH(k_lres_predict, dim3((g.mcols + 3) / 4, g.mrows, batch * g.C), dim3(64), g, ws.low,
+                ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
+    HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
+    HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, batch), b256, g, ws, 0);
+    stream = stream_saved;
+  }
+  if (side) (void)hipEventRecord(ev_join, side);
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
   const bool pix = use_pix_path(g);
   if (pix) {
@@ -1847,8 +1867,8 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
-  HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
-  HIMG_LAUNCH_PAD(k_tok_hist, dim3(nsp, batch), b256, g, ws, 0);
+  HIMG_LAUNCH_PAD(k_tok_hist, dim3(g.rows, batch), b256, g, ws, g.lres_spans);   // FRES rows
+  if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
@@ -1917,7 +1937,7 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
     if (start + width > out_cap) width = out_cap - start;
     (void)hipMemsetAsync(d_out + start, 0, width, stream);
   }
-  HIMG_LAUNCH(k_lres_predict, dim3(g.mcols, g.mrows, g.C), dim3(64), g, ws.low, ws.plane_stride,
+  HIMG_LAUNCH(k_lres_predict, dim3((g.mcols + 3) / 4, g.mrows, g.C), dim3(64), g, ws.low, ws.plane_stride,
               ws.lres_sym, ws.lres_stride, lt);
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, 1), b256, g, ws);
   HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, 1), b256, g, ws, 0);
