@@ -95,6 +95,7 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
   uint8_t shift[2][64];
 };
 
+constexpr int kLresMemoWords = 6;
 struct DecWs {
   DecFrame *frames;          // [f]
   int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
@@ -118,6 +119,7 @@ struct DecWs {
   uint32_t *spec_start;      // [f][lres_chunks][1024] lane start, bits from the chunk's nominal start
   uint32_t *spec_endpos;     // [f][lres_chunks][1024] lane end, same origin
   uint32_t *spec_cnt;        // [f][lres_chunks][1024] symbols per lane
+  uint32_t *spec_memo;       // [f][lres_chunks][1024][kLresMemoWords] starts the lane has decoded from, packed
   uint64_t *spec_end;        // [f][lres_chunks] payload bit where the chunk's speculative chain ends
   uint64_t *fix_end;         // [f][lres_chunks] the same after the correction pass
   uint64_t *spec_tot;        // [f][lres_chunks] symbols of the chunk

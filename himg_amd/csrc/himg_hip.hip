@@ -471,7 +471,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
     const size_t max_bits = 8ull * ((size_t)g.lres_size + kTreeStride);
     const size_t cb = (size_t)kDecThreads * 8 * 32;
     int nch = (int)((max_bits + cb - 1) / cb);
-    if (nch > 1024) nch = 1024;  // beyond this the serial path takes over (k_lres_verify)
+    if (nch > 1024) nch = 1024;  // beyond this the serial path takes over (k_lres_fix)
     w.lres_chunks = nch;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += round_up(bytes, 256); return o; };
@@ -484,6 +484,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
     const size_t o_vb = carve((size_t)batch * nch * 8);
     const size_t o_ok = carve((size_t)batch * 4);
     const size_t o_eb = carve((size_t)batch * 8);
+    const size_t o_mm = carve((size_t)batch * nch * kDecThreads * 4 * himg_dev::kLresMemoWords);
     if (!ctx->d_spec.reserve(off)) return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
     uint8_t *b = (uint8_t *)ctx->d_spec.p;
     w.spec_start = (uint32_t *)(b + o_ss); w.spec_cnt = (uint32_t *)(b + o_sc);
@@ -491,6 +492,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
     w.spec_endpos = (uint32_t *)(b + o_sp); w.fix_end = (uint64_t *)(b + o_fe);
     w.ver_base = (uint64_t *)(b + o_vb); w.ver_ok = (int32_t *)(b + o_ok);
     w.lres_endbit = (uint64_t *)(b + o_eb);
+    w.spec_memo = (uint32_t *)(b + o_mm);
   }
   ctx->dec_geom = g;
   ctx->dec_batch = batch;

@@ -4,7 +4,7 @@
 //   k_dec_parse       RIFF chunk headers, mapping tables, QCFG, both Huffman trees,
 //                     decode tables (decoder.cpp:144-290,428-461, huffman_dec.cpp:152-229)
 //   k_dec_rowwalk     index of the FRES block rows (huffman_dec.cpp:232-248), side stream
-//   k_lres_chain<>, k_lres_verify, k_lres_write, k_lres_finish
+//   k_lres_spec, k_lres_fix, k_lres_write, k_lres_finish
 //                     the LRES stream, all chunks in parallel (huffman_dec.cpp:274-418)
 //   k_lres_unpredict  inverse low-res prediction              (downsampled.cpp:318-382)
 //   k_row_count       fixpoint rounds of every FRES block row (huffman_dec.cpp:274-418)
@@ -783,13 +783,20 @@ __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t 
 // lanes whose start changes decode again.
 // Lanes whose range lies beyond the payload (`active` false) own nothing and stay
 // out of it: passing the chain's end along them would cost one round per lane.
-template <bool SOA = false, class RD = GReader>
+// MEMO > 0: the lane remembers its last MEMO (start -> end, count) results in
+// memo[3 * MEMO] (start ~0u = empty; the caller may pre-load it) and a start it has
+// seen before costs a look-up.  For streams that do NOT self-synchronise -- codes of
+// nearly one length, e.g. the 5/6-bit codes of the LRES predictor bytes: a wrong
+// phase survives thousands of tokens there -- every round moves every lane of such a
+// stretch to one of the same few phases again, and the correction passes along the
+// chain one lane per round: rounds that are look-ups instead of decodes.
+template <bool SOA = false, class RD = GReader, int MEMO = 0>
 __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, StreamShared *sh,
                                               uint32_t first, bool active, uint32_t lim,
                                               uint32_t *start_io, uint32_t *endpos_io,
                                               uint32_t *cnt_io, uint32_t *rounds, bool warm,
                                               uint32_t lead_bits, long long *c_first = nullptr,
-                                              long long *c_phase = nullptr) {
+                                              long long *c_phase = nullptr, uint32_t *memo = nullptr) {
   const int tid = threadIdx.x;
   const long long t_in = clock64();
   uint32_t start = *start_io, endpos = *endpos_io, cnt = *cnt_io;
@@ -825,7 +832,14 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
   if (T > lim || T < nominal) T = lim;
   uint32_t posT = ~0u, cT = 0;
   for (;;) {
-    if (dirty) {
+    bool hit = false;
+    if (MEMO > 0 && dirty) {
+#pragma unroll
+      for (int e = 0; e < MEMO; ++e)
+        if (memo[3 * e] == start) { endpos = memo[3 * e + 1]; cnt = memo[3 * e + 2]; hit = true; }
+      if (hit) posT = ~0u;   // (endpos, cnt) no longer belong to the re-join checkpoint
+    }
+    if (dirty && !hit) {
       uint32_t p1, c1;
       lean_count<SOA>(rd, tb, start, T, &p1, &c1);
       if (p1 == posT) {
@@ -839,6 +853,13 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
       }
       posT = p1;
       cT = c1;
+      if (MEMO > 0) {
+#pragma unroll
+        for (int e = MEMO - 1; e > 0; --e) {
+          memo[3 * e] = memo[3 * e - 3]; memo[3 * e + 1] = memo[3 * e - 2]; memo[3 * e + 2] = memo[3 * e - 1];
+        }
+        memo[0] = start; memo[1] = endpos; memo[2] = cnt;
+      }
     }
     sh->nxt[tid + 1] = endpos;
     __syncthreads();
@@ -1206,15 +1227,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
 //   k_lres_spec    chunk k assumes its first token starts at its nominal first
 //                  bit and runs the in-chunk fixpoint; stores every lane's start,
 //                  end and symbol count, the chunk's end position and total.
-//   k_lres_fix     chunk k (k >= 1) restarts its fixpoint WARM with lane 0 at
-//                  T_k = spec end of chunk k-1; only lanes whose start changes
-//                  decode again (a handful unless the data does not
-//                  self-synchronise).  Stores the corrected chain, end and total.
-//   k_lres_verify  chunk 0 is exact, so T_1 and hence chunk 1's corrected chain are
-//                  exact; T_2 was taken from chunk 1's SPECULATIVE end, which is
-//                  right iff the correction left that end unchanged -- and so on.
-//                  All ends unchanged => every chunk exact (induction).  Output
-//                  offsets = scan of the corrected totals.
+//   k_lres_fix     one workgroup per frame: chunk k (k >= 1) is re-based on
+//                  T_k = spec end of chunk k-1 -- by one sub-sequence of work when
+//                  the chain re-joins the speculative one at once (the normal case),
+//                  by a WARM restart of the chunk's fixpoint otherwise -- and the
+//                  chain of ends is verified (see the kernel).
 //   k_lres_write   chunk k writes its symbols from the corrected lane starts.
 // If an end did change (a mis-speculation ran through a whole 32 KiB chunk) the
 // frame falls back to the serial workgroup-per-stream path (k_dec_huff).
@@ -1222,34 +1239,36 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
 constexpr int kLresSubBits = 256;   // bits per lane
 constexpr int kLresChunkBits = kDecThreads * kLresSubBits;
 
+// One chunk of the LRES stream, tables already in LDS.  FIX false: the speculative
+// in-chunk fixpoint from the nominal first bit.  FIX true: the warm restart with lane
+// 0 at T = the speculative end of the previous chunk (the caller has established that
+// the cheap test failed).
+// The chunk's payload is staged in LDS first (s_pay, kLresPayWords dwords): the rounds
+// of a chain that does not self-synchronise -- the run tokens of a constant plane, e.g.
+// opaque alpha, repeat with a period and keep a wrong phase for their whole length --
+// are ONE lane decoding one sub-sequence each, i.e. pure load latency, and that of the
+// LDS is a tenth of the L2's.
+constexpr int kLresPayWords = kDecThreads * kLresSubBits / 32 + 8;
+constexpr int kLresMemo = kLresMemoWords;   // starts a lane remembers
 template <bool FIX>
-__global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, const uint8_t *packed,
-                                                            size_t in_stride, const uint32_t *sizes) {
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
-  __shared__ StreamShared sh;
-  const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-  DecFrame *df = ws.frames + f;
-  if (df->status) return;
+__device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p, uint32_t stream_size,
+                                const DecFrame *df, int f, int k, const GrpTables &tb, StreamShared *sh,
+                                uint32_t *s_pay) {
+  const int tid = threadIdx.x;
   const uint32_t pay_off = df->s[0].payload_off;
   const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
   const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
   const size_t slot = (size_t)f * ws.lres_chunks + k;
   uint64_t *end_out = FIX ? ws.fix_end : ws.spec_end;
-  if (cur >= P1) {
-    if (tid == 0) { end_out[slot] = cur; ws.spec_tot[slot] = 0; }
-    return;
-  }
-  if (FIX && k == 0) {  // chunk 0 is exact already
-    if (tid == 0) ws.fix_end[slot] = ws.spec_end[slot];
-    return;
-  }
-  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  GReader rd;
-  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
+  GReader gr;
+  const uint32_t rel0 = gr.attach(p, stream_size, 8ull * pay_off + cur);
+  // Bits up to rel0 + chunk + 46 are consumed and the reader runs three dwords ahead:
+  // all inside the staged words, the clamp at jmax is never the stream's data.
+  for (int j = tid; j < kLresPayWords; j += kDecThreads) s_pay[j] = gr.ld((uint32_t)j);
+  __syncthreads();
+  LReader rd;
+  rd.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
+  rd.jmax = kLresPayWords - 1;
   const unsigned long long rem = P1 - cur;
   const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
   const uint32_t my_b0 = rel0 + tid * kLresSubBits;
@@ -1257,32 +1276,6 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
   if (lim > rel_end) lim = rel_end;
   const bool active = my_b0 < rel_end;
   const int last_active = (int)((rel_end - rel0 - 1u) / kLresSubBits);
-  __syncthreads();
-  if (FIX) {
-    // Cheap test first: lane 0 re-decodes its own sub-sequence from the true start
-    // T.  If it ends where its speculative chain ended, no other lane changes and
-    // the chunk is done.
-    if (tid == 0) {
-      const unsigned long long T = ws.spec_end[slot - 1];
-      sh.flag = 0;
-      if (T >= cur && T < cur + kLresSubBits) {
-        uint32_t pos, c;
-        lean_count(rd, tb, rel0 + (uint32_t)(T - cur), lim, &pos, &c);
-        if (pos - rel0 == ws.spec_endpos[slot * kDecThreads]) {
-          const unsigned long long oldc = ws.spec_cnt[slot * kDecThreads];
-          ws.spec_start[slot * kDecThreads] = (uint32_t)(T - cur);
-          ws.spec_cnt[slot * kDecThreads] = c;
-          ws.spec_tot[slot] = ws.spec_tot[slot] - oldc + c;
-          ws.fix_end[slot] = ws.spec_end[slot];
-          sh.flag = 1;
-          uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1)) * 8;
-          atomicAdd(&st[2], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    if (sh.flag) return;
-  }
   uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0, first = rel0;
   if (FIX) {
     const unsigned long long T = ws.spec_end[slot - 1];
@@ -1296,9 +1289,34 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     endpos = rel0 + ws.spec_endpos[slot * kDecThreads + tid];
     cnt = ws.spec_cnt[slot * kDecThreads + tid];
   }
-  lean_fixpoint(rd, tb, &sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX, (uint32_t)g.lead_bits);
+  // The lane's memo (lean_fixpoint), handed from the speculative pass to the correction
+  // through ws.spec_memo, one packed word per entry: start - nominal (<= 46: the
+  // previous lane's last token) | end - lim (<= 46) << 6 | symbols (< 2^20) << 12.
+  // Lane 0's start is given, it has no use for one.
+  uint32_t memo[3 * kLresMemo];
+  uint32_t *gm = ws.spec_memo + (slot * kDecThreads + tid) * kLresMemo;
+#pragma unroll
+  for (int e = 0; e < kLresMemo; ++e) {
+    memo[3 * e] = ~0u; memo[3 * e + 1] = memo[3 * e + 2] = 0;
+    if (FIX && tid > 0) {
+      const uint32_t m = gm[e];
+      if (m != ~0u) { memo[3 * e] = my_b0 + (m & 63u); memo[3 * e + 1] = lim + ((m >> 6) & 63u); memo[3 * e + 2] = m >> 12; }
+    }
+  }
+  const long long c_in = clock64();
+  lean_fixpoint<false, LReader, kLresMemo>(rd, tb, sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX,
+                                           (uint32_t)g.lead_bits, nullptr, nullptr, memo);
+  const long long c_fix = clock64() - c_in;
+  if (!FIX) {
+#pragma unroll
+    for (int e = 0; e < kLresMemo; ++e) {
+      const uint32_t ds = memo[3 * e] - my_b0, de = memo[3 * e + 1] - lim;
+      gm[e] = (memo[3 * e] == ~0u || tid == 0 || ds > 46u || de > 46u || memo[3 * e + 2] >= (1u << 20))
+                  ? ~0u : (ds | (de << 6) | (memo[3 * e + 2] << 12));
+    }
+  }
   unsigned long long tot;
-  block_scan_u64(cnt, sh.sm64, &tot);
+  block_scan_u64(cnt, sh->sm64, &tot);
   ws.spec_start[slot * kDecThreads + tid] = start - rel0;
   ws.spec_endpos[slot * kDecThreads + tid] = endpos - rel0;
   ws.spec_cnt[slot * kDecThreads + tid] = cnt;
@@ -1308,21 +1326,113 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_chain(Geom g, DecWs ws, co
     atomicAdd(&st[FIX ? 2 : 0], 1u);
     atomicAdd(&st[FIX ? 3 : 1], rounds);
     atomicMax(&st[FIX ? 5 : 4], rounds);   // the slowest chunk sets the kernel's duration
+    atomicMax(&st[FIX ? 7 : 6], (uint32_t)(c_fix >> 4));
   }
 }
 
-__global__ __launch_bounds__(kDecThreads) void k_lres_verify(Geom g, DecWs ws) {
-  __shared__ unsigned long long sm64[kDecThreads / 64];
+// k_lres_spec: every chunk of every frame, speculatively, in parallel.
+__global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, const uint8_t *packed,
+                                                           size_t in_stride, const uint32_t *sizes) {
+  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ uint32_t sub[kSubEntries];
+  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ StreamShared sh;
+  __shared__ uint32_t s_pay[kLresPayWords];
+  const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  if (tid == 0) sh.flag = df->status;
+  __syncthreads();
+  if (sh.flag) return;
+  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - df->s[0].payload_off);
+  const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
+  const size_t slot = (size_t)f * ws.lres_chunks + k;
+  if (cur >= P1) {
+    if (tid == 0) { ws.spec_end[slot] = cur; ws.spec_tot[slot] = 0; }
+    return;
+  }
+  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+  __syncthreads();
+  GrpTables tb;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  lres_chain_body<false>(g, ws, packed + (size_t)f * in_stride, sizes[f], df, f, k, tb, &sh, s_pay);
+}
+
+// k_lres_fix: correction and verification of ALL chunks of a frame by one workgroup.
+//   1. lane k = chunk k.  Chunk k's true first token starts where chunk k-1's
+//      speculative chain ended (T); lane k decodes the first sub-sequence of its chunk
+//      from T, and if that ends where the speculative first lane ended, nothing else in
+//      the chunk changes: the chunk is settled with one sub-sequence of work (this
+//      used to cost a whole workgroup and a load of the decode tables per chunk);
+//   2. the chunks that did not re-join (none, normally) take the warm restart, one
+//      after the other, with the whole workgroup;
+//   3. chunk 0 is exact, so T_1 and hence chunk 1's corrected chain are exact; T_2 was
+//      taken from chunk 1's SPECULATIVE end, which is right iff the correction left
+//      that end unchanged -- and so on.  All ends unchanged => every chunk exact
+//      (induction).  Output offsets = scan of the corrected totals.
+__global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, const uint8_t *packed,
+                                                          size_t in_stride, const uint32_t *sizes) {
+  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
+  __shared__ uint32_t sub[kSubEntries];
+  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ StreamShared sh;
+  __shared__ uint8_t s_pending[kDecThreads];
   __shared__ int s_bad;
+  __shared__ uint32_t s_pay[kLresPayWords];
   const int f = blockIdx.x, k = threadIdx.x;
   DecFrame *df = ws.frames + f;
-  if (k == 0) { ws.ver_ok[f] = 0; ws.lres_endbit[f] = ~0ull; s_bad = 0; }
-  if (df->status) return;
-  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - df->s[0].payload_off);
-  const int nact = (int)((P1 + kLresChunkBits - 1) / kLresChunkBits);
+  if (k == 0) { ws.ver_ok[f] = 0; ws.lres_endbit[f] = ~0ull; s_bad = 0; sh.flag = df->status; }
+  s_pending[k] = 0;
   __syncthreads();
+  if (sh.flag) return;
+  const uint32_t pay_off = df->s[0].payload_off;
+  const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
+  const int nact = (int)((P1 + kLresChunkBits - 1) / kLresChunkBits);
   if (nact > ws.lres_chunks || nact > kDecThreads) return;  // ver_ok stays 0 -> serial path
+  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+  __syncthreads();
+  GrpTables tb;
+  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const uint8_t *p = packed + (size_t)f * in_stride;
   const size_t slot = (size_t)f * ws.lres_chunks + k;
+  const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
+  // ---- 1: the cheap test, all chunks at once
+  if (k == 0) {
+    ws.fix_end[slot] = ws.spec_end[slot];   // chunk 0 is exact already
+  } else if (k < nact) {
+    const unsigned long long T = ws.spec_end[slot - 1];
+    bool settled = false;
+    if (T >= cur && T < cur + kLresSubBits) {
+      GReader rd;
+      const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off + cur);
+      const unsigned long long rem = P1 - cur;
+      uint32_t lim = rel0 + kLresSubBits;
+      const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
+      if (lim > rel_end) lim = rel_end;
+      uint32_t pos, c;
+      lean_count(rd, tb, rel0 + (uint32_t)(T - cur), lim, &pos, &c);
+      if (pos - rel0 == ws.spec_endpos[slot * kDecThreads]) {
+        const unsigned long long oldc = ws.spec_cnt[slot * kDecThreads];
+        ws.spec_start[slot * kDecThreads] = (uint32_t)(T - cur);
+        ws.spec_cnt[slot * kDecThreads] = c;
+        ws.spec_tot[slot] = ws.spec_tot[slot] - oldc + c;
+        ws.fix_end[slot] = ws.spec_end[slot];
+        settled = true;
+        atomicAdd(&ws.stats[((size_t)f * (g.rows + 1)) * 8 + 2], 1u);
+      }
+    }
+    if (!settled) s_pending[k] = 1;
+  }
+  __syncthreads();
+  // ---- 2: warm restarts of what is left
+  for (int q = 1; q < nact; ++q) {
+    if (!s_pending[q]) continue;   // LDS: the same for every lane
+    lres_chain_body<true>(g, ws, p, sizes[f], df, f, q, tb, &sh, s_pay);
+    __syncthreads();
+  }
+  // ---- 3: verification and output offsets (other lanes' global writes of this
+  // kernel are read below)
+  __threadfence_block();
+  __syncthreads();
   unsigned long long ntot = 0;
   if (k < nact) {
     ntot = ws.spec_tot[slot];
@@ -1331,7 +1441,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_verify(Geom g, DecWs ws) {
     if (k + 1 < nact && ws.fix_end[slot] != ws.spec_end[slot]) s_bad = 1;
   }
   unsigned long long tot;
-  const unsigned long long base = block_scan_u64(ntot, sm64, &tot);
+  const unsigned long long base = block_scan_u64(ntot, sh.sm64, &tot);
   if (k < nact) ws.ver_base[slot] = base;
   __syncthreads();
   if (k == 0) ws.ver_ok[f] = (s_bad || g.lres_serial) ? 0 : 1;
@@ -2189,11 +2299,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   if (ws.rc_stats) (void)hipMemsetAsync(ws.rc_stats, 0, (size_t)batch * g.rows * 8 * sizeof(uint32_t), stream);
   // k_lres_write stores the non-zero symbols only.
   (void)hipMemsetAsync(ws.lres_sym, 0, (size_t)batch * ws.lres_stride, stream);
-  HIMG_LAUNCH(k_lres_chain<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+  HIMG_LAUNCH(k_lres_spec, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
               d_packed, in_stride, d_sizes);
-  HIMG_LAUNCH(k_lres_chain<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
-              d_packed, in_stride, d_sizes);
-  HIMG_LAUNCH(k_lres_verify, dim3(batch), dim3(kDecThreads), g, ws);
+  HIMG_LAUNCH(k_lres_fix, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_write, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws, d_packed,
               in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);

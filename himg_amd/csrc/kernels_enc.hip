@@ -108,20 +108,24 @@ __global__ __launch_bounds__(256) void k_lowres_avg(Geom g, const uint8_t *frame
 }
 
 // k_lowres_blend: m = blend of the averages at (v-1,v) x (u-1,u) (downsampled.cpp:98-113).
+constexpr int kBlendRows = 8;   // block rows per k_lowres_blend workgroup (the kernel is launch-bound)
 __global__ __launch_bounds__(256) void k_lowres_blend(Geom g, const uint8_t *avg, uint8_t *low,
-                                                      size_t plane_stride, int v0) {
+                                                      size_t plane_stride, int v0, int v1) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y + v0;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
   if (u >= g.cols) return;
   const uint8_t *a = avg + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
-  const int r1 = max(0, v - 1), c1 = max(0, u - 1);
-  const int x11 = a[r1 * g.cols + c1], x12 = a[r1 * g.cols + u];
-  const int x21 = a[v * g.cols + c1], x22 = a[v * g.cols + u];
-  const int a1 = (x11 + 15 * x12 + 8) >> 4;
-  const int a2 = (x21 + 15 * x22 + 8) >> 4;
-  low[(size_t)f * plane_stride + ((size_t)c * g.rows + v) * g.cols + u] =
-      (uint8_t)((a1 + 15 * a2 + 8) >> 4);
+  const int c1 = max(0, u - 1);
+  const int vb = v0 + (int)blockIdx.y * kBlendRows;
+  for (int v = vb; v < min(vb + kBlendRows, v1); ++v) {
+    const int r1 = max(0, v - 1);
+    const int x11 = a[r1 * g.cols + c1], x12 = a[r1 * g.cols + u];
+    const int x21 = a[v * g.cols + c1], x22 = a[v * g.cols + u];
+    const int a1 = (x11 + 15 * x12 + 8) >> 4;
+    const int a2 = (x21 + 15 * x22 + 8) >> 4;
+    low[(size_t)f * plane_stride + ((size_t)c * g.rows + v) * g.cols + u] =
+        (uint8_t)((a1 + 15 * a2 + 8) >> 4);
+  }
 }
 
 // Predictors of downsampled.cpp:41-60.
@@ -1836,8 +1840,8 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   prof_end(prof, stream);
 
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride, 0);
-  HIMG_LAUNCH(k_lowres_blend, dim3(gx, g.rows, batch * g.C), b256, g, ws.avg, ws.low,
-              ws.plane_stride, 0);
+  HIMG_LAUNCH(k_lowres_blend, dim3(gx, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256, g, ws.avg, ws.low,
+              ws.plane_stride, 0, g.rows);
   // The LRES branch (predictor selection + delta chain, zero-run summaries, token
   // histogram of the LRES spans: 1/64 of the data, latency-bound kernels) forks to the
   // side stream and runs beside the pixel stage and the FRES histogram; the two
@@ -1904,7 +1908,8 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
   const int a0 = r0 > 0 ? r0 - 1 : 0, a1 = r1 < g.rows ? r1 + 1 : g.rows;
   const int l1 = r1 < g.rows ? r1 + 1 : g.rows;
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, a1 - a0, 1), b256, g, d_frame_base, ws.avg, ws.plane_stride, a0);
-  HIMG_LAUNCH(k_lowres_blend, dim3(gx, l1 - r0, g.C), b256, g, ws.avg, ws.low, ws.plane_stride, r0);
+  HIMG_LAUNCH(k_lowres_blend, dim3(gx, (l1 - r0 + kBlendRows - 1) / kBlendRows, g.C), b256, g, ws.avg, ws.low,
+              ws.plane_stride, r0, l1);
   launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
   HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
 }

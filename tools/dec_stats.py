@@ -15,6 +15,7 @@ rows = (h + 7) // 8
 st = eng.debug_read("dec_stats", 0, (rows + 1) * 32, np.uint32, decoder=True).reshape(rows + 1, 8)
 names = ["chunks", "rounds", "clk_transform/16, slowest wave (lres: fix chunks)", "clk_workgroup/16 (lres: fix rounds; unfused: clk_round1)", "clk_sync/16", "clk_write/16", "pay_len", "out_size"]
 print("LRES: chunks %d, fixpoint rounds %d (slowest chunk %d); corrected chunks %d, rounds %d (slowest %d)" % (st[0][0], st[0][1], st[0][4], st[0][2], st[0][3], st[0][5]))
+print("LRES: longest fixpoint %d cycles (speculative), %d cycles (corrected)" % (int(st[0][6]) * 16, int(st[0][7]) * 16))
 ps = eng.debug_read("parse_stats", 0, 16, np.uint32, decoder=True)
 print("k_dec_parse cycles: serial %d, lut %d, sub %d, grp %d" % tuple((ps.astype(np.int64) * 16).tolist()))
 rc = eng.debug_read("rowcount_stats", 0, rows * 32, np.uint32, decoder=True).reshape(rows, 8).astype(np.float64) * 16
