@@ -591,7 +591,7 @@ def main():
         # (encode), packed read + W*H*4 written (decode); one launch processes B frames.
         alg_bytes_side = B * W * H * 4.0 + packed_total
         alg_bytes_launch = alg_bytes_side * G / B   # one launch processes G = B/streams frames
-        enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_tile_fwd_pk", "k_lres_summary",
+        enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_pix_fwd", "k_lres_summary",
                       "k_tok_hist", "k_tree", "k_sizes", "k_emit", "k_padfix", "memset"}
         stages = {k: {"ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
         dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None

@@ -19,6 +19,7 @@
 #include "himg_dev.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace himg_dev {
 
@@ -1185,7 +1186,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
 
   const int blk = blockIdx.x + first_block, f = blockIdx.y;
   DecFrame *df = ws.frames + f;
-  if (df->status) return;
+  // One read for the whole workgroup (other workgroups flag the frame concurrently;
+  // a per-lane read could let some waves leave ahead of the barriers below).
+  if (threadIdx.x == 0) sh.flag = df->status;
+  __syncthreads();
+  if (sh.flag) return;
   const int strm = blk == 0 ? 0 : 1;
   if (strm == 0 && lres_fallback_only && ws.ver_ok[f]) return;  // parallel LRES path succeeded
   const uint8_t *p = packed + (size_t)f * in_stride;
@@ -1250,7 +1255,7 @@ constexpr int kLresChunkBits = kDecThreads * kLresSubBits;
 // LDS is a tenth of the L2's.
 constexpr int kLresPayWords = kDecThreads * kLresSubBits / 32 + 8;
 constexpr int kLresMemo = kLresMemoWords;   // starts a lane remembers
-template <bool FIX>
+template <bool FIX, bool STAGE>
 __device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p, uint32_t stream_size,
                                 const DecFrame *df, int f, int k, const GrpTables &tb, StreamShared *sh,
                                 uint32_t *s_pay) {
@@ -1262,13 +1267,17 @@ __device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p
   uint64_t *end_out = FIX ? ws.fix_end : ws.spec_end;
   GReader gr;
   const uint32_t rel0 = gr.attach(p, stream_size, 8ull * pay_off + cur);
-  // Bits up to rel0 + chunk + 46 are consumed and the reader runs three dwords ahead:
-  // all inside the staged words, the clamp at jmax is never the stream's data.
-  for (int j = tid; j < kLresPayWords; j += kDecThreads) s_pay[j] = gr.ld((uint32_t)j);
-  __syncthreads();
-  LReader rd;
-  rd.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
-  rd.jmax = kLresPayWords - 1;
+  typename std::conditional<STAGE, LReader, GReader>::type rd;
+  if constexpr (STAGE) {
+    // Bits up to rel0 + chunk + 46 are consumed and the reader runs three dwords ahead:
+    // all inside the staged words, the clamp at jmax is never the stream's data.
+    for (int j = tid; j < kLresPayWords; j += kDecThreads) s_pay[j] = gr.ld((uint32_t)j);
+    __syncthreads();
+    rd.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
+    rd.jmax = kLresPayWords - 1;
+  } else {
+    rd = gr;
+  }
   const unsigned long long rem = P1 - cur;
   const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
   const uint32_t my_b0 = rel0 + tid * kLresSubBits;
@@ -1304,7 +1313,7 @@ __device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p
     }
   }
   const long long c_in = clock64();
-  lean_fixpoint<false, LReader, kLresMemo>(rd, tb, sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX,
+  lean_fixpoint<false, decltype(rd), kLresMemo>(rd, tb, sh, first, active, lim, &start, &endpos, &cnt, &rounds, FIX,
                                            (uint32_t)g.lead_bits, nullptr, nullptr, memo);
   const long long c_fix = clock64() - c_in;
   if (!FIX) {
@@ -1331,13 +1340,14 @@ __device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p
 }
 
 // k_lres_spec: every chunk of every frame, speculatively, in parallel.
+template <bool STAGE>
 __global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, const uint8_t *packed,
                                                            size_t in_stride, const uint32_t *sizes) {
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
   __shared__ uint32_t sub[kSubEntries];
   __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
   __shared__ StreamShared sh;
-  __shared__ uint32_t s_pay[kLresPayWords];
+  __shared__ uint32_t s_pay[STAGE ? kLresPayWords : 1];
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   if (tid == 0) sh.flag = df->status;
@@ -1354,7 +1364,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, con
   __syncthreads();
   GrpTables tb;
   tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
-  lres_chain_body<false>(g, ws, packed + (size_t)f * in_stride, sizes[f], df, f, k, tb, &sh, s_pay);
+  lres_chain_body<false, STAGE>(g, ws, packed + (size_t)f * in_stride, sizes[f], df, f, k, tb, &sh, s_pay);
 }
 
 // k_lres_fix: correction and verification of ALL chunks of a frame by one workgroup.
@@ -1369,6 +1379,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, con
 //      taken from chunk 1's SPECULATIVE end, which is right iff the correction left
 //      that end unchanged -- and so on.  All ends unchanged => every chunk exact
 //      (induction).  Output offsets = scan of the corrected totals.
+template <bool STAGE>
 __global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, const uint8_t *packed,
                                                           size_t in_stride, const uint32_t *sizes) {
   __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
@@ -1377,7 +1388,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, cons
   __shared__ StreamShared sh;
   __shared__ uint8_t s_pending[kDecThreads];
   __shared__ int s_bad;
-  __shared__ uint32_t s_pay[kLresPayWords];
+  __shared__ uint32_t s_pay[STAGE ? kLresPayWords : 1];
   const int f = blockIdx.x, k = threadIdx.x;
   DecFrame *df = ws.frames + f;
   if (k == 0) { ws.ver_ok[f] = 0; ws.lres_endbit[f] = ~0ull; s_bad = 0; sh.flag = df->status; }
@@ -1426,7 +1437,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, cons
   // ---- 2: warm restarts of what is left
   for (int q = 1; q < nact; ++q) {
     if (!s_pending[q]) continue;   // LDS: the same for every lane
-    lres_chain_body<true>(g, ws, p, sizes[f], df, f, q, tb, &sh, s_pay);
+    lres_chain_body<true, STAGE>(g, ws, p, sizes[f], df, f, q, tb, &sh, s_pay);
     __syncthreads();
   }
   // ---- 3: verification and output offsets (other lanes' global writes of this
@@ -1546,7 +1557,8 @@ __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
   const int mu = blockIdx.x * 4 + b, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
   const DecFrame *df = ws.frames + f;
-  if (df->status) return;
+  // A single wavefront: the read is one scalar load, uniform by construction.
+  if (__builtin_amdgcn_readfirstlane(df->status)) return;
   s_lmap[lane] = df->lmap[lane];
   s_lmap[lane + 64] = df->lmap[lane + 64];
   __syncthreads();
@@ -1926,7 +1938,10 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
   __shared__ uint32_t s_shiftp[2][32];
   const int v = blockIdx.y + v0, f = blockIdx.z;
   const DecFrame *df = ws.frames + f;
-  if (df->status) return;
+  __shared__ int s_status;
+  if (threadIdx.x == 0) s_status = df->status;
+  __syncthreads();
+  if (s_status) return;
   {
     const int k = threadIdx.x;
     const int sc = (int8_t)k;
@@ -1972,7 +1987,9 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const int f = blockIdx.y, tid = threadIdx.x;
   const long long c_in = clock64();
   DecFrame *df = ws.frames + f;
-  if (df->status) return;
+  if (tid == 0) sh->flag = df->status;
+  __syncthreads();
+  if (sh->flag) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
   load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
   if (tid < 256) {
@@ -2299,9 +2316,17 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   if (ws.rc_stats) (void)hipMemsetAsync(ws.rc_stats, 0, (size_t)batch * g.rows * 8 * sizeof(uint32_t), stream);
   // k_lres_write stores the non-zero symbols only.
   (void)hipMemsetAsync(ws.lres_sym, 0, (size_t)batch * ws.lres_stride, stream);
-  HIMG_LAUNCH(k_lres_spec, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
-              d_packed, in_stride, d_sizes);
-  HIMG_LAUNCH(k_lres_fix, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
+  static const int lres_stage = getenv("HIMG_LRES_STAGE") ? atoi(getenv("HIMG_LRES_STAGE")) : 3;
+  if (lres_stage & 1)
+    HIMG_LAUNCH(k_lres_spec<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+                d_packed, in_stride, d_sizes);
+  else
+    HIMG_LAUNCH(k_lres_spec<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+                d_packed, in_stride, d_sizes);
+  if (lres_stage & 2)
+    HIMG_LAUNCH(k_lres_fix<true>, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
+  else
+    HIMG_LAUNCH(k_lres_fix<false>, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_write, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws, d_packed,
               in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);

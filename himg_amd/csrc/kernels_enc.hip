@@ -4,9 +4,9 @@
 //   k_lowres_avg      colour lift + 8x8 box average          (ycbcr.cpp:24-52, downsampled.cpp:76-96)
 //   k_lowres_blend    1/16-phase blend -> low-res plane      (downsampled.cpp:98-113)
 //   k_lres_predict    predictor select + delta coding        (downsampled.cpp:177-316)
-//   k_tile_fwd_pk /   lift, low-res removal, WHT, quantize,  (encoder.cpp:258-327, hadamard.cpp:78-88,
+//   k_pix_fwd /       lift, low-res removal, WHT, quantize,  (encoder.cpp:258-327, hadamard.cpp:78-88,
 //   k_tile_fwd        compand, coefficient-major scatter      quantize.cpp:127-151, mapper.cpp:159-182)
-//                     (_pk: full RGBA8 tiles, two channels per register in packed int16)
+//                     (k_pix_fwd: full RGBA8 tiles, two channels per register in packed int16)
 //   k_lres_summary    zero-run summaries of LRES spans
 //   k_tok_hist        RLE tokenise + histogram per span      (huffman_enc.cpp:98-144)
 //   k_tree            Huffman tree, codes, serialised tree   (huffman_enc.cpp:148-238)
@@ -261,7 +261,7 @@ __device__ __forceinline__ void wht8(int &x0, int &x1, int &x2, int &x3, int &x4
 // 64 consecutive symbol bytes (encoder.cpp:320-323 layout).
 //
 // This is the generic kernel (ragged edges, 1-3 channels, pixel stride != 4);
-// full RGBA8 tiles take k_tile_fwd_pk below.  Channels are processed one after
+// full RGBA8 tiles take k_pix_fwd below.  Channels are processed one after
 // the other and the tile's pixels are re-read for each instead of being held in
 // registers, which keeps the register count down.
 // ---------------------------------------------------------------------------
@@ -392,12 +392,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_fwd(Geom g, const uint8_t
 }
 
 // ---------------------------------------------------------------------------
-// k_tile_fwd_pk: the same stage for the BASELINE shape (full tiles, packed
-// RGBA8), two channels per register in packed int16 (v_pk_*_i16).  With 8-bit
-// input the forward path never leaves int16 (|coefficient| <= 255 * 64), so the
-// packed arithmetic is exact.  The WHT and the quantiser run on channel pairs,
-// which halves their instruction count, and the tile is read twice instead of
-// four times.
+// Packed int16 helpers of the pixel stage for full RGBA8 tiles (k_pix_fwd below):
+// two channels per register (v_pk_*_i16).  With 8-bit input the forward path never
+// leaves int16 (|coefficient| <= 255 * 64), so the packed arithmetic is exact.
 // ---------------------------------------------------------------------------
 typedef short pk16 __attribute__((ext_vector_type(2)));
 typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
@@ -412,130 +409,10 @@ __device__ __forceinline__ void wht8_pk(pk16 &x0, pk16 &x1, pk16 &x2, pk16 &x3, 
   x4 = b2 - b3; x5 = b6 - b7; x6 = b4 - b5; x7 = b0 - b1;
 }
 
-// Channels (2 * PAIR, 2 * PAIR + 1) of one pixel, colour lift of ycbcr.cpp:32-37
-// applied on the fly: pair 0 = (Y, Cb), pair 1 = (Cr, alpha).
-template <bool YCBCR, int PAIR>
-__device__ __forceinline__ pk16 pair_value(uint32_t px) {
-  int a, b;
-  if (!YCBCR) {
-    a = (int)((px >> (16 * PAIR)) & 255u);
-    b = (int)((px >> (16 * PAIR + 8)) & 255u);
-  } else {
-    const int c0 = px & 255, c1 = (px >> 8) & 255, c2 = (px >> 16) & 255;
-    if (PAIR == 0) { a = (c0 + 2 * c1 + c2 + 2) >> 2; b = (c2 - c1 + 256) >> 1; }
-    else { a = (c0 - c1 + 256) >> 1; b = (int)(px >> 24); }
-  }
-  pk16 r;
-  r.x = (short)a; r.y = (short)b;
-  return r;
-}
-
-template <bool YCBCR, int PAIR>
-__device__ __forceinline__ void residual_pair(const uint8_t *row0, size_t pitch, const int lA[9],
-                                              const int rA[9], const int lB[9], const int rB[9],
-                                              pk16 b[64]) {
-  // The pixel rows are loaded just in time, two rows ahead at most (the scheduling
-  // barrier keeps the compiler from hoisting all 16 loads to the top): the tile's
-  // 64 pixels never sit in registers at once, which is what decides between two
-  // and three waves per SIMD for this kernel.
-#pragma unroll
-  for (int y = 0; y < 8; ++y) {
-    const uint4 *rp = reinterpret_cast<const uint4 *>(row0 + (size_t)y * pitch);
-    const uint4 q0 = rp[0], q1 = rp[1];
-    int aA[9], aB[9];
-    aA[0] = lA[y]; aA[8] = rA[y];
-    aB[0] = lB[y]; aB[8] = rB[y];
-    interp9(aA);
-    interp9(aB);
-    const uint32_t q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      pk16 lo;
-      lo.x = (short)aA[x]; lo.y = (short)aB[x];
-      b[y * 8 + x] = pair_value<YCBCR, PAIR>(q[x]) - lo;
-    }
-    if (y & 1) __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-template <bool YCBCR, int COLS>
-__global__ __launch_bounds__(kTileThreads, 3) void k_tile_fwd_pk(Geom g, const uint8_t *frames,
-                                                     const uint8_t *low, size_t plane_stride,
-                                                     uint8_t *fres_sym, size_t fres_stride,
-                                                     const uint8_t *__restrict__ fmap_lut,
-                                                     ShiftTables st, int v0) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  const int v = blockIdx.y + v0, f = blockIdx.z;
-  if (u >= g.cols) return;
-  const uint8_t *img = frames + (long long)f * g.frame_bytes;
-  const int u2 = min(u + 1, g.cols - 1), v2 = min(v + 1, g.rows - 1);
-  const int cols = COLS ? COLS : g.cols;
-  uint8_t *dst_row = fres_sym + (size_t)f * fres_stride + (size_t)v * g.row_block + u;
-  const uint8_t *row0 = img + ((long long)(8 * v) * g.W + 8 * u) * 4;
-  const size_t pitch = (size_t)g.W * 4;
-
-#pragma unroll 1
-  for (int pr = 0; pr < 2; ++pr) {
-    // Bilinear low-res blocks of both channels from their four corners
-    // (downsampled.cpp:116-169).
-    const uint8_t *mA = low + (size_t)f * plane_stride + (size_t)(2 * pr) * g.rows * g.cols;
-    const uint8_t *mB = mA + (size_t)g.rows * g.cols;
-    int lA[9], rA[9], lB[9], rB[9];
-    lA[0] = mA[(size_t)v * g.cols + u];  lA[8] = mA[(size_t)v2 * g.cols + u];
-    rA[0] = mA[(size_t)v * g.cols + u2]; rA[8] = mA[(size_t)v2 * g.cols + u2];
-    lB[0] = mB[(size_t)v * g.cols + u];  lB[8] = mB[(size_t)v2 * g.cols + u];
-    rB[0] = mB[(size_t)v * g.cols + u2]; rB[8] = mB[(size_t)v2 * g.cols + u2];
-    interp9(lA); interp9(rA); interp9(lB); interp9(rB);
-
-    pk16 b[64];
-    if (pr == 0) residual_pair<YCBCR, 0>(row0, pitch, lA, rA, lB, rB, b);
-    else residual_pair<YCBCR, 1>(row0, pitch, lA, rA, lB, rB, b);
-
-    // Forward 2-D WHT: rows, then columns (hadamard.cpp:78-88).
-#pragma unroll
-    for (int y = 0; y < 8; ++y)
-      wht8_pk(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
-              b[y * 8 + 6], b[y * 8 + 7]);
-#pragma unroll
-    for (int x = 0; x < 8; ++x)
-      wht8_pk(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
-
-    // Chroma shift table for Cb and Cr only (encoder.cpp:284): pair 0 = (Y, Cb),
-    // pair 1 = (Cr, alpha).
-    const uint8_t *shA = st.s[YCBCR ? pr : 0];
-    const uint8_t *shB = st.s[YCBCR ? 1 - pr : 0];
-    uint8_t *dstA = dst_row + (size_t)(2 * pr) * 64 * cols;
-    uint8_t *dstB = dstA + (size_t)64 * cols;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int pos = kScan[i];
-      const int sA = shA[pos], sB = shB[pos];
-      upk16 sh, rnd;
-      sh.x = (unsigned short)sA; sh.y = (unsigned short)sB;
-      rnd.x = (unsigned short)(sA ? (1 << (sA - 1)) : 0);
-      rnd.y = (unsigned short)(sB ? (1 << (sB - 1)) : 0);
-      const pk16 x = b[pos];
-      // Sign-magnitude rounding shift (quantize.cpp:135-148).
-      const pk16 fifteen = {15, 15};
-      const pk16 sign = x >> fifteen;              // 0 or -1 per half
-      const upk16 mag = __builtin_bit_cast(upk16, (pk16)((x ^ sign) - sign));
-      const upk16 q = (mag + rnd) >> sh;
-      // Companding (mapper.cpp:159-182): the full-res table is the identity up to
-      // 50; larger magnitudes go through the LUT of the restated search.
-      upk16 code = q;
-      if (q.x > 50) code.x = fmap_lut[q.x];
-      if (q.y > 50) code.y = fmap_lut[q.y];
-      const pk16 o = (__builtin_bit_cast(pk16, code) ^ sign) - sign;
-      dstA[(size_t)i * cols] = (uint8_t)o.x;
-      dstB[(size_t)i * cols] = (uint8_t)o.y;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // k_pix_fwd: the pixel stage of the BASELINE shapes (full tiles, packed RGBA8,
 // cols a multiple of 16) in its round-2 form.  Lane = tile, a wavefront = 64
-// adjacent tiles of one block row, like k_tile_fwd_pk, but
+// adjacent tiles of one block row, like k_tile_fwd, but
 //   * the tile's 64 pixels are loaded ONCE (sixteen 16-byte loads) and stay in
 //     registers for both channel pairs -- the kernel runs at two waves per SIMD,
 //     which costs this ALU-dense code a few per cent and saves a second pass
@@ -1804,20 +1681,6 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
 #undef HIMG_PIX
 }
 
-// Full tiles of packed RGBA8: the packed-int16 kernel, block rows [r0, r0 + n).
-static void launch_tile_pk(const Geom &g, const EncWs &ws, const uint8_t *d_frames,
-                           const ShiftTables &st, const uint8_t *d_fmap_lut, int r0, int n, int batch,
-                           hipStream_t stream, Profiler *prof) {
-  const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
-  const dim3 grid(gxt, n, batch), block(kTileThreads);
-#define HIMG_TILE_PK(Y, COLS)                                                                   \
-  HIMG_LAUNCH((k_tile_fwd_pk<Y, COLS>), grid, block, g, d_frames, ws.low, ws.plane_stride,      \
-              ws.fres_sym, ws.fres_stride, d_fmap_lut, st, r0)
-  if (g.ycbcr) { if (g.cols == 512) HIMG_TILE_PK(true, 512); else HIMG_TILE_PK(true, 0); }
-  else { if (g.cols == 512) HIMG_TILE_PK(false, 512); else HIMG_TILE_PK(false, 0); }
-#undef HIMG_TILE_PK
-}
-
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
                    uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,
                    const StaticChunks &sc, const ShiftTables &st, const LresTables &lt,
@@ -1865,8 +1728,6 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   const bool pix = use_pix_path(g);
   if (pix) {
     launch_pix(g, ws, d_frames, st, d_fmap_lut, 0, g.rows, batch, stream, prof);
-  } else if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
-    launch_tile_pk(g, ws, d_frames, st, d_fmap_lut, 0, g.rows, batch, stream, prof);
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
@@ -1889,8 +1750,6 @@ static void launch_tile_rows(const Geom &g, const EncWs &ws, const uint8_t *d_fr
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
   if (use_pix_path(g)) {
     launch_pix(g, ws, d_frame_base, st, d_fmap_lut, r0, n, 1, stream, prof);
-  } else if (g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4) {
-    launch_tile_pk(g, ws, d_frame_base, st, d_fmap_lut, r0, n, 1, stream, prof);
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, n, 1), dim3(kTileThreads), g, d_frame_base,
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, r0);

@@ -26,7 +26,7 @@ def kname(full):
     return n
 
 # Kernels that read their input as 16-byte-per-lane coalesced streams.
-STREAMING = {"k_lowres_avg", "k_tile_fwd_pk", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_m", "k_lres_summary"}
+STREAMING = {"k_lowres_avg", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_m", "k_lres_summary"}
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 dur = collections.defaultdict(lambda: [0.0, 0])
