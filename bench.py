@@ -67,6 +67,8 @@ def parse_args():
                     help="frames: independent frames sharded over ranks (default, the headline "
                          "metric); rows: ONE frame (default 16384x16384, BASELINE config 4) sharded by "
                          "block rows with RCCL all-reduce / all-gather / gather (encode only)")
+    ap.add_argument("--rows-timeout", type=int, default=240,
+                    help="seconds the config-4 rows leg may take before the frames line is printed without it")
     ap.add_argument("--no-rows", action="store_true",
                     help="skip the row-sharded 16384x16384 leg (the `rows` object of the frames line)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -668,7 +670,32 @@ def main():
     if not args.no_rows:
         del d_frames, d_out, d_pix, frames
         torch.cuda.empty_cache()
-        rows_obj = rows_leg(args, rank, local_rank, world, dev, max(5, min(args.steps, 10)), 2)
+        # The frames line must come out whatever happens to the rows leg (its RCCL
+        # exchanges are the only collectives in this program): if the leg raises, or
+        # has not finished within --rows-timeout seconds (a rank stuck in a collective
+        # its peer left), rank 0 prints the line with the reason in "rows" and every
+        # rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["rows"] = {"error": "rows leg did not finish within %d s" % args.rows_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 3)
+
+        dog = threading.Timer(args.rows_timeout + (0 if rank == 0 else 5), give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            rows_obj = rows_leg(args, rank, local_rank, world, dev, max(5, min(args.steps, 10)), 2)
+        except Exception as e:   # noqa: BLE001 -- reported in the line, not swallowed
+            if rank != 0:
+                raise
+            rows_obj = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["rows"] = rows_obj
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog.cancel()
         if rank == 0:
             out["rows"] = rows_obj
     if rank == 0:
