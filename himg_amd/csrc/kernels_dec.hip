@@ -758,7 +758,11 @@ __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t 
       const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
       uint32_t y = SOA ? t.gy[idx] : reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
       uint32_t pre = 0, by;
+#ifdef HIMG_X_NOLONG
+      if (y == 0) y = 11u | (11u << 27);
+#else
       if (__builtin_expect(y == 0, 0)) y = long_token<SOA>(rd, t, idx, &pre, &by, &bad);
+#endif
       const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
       const uint32_t n = y >> 27;
       rd.consume((int)n);
@@ -894,7 +898,11 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
       const uint2 e = t.grp[idx];
       uint32_t y = e.y, by = e.x, pre = 0;
+#ifdef HIMG_X_NOLONG
+      if (y == 0) y = 11u | (11u << 27);
+#else
       if (__builtin_expect(y == 0, 0)) y = long_token<false>(rd, t, idx, &pre, &by, &bad);
+#endif
       const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
       const uint32_t n = y >> 27;
       rd.consume((int)n);

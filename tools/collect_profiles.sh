@@ -1,0 +1,15 @@
+#!/bin/bash
+# Copy what tools/refresh_profiles.sh left under gpurun_out/<dir> into profiles/ under
+# this round's names:  tools/collect_profiles.sh gpurun_out/r02c r02
+set -eu
+SRC=$1
+TAG=$2
+grep '^{' "$SRC/bench.json" | tail -1 > "profiles/${TAG}_bench.json"
+cp "$SRC/cfg3_sweep.json" "profiles/${TAG}_cfg3_sweep.json"
+cp "$SRC/cfg4_rows.json" "profiles/${TAG}_cfg4_rows.json"
+cp "$SRC/latency.json" "profiles/${TAG}_latency.json"
+cp "$SRC"/stats_default/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_default.csv"
+cp "$SRC"/stats_streams1/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_streams1.csv"
+cp "$SRC/pmc/summary.json" "profiles/${TAG}_pmc_summary.json"
+cp "$SRC/traffic.json" profiles/traffic.json
+ls -la profiles/${TAG}_* profiles/traffic.json

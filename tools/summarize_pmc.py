@@ -28,20 +28,40 @@ def kname(full):
 # Kernels that read their input as 16-byte-per-lane coalesced streams.
 STREAMING = {"k_lowres_avg", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_m", "k_lres_summary"}
 
+# A kernel launched with several grid sizes per step (k_tok_hist: the LRES spans on the
+# side stream, then the FRES rows) is reported per grid: the largest under the kernel's
+# name, the others as "name[grid N]" -- a mean over both would halve every per-launch
+# figure of the launch that matters.
+def grid_of(r):
+    if "Grid_Size" in r:
+        return int(r["Grid_Size"])
+    return int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1))
+
+
+rows_c, rows_t = [], []
+for path in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+    rows_c += [(kname(r["Kernel_Name"]), grid_of(r), r) for r in csv.DictReader(open(path))]
+for path in glob.glob(os.path.join(root, "*", "*", "*kernel_trace.csv")):
+    rows_t += [(kname(r["Kernel_Name"]), grid_of(r), r) for r in csv.DictReader(open(path))]
+gmax = collections.defaultdict(int)
+for k, g, _ in rows_c + rows_t:
+    gmax[k] = max(gmax[k], g)
+
+
+def key(k, g):
+    return k if g == gmax[k] else "%s[grid %d]" % (k, g)
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 dur = collections.defaultdict(lambda: [0.0, 0])
-for path in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
-    for r in csv.DictReader(open(path)):
-        k = kname(r["Kernel_Name"])
-        a = acc[k][r["Counter_Name"]]
-        a[0] += float(r["Counter_Value"])
-        a[1] += 1
-for path in glob.glob(os.path.join(root, "*", "*", "*kernel_trace.csv")):
-    for r in csv.DictReader(open(path)):
-        k = kname(r["Kernel_Name"])
-        d = dur[k]
-        d[0] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
-        d[1] += 1
+for k, g, r in rows_c:
+    a = acc[key(k, g)][r["Counter_Name"]]
+    a[0] += float(r["Counter_Value"])
+    a[1] += 1
+for k, g, r in rows_t:
+    d = dur[key(k, g)]
+    d[0] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+    d[1] += 1
 out = {}
 for k in sorted(acc, key=lambda k: -dur[k][0]):
     if not k.startswith("k_"):
@@ -57,7 +77,7 @@ for k in sorted(acc, key=lambda k: -dur[k][0]):
         raw = row["FETCH_SIZE"] * 1024 / 1e6
         row["hbm_read_MB_raw"] = raw
         row["hbm_read_MB_x2"] = 2 * raw
-        row["hbm_read_MB_corrected"] = 2 * raw if k.split("<")[0] in STREAMING else raw
+        row["hbm_read_MB_corrected"] = 2 * raw if k.split("<")[0].split("[")[0] in STREAMING else raw
     if "WRITE_SIZE" in row:
         row["hbm_write_MB"] = row["WRITE_SIZE"] * 1024 / 1e6
     out[k] = row
