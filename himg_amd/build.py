@@ -56,6 +56,7 @@ def build_lib(force=False, verbose=False):
             else:
                 cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
                        "-Wno-unused-value", "-c", s, "-o", o] + inc
+                cmd += os.environ.get("HIMG_EXTRA_HIPCC_FLAGS", "").split()   # experiments (-D...)
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

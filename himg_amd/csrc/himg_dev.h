@@ -101,7 +101,7 @@ struct DecWs {
   int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
   uint2 *grp;                // [f][2][1<<kLutBits] group table (kernels_dec.hip GrpTables)
   uint32_t *gyc;             // [f][2][1<<kLutBits] step words of the count-only groups (no four-byte limit)
-  uint32_t *sub;             // [f][2][kSubEntries] second-level entries for codes longer than kLutBits
+  uint2 *sub;                // [f][2][kSubEntries] second-level entries for codes longer than kLutBits (.x byte / node, .y step word)
   uint32_t *row_off;         // [f][rows] payload byte offset of each FRES row
   uint32_t *row_len;         // [f][rows]
   uint8_t *lres_sym;         size_t lres_stride;

@@ -444,7 +444,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
       !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 3 * 4) ||
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_gyc.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
-      !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 4) ||
+      !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 8) ||
       !ctx->d_lane.reserve((size_t)batch * g.rows * (2 * kDecThreads + 4) * 4) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
@@ -455,7 +455,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.nodes = (int32_t *)ctx->d_nodes.p;
   w.grp = (uint2 *)ctx->d_grp.p;
   w.gyc = (uint32_t *)ctx->d_gyc.p;
-  w.sub = (uint32_t *)ctx->d_sub.p;
+  w.sub = (uint2 *)ctx->d_sub.p;
   w.lane_start = (uint32_t *)ctx->d_lane.p;
   w.lane_off = w.lane_start + (size_t)batch * g.rows * kDecThreads;
   w.row_off = (uint32_t *)ctx->d_rows.p;

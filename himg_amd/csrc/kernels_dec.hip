@@ -405,8 +405,24 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
       }
     }
     __syncthreads();
-    uint32_t *sub = ws.sub + ((size_t)f * 2 + s) * kSubEntries;
-    for (int k = lane; k < kSubEntries; k += kParseThreads) sub[k] = s_sub[s][k];
+    // Out in the decoder's entry form: .x the literal byte, .y the step word of the ONE
+    // token (code bits = what is left of the code after the kLutBits-bit prefix); a node
+    // reference as .x = node | depth << 16, .y = 0 (also "nothing there": 0, 0).
+    uint2 *sub = ws.sub + ((size_t)f * 2 + s) * kSubEntries;
+    for (int k = lane; k < kSubEntries; k += kParseThreads) {
+      const uint32_t e = s_sub[s][k];
+      uint2 o;
+      if (e & 31u) {
+        const uint32_t rest = e & 31u, eb = (e >> 5) & 31u, cb = (e >> 10) & 511u;
+        const uint32_t cls = eb == 0 ? (cb == 2 ? 1u : 0u) : (eb == 2 ? 2u : eb == 4 ? 3u : eb == 8 ? 4u : 5u);
+        o.x = (e >> 19) & 255u;
+        o.y = grp_y(rest, eb, cb, rest, cls);
+      } else {
+        o.x = (e >> 20) | (((e >> 10) & 63u) << 16);
+        o.y = 0;
+      }
+      sub[k] = o;
+    }
   }
   const long long c_sub = clock64();
   for (int s = 0; s < 2; ++s) {
@@ -569,13 +585,42 @@ constexpr uint32_t kPayPad = 4;         // dwords past the payload the reader ma
 constexpr uint32_t kJoinBits = 64;     // a moved lane re-joins its earlier decode this far past its nominal start
 
 struct GrpTables {
-  const uint2 *grp;           // LDS, 1 << kLutBits entries
-  const uint32_t *gx, *gy;    // the same table as two arrays (count-only kernels: the hot
-                              // read is .y alone, and a stride-2 dword read of the
+  const uint2 *grp;           // LDS: 1 << kLutBits first-level entries, then kSubEntries
+                              // second-level entries (.x bytes / descriptor, .y step word)
+  const uint32_t *gx, *gy;    // the same two tables as two arrays, each (1 << kLutBits) +
+                              // kSubEntries long, gx right behind gy (count-only kernels:
+                              // the hot read is .y alone, and a stride-2 dword read of the
                               // interleaved table uses every other LDS bank only)
-  const uint32_t *sub;        // LDS, second-level entries (codes longer than kLutBits)
-  const short *ca, *cb, *sy;  // LDS tree nodes
+  const uint32_t *nd;         // LDS tree nodes: child a | child b << 10 | (symbol + 1) << 20
 };
+constexpr int kTabEntries = (1 << kLutBits) + kSubEntries;
+
+// The decode tables of one stream as they sit in LDS (interleaved form).
+struct __attribute__((aligned(16))) LdsTables {
+  uint2 grp[kTabEntries];
+  uint32_t nd[kMaxNodes + 1];
+};
+__device__ __forceinline__ GrpTables tables_of(const LdsTables *T) {
+  GrpTables t;
+  t.grp = T->grp; t.gx = nullptr; t.gy = nullptr; t.nd = T->nd;
+  return t;
+}
+__device__ __forceinline__ uint32_t pack_node(int a, int b, int sym) {
+  return ((uint32_t)a & 1023u) | (((uint32_t)b & 1023u) << 10) | ((uint32_t)(sym + 1) << 20);
+}
+
+// LDS byte address of a pointer into LDS, and loads through such an address (the
+// hot loops keep "which table, how many index bits" as an address and a mask).
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t a) { return *(lds_u32p)(uintptr_t)a; }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 lds_ld64(uint32_t a) {
+  const u32x2 v = *(const __attribute__((address_space(3))) u32x2 *)(uintptr_t)a;
+  return make_uint2(v.x, v.y);
+}
 
 // Exclusive scan of a 64-bit value over the 1024-thread workgroup.
 __device__ __forceinline__ unsigned long long block_scan_u64(unsigned long long v,
@@ -654,6 +699,25 @@ struct ReaderT {
 typedef ReaderT<const uint32_t *> GReader;                                        // payload in place (L2)
 typedef ReaderT<const __attribute__((address_space(3))) uint32_t *> LReader;      // payload staged in LDS
 
+// Words [0, n) of a global reader's window -> LDS (dst 16-byte aligned, room for n
+// rounded up to 4): four words per lane and step with ONE 16-byte load (the stream is
+// only dword aligned; global memory takes that), so a 33 KiB row is three loads per
+// lane in flight instead of nine one after the other.  Words past the stream's last
+// dword repeat it, exactly like ReaderT::ld, and nothing past it is read.
+struct __attribute__((packed, aligned(4))) PackedU4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ void stage_payload(const GReader &rd, uint32_t *dst, uint32_t n) {
+  for (uint32_t k = threadIdx.x; 4u * k < n; k += kDecThreads) {
+    uint4 v;
+    if (4u * k + 3u <= rd.jmax) {
+      const PackedU4 q = *reinterpret_cast<const PackedU4 *>(rd.w + 4u * k);
+      v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+    } else {
+      v.x = rd.ld(4u * k); v.y = rd.ld(4u * k + 1u); v.z = rd.ld(4u * k + 2u); v.w = rd.ld(4u * k + 3u);
+    }
+    *reinterpret_cast<uint4 *>(dst + 4u * k) = v;
+  }
+}
+
 // Extra bits and run base per token class (huffman_common.h:24-28).
 __device__ __forceinline__ uint32_t class_eb(uint32_t c) { return (0xE84200u >> (4u * c)) & 15u; }
 __device__ __forceinline__ uint32_t class_base(uint32_t c) {
@@ -668,49 +732,62 @@ __device__ __forceinline__ uint32_t first_token_word(uint32_t y) {
   return tb | (eb << 5) | (class_base(c) << 10) | ((tb + eb) << 27);
 }
 
-// A token whose code is longer than the first-level table (huffman_dec.cpp:291-328):
-// out of line of the hot loops, it resolves ONE token -- second-level table, the
-// tree below it for whatever is deeper still --, consumes the code bits and returns
-// a step word whose code-bit count is 0 (only the extra bits are left to take).
-// *pre = code bits consumed, *byte = the literal (0 for runs).  bad is set (never
+// The tree walk for whatever neither table resolves (huffman_dec.cpp:291-328): from
+// the node and depth in x (node | depth << 16; 0: nothing there), `base` code bits of
+// the token already consumed from the window.  Consumes the rest of the code, returns
+// a step word whose code-bit count is 0 (only the extra bits are left to take);
+// *len_out = the code's length, *byte = the literal (0 for runs).  bad is set (never
 // cleared) on symbols the reference rejects (huffman_dec.cpp:349-352).
-template <bool SOA, class RD>
-__device__ __forceinline__ uint32_t long_token(RD &rd, const GrpTables &t, uint32_t idx, uint32_t *pre,
-                                            uint32_t *byte, bool *bad) {
-  const uint32_t ex = SOA ? t.gx[idx] : t.grp[idx].x;
-  int node = (int)(ex & 0xffffu), len = (int)((ex >> 16) & 0x7fffu), base = 0;
-  if (ex >> 31) {
-    rd.consume(kLutBits);
-    rd.refill();
-    base = kLutBits;
-    const uint32_t e2 = t.sub[((ex >> 8) & 0xffffu) + __builtin_amdgcn_ubfe((uint32_t)rd.win, 0, ex & 255u)];
-    if (e2 & 31u) {   // resolved: the common case by far
-      const uint32_t rest = e2 & 31u, eb = (e2 >> 5) & 31u;
-      rd.consume((int)rest);
-      rd.refill();
-      *pre = kLutBits + rest;
-      *byte = (e2 >> 19) & 255u;
-      return (e2 & 0x0007ffe0u) | (eb << 27);
-    }
-    node = (int)(e2 >> 20);
-    len = (int)((e2 >> 10) & 63u);
-    if (e2 == 0) len = 0;   // nothing there: flagged below
-  }
-  while (len >= base && t.sy[node] < 0 && len < kMaxDepth) {
-    node = ((rd.win >> (len - base)) & 1ull) ? t.cb[node] : t.ca[node];
+template <class RD>
+__device__ __forceinline__ uint32_t walk_token(RD &rd, const GrpTables &t, uint32_t x, int base,
+                                               uint32_t *len_out, uint32_t *byte, bool *bad) {
+  int node = (int)(x & 0xffffu), len = (int)((x >> 16) & 0x7fffu);
+  uint32_t nd = t.nd[node];
+  while (len >= base && (nd >> 20) == 0 && len < kMaxDepth) {
+    node = (int)(((rd.win >> (len - base)) & 1ull) ? (nd >> 10) & 1023u : nd & 1023u);
+    nd = t.nd[node];
     ++len;
   }
-  const int sym = t.sy[node];
+  const int sym = (int)(nd >> 20) - 1;
   const bool ok = sym >= 0 && sym <= 260 && len > base;
   if (!ok) *bad = true;
   if (len <= base) len = base + 1;  // keep moving on a degenerate tree
   rd.consume(len - base);
   rd.refill();
-  *pre = (uint32_t)len;
+  *len_out = (uint32_t)len;
   const uint32_t c = !ok ? 0u : (sym < 256 ? 0u : (uint32_t)sym - 255u);
   const uint32_t eb = class_eb(c);
   *byte = (ok && sym < 256) ? (uint32_t)sym : 0u;
   return (eb << 5) | ((ok ? class_base(c) : 0u) << 10) | (eb << 27);
+}
+
+// A token whose code is longer than the first-level table, resolved in ONE call (the
+// tails and the exact paths; the hot loops spread it over two steps instead, see
+// lean_count): second-level table, the tree below it for whatever is deeper still.
+// Consumes the code bits and returns a step word whose code-bit count is 0.
+// *pre = code bits consumed, *byte = the literal (0 for runs).
+template <bool SOA, class RD>
+__device__ __forceinline__ uint32_t long_token(RD &rd, const GrpTables &t, uint32_t idx, uint32_t *pre,
+                                            uint32_t *byte, bool *bad) {
+  uint32_t x = SOA ? t.gx[idx] : t.grp[idx].x;
+  int base = 0;
+  if (x >> 31) {
+    rd.consume(kLutBits);
+    rd.refill();
+    base = kLutBits;
+    const uint32_t j = (1u << kLutBits) + ((x >> 8) & 0xffffu) + __builtin_amdgcn_ubfe((uint32_t)rd.win, 0, x & 255u);
+    const uint32_t y2 = SOA ? t.gy[j] : t.grp[j].y;
+    x = SOA ? t.gx[j] : t.grp[j].x;
+    if (y2) {   // resolved: the common case by far
+      const uint32_t rest = y2 & 31u, eb = (y2 >> 5) & 31u;
+      rd.consume((int)rest);
+      rd.refill();
+      *pre = kLutBits + rest;
+      *byte = x;
+      return (y2 & 0x0007ffe0u) | (eb << 27);
+    }
+  }
+  return walk_token(rd, t, x, base, pre, byte, bad);
 }
 
 // One decode step in its general form (the tails and the exact paths; the hot
@@ -753,22 +830,44 @@ __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t 
     if (!cont) rd.init(pos);
     const int limk = (int)lim - kLutBits;
     bool bad = false;
-    while ((int)pos <= limk) {
+    // The table a step indexes is lane state (tm: index mask, tb: LDS address, both in
+    // bytes): a code longer than the first-level table is NOT resolved on the spot --
+    // that was a 40-instruction detour with two dependent LDS reads which the whole
+    // wavefront waited for whenever one of its 64 lanes met such a code (57 % of the
+    // steps) -- but taken as a step that consumes the kLutBits known bits, produces
+    // nothing and points the lane's NEXT step at the code's second-level table.
+    constexpr int SH = SOA ? 2 : 3;
+    const uint32_t TM = ((1u << kLutBits) - 1u) << SH;
+    const uint32_t TB = SOA ? lds_addr(t.gy) : lds_addr(t.grp) + 4u;   // the .y words
+    const uint32_t XOFF = SOA ? (uint32_t)kTabEntries * 4u : 0xfffffffcu;   // from .y to its .x
+    uint32_t tm = TM, tb = TB;
+    auto step = [&]() {
       rd.refill();
-      const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
-      uint32_t y = SOA ? t.gy[idx] : reinterpret_cast<const uint32_t *>(t.grp)[2 * idx + 1];
-      uint32_t pre = 0, by;
-#ifdef HIMG_X_NOLONG
-      if (y == 0) y = 11u | (11u << 27);
-#else
-      if (__builtin_expect(y == 0, 0)) y = long_token<SOA>(rd, t, idx, &pre, &by, &bad);
-#endif
+      const uint32_t a = ((((uint32_t)rd.win) << SH) & tm) + tb;
+      uint32_t y = lds_ld32(a);
+      uint32_t ntm = TM, ntb = TB, adv = 0;
+      if (__builtin_expect(y == 0, 0)) {
+        const uint32_t x = lds_ld32(a + XOFF);
+        if ((x >> 31) && tm == TM) {
+          ntm = ((1u << (x & 255u)) - 1u) << SH;
+          ntb = TB + (((1u << kLutBits) + ((x >> 8) & 0xffffu)) << SH);
+          y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
+        } else {
+          const int base = tm == TM ? 0 : kLutBits;
+          uint32_t len, by;
+          y = walk_token(rd, t, x, base, &len, &by, &bad);
+          adv = len - (uint32_t)base;
+        }
+      }
+      tm = ntm; tb = ntb;
       const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
       const uint32_t n = y >> 27;
       rd.consume((int)n);
-      pos += pre + n;
+      pos += adv + n;
       c += ((y >> 10) & 511u) + extra;
-    }
+    };
+    while ((int)pos <= limk) step();
+    if (tm != TM) step();   // the loop ended between the two steps of a long code
     while (pos < lim) {
       uint32_t nbits, cnt, by;
       lean_step<false, SOA>(rd, t, true, &nbits, &cnt, &by, &bad);
@@ -893,16 +992,27 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
     rd.init(bp);
     const int limk = (int)lim - kLutBits;
     uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
-    while ((int)bp <= limk) {
+    // Long codes: two steps, the table being lane state (see lean_count).
+    const uint32_t TM = ((1u << kLutBits) - 1u) << 3, TB = lds_addr(t.grp);
+    uint32_t tm = TM, tb = TB;
+    auto step = [&]() {
       rd.refill();
-      const uint32_t idx = (uint32_t)rd.win & ((1u << kLutBits) - 1u);
-      const uint2 e = t.grp[idx];
-      uint32_t y = e.y, by = e.x, pre = 0;
-#ifdef HIMG_X_NOLONG
-      if (y == 0) y = 11u | (11u << 27);
-#else
-      if (__builtin_expect(y == 0, 0)) y = long_token<false>(rd, t, idx, &pre, &by, &bad);
-#endif
+      const uint2 e = lds_ld64(((((uint32_t)rd.win) << 3) & tm) + tb);
+      uint32_t y = e.y, by = e.x, ntm = TM, ntb = TB, adv = 0;
+      if (__builtin_expect(y == 0, 0)) {
+        if ((by >> 31) && tm == TM) {
+          ntm = ((1u << (by & 255u)) - 1u) << 3;
+          ntb = TB + (((1u << kLutBits) + ((by >> 8) & 0xffffu)) << 3);
+          y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
+          by = 0;
+        } else {
+          const int base = tm == TM ? 0 : kLutBits;
+          uint32_t len;
+          y = walk_token(rd, t, by, base, &len, &by, &bad);
+          adv = len - (uint32_t)base;
+        }
+      }
+      tm = ntm; tb = ntb;
       const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
       const uint32_t n = y >> 27;
       rd.consume((int)n);
@@ -910,8 +1020,10 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       atomicOr(&o32[op >> 2], (uint32_t)v);
       atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
       op += ((y >> 10) & 511u) + extra;
-      bp += pre + n;
-    }
+      bp += adv + n;
+    };
+    while ((int)bp <= limk) step();
+    if (tm != TM) step();
     while (bp < lim) {
       uint32_t nbits, cnt, by;
       lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
@@ -1062,7 +1174,7 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
 // GLOBAL (with FUSED false): the output goes straight to `gout`, PRE-ZEROED global
 // memory, without the LDS window (win may be nullptr) -- the LRES serial fallback.
 template <bool FUSED, bool GLOBAL = false>
-__device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
+__device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
                              uint32_t *stats, uint32_t max_sub, uint32_t lead_bits,
@@ -1161,20 +1273,19 @@ __device__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pa
   return bad;
 }
 
-// Tree nodes and group table of stream `strm` of frame f -> LDS.
+// Tree nodes and decode tables of stream `strm` of frame f -> LDS.
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
-                                                uint2 *grp, uint32_t *sub, short *ca, short *cb,
-                                                short *sy) {
+                                                LdsTables *T) {
   const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
   const int nn = df->s[strm].num_nodes;
-  for (int k = threadIdx.x; k < nn; k += kDecThreads) {
-    ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
-  }
+  for (int k = threadIdx.x; k < nn; k += kDecThreads)
+    T->nd[k] = pack_node(nodes[3 * k + 0], nodes[3 * k + 1], nodes[3 * k + 2]);
   const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + strm) * (1u << kLutBits));
   for (int k = threadIdx.x; k < (1 << kLutBits) / 2; k += kDecThreads)
-    reinterpret_cast<uint4 *>(grp)[k] = gg[k];
-  const uint32_t *gs = ws.sub + ((size_t)f * 2 + strm) * kSubEntries;
-  for (int k = threadIdx.x; k < kSubEntries; k += kDecThreads) sub[k] = gs[k];
+    reinterpret_cast<uint4 *>(T->grp)[k] = gg[k];
+  const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + strm) * kSubEntries);
+  for (int k = threadIdx.x; k < kSubEntries / 2; k += kDecThreads)
+    reinterpret_cast<uint4 *>(T->grp + (1 << kLutBits))[k] = gs[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -1187,9 +1298,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
                                                           int first_block, int lres_fallback_only,
                                                           int use_row_count) {
   __shared__ uint32_t win[kWinBytes / 4 + 1];
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ LdsTables T;
   __shared__ StreamShared sh;
 
   const int blk = blockIdx.x + first_block, f = blockIdx.y;
@@ -1223,10 +1332,9 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
       if (use_row_count == 2 && pre_off[kDecThreads + 2] != 0) return;
     }
   }
-  load_dec_tables(ws, df, f, strm, grp, sub, ca, cb, sy);
+  load_dec_tables(ws, df, f, strm, &T);
   __syncthreads();
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const GrpTables tb = tables_of(&T);
   const int bad = decode_stream<false>(p, sizes[f], pay_off, pay_len, out_size, tb, &sh, nullptr, win,
                                        out, ws.stats + ((size_t)f * (g.rows + 1) + blk) * 8,
                                        (uint32_t)g.max_sub, (uint32_t)g.lead_bits, pre_start, pre_off);
@@ -1264,7 +1372,7 @@ constexpr int kLresChunkBits = kDecThreads * kLresSubBits;
 constexpr int kLresPayWords = kDecThreads * kLresSubBits / 32 + 8;
 constexpr int kLresMemo = kLresMemoWords;   // starts a lane remembers
 template <bool FIX, bool STAGE>
-__device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p, uint32_t stream_size,
+__device__ __forceinline__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p, uint32_t stream_size,
                                 const DecFrame *df, int f, int k, const GrpTables &tb, StreamShared *sh,
                                 uint32_t *s_pay) {
   const int tid = threadIdx.x;
@@ -1279,7 +1387,7 @@ __device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p
   if constexpr (STAGE) {
     // Bits up to rel0 + chunk + 46 are consumed and the reader runs three dwords ahead:
     // all inside the staged words, the clamp at jmax is never the stream's data.
-    for (int j = tid; j < kLresPayWords; j += kDecThreads) s_pay[j] = gr.ld((uint32_t)j);
+    stage_payload(gr, s_pay, (uint32_t)kLresPayWords);
     __syncthreads();
     rd.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
     rd.jmax = kLresPayWords - 1;
@@ -1351,11 +1459,9 @@ __device__ void lres_chain_body(const Geom &g, const DecWs &ws, const uint8_t *p
 template <bool STAGE>
 __global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, const uint8_t *packed,
                                                            size_t in_stride, const uint32_t *sizes) {
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ LdsTables T;
   __shared__ StreamShared sh;
-  __shared__ uint32_t s_pay[STAGE ? kLresPayWords : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pay[STAGE ? kLresPayWords : 4];
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   if (tid == 0) sh.flag = df->status;
@@ -1368,10 +1474,9 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, con
     if (tid == 0) { ws.spec_end[slot] = cur; ws.spec_tot[slot] = 0; }
     return;
   }
-  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, &T);
   __syncthreads();
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const GrpTables tb = tables_of(&T);
   lres_chain_body<false, STAGE>(g, ws, packed + (size_t)f * in_stride, sizes[f], df, f, k, tb, &sh, s_pay);
 }
 
@@ -1390,13 +1495,11 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_spec(Geom g, DecWs ws, con
 template <bool STAGE>
 __global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, const uint8_t *packed,
                                                           size_t in_stride, const uint32_t *sizes) {
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ LdsTables T;
   __shared__ StreamShared sh;
   __shared__ uint8_t s_pending[kDecThreads];
   __shared__ int s_bad;
-  __shared__ uint32_t s_pay[STAGE ? kLresPayWords : 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pay[STAGE ? kLresPayWords : 4];
   const int f = blockIdx.x, k = threadIdx.x;
   DecFrame *df = ws.frames + f;
   if (k == 0) { ws.ver_ok[f] = 0; ws.lres_endbit[f] = ~0ull; s_bad = 0; sh.flag = df->status; }
@@ -1407,10 +1510,9 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, cons
   const unsigned long long P1 = 8ull * (df->s[0].chunk_end - pay_off);
   const int nact = (int)((P1 + kLresChunkBits - 1) / kLresChunkBits);
   if (nact > ws.lres_chunks || nact > kDecThreads) return;  // ver_ok stays 0 -> serial path
-  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, &T);
   __syncthreads();
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const GrpTables tb = tables_of(&T);
   const uint8_t *p = packed + (size_t)f * in_stride;
   const size_t slot = (size_t)f * ws.lres_chunks + k;
   const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
@@ -1468,9 +1570,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_fix(Geom g, DecWs ws, cons
 
 __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, const uint8_t *packed,
                                                             size_t in_stride, const uint32_t *sizes) {
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ LdsTables T;
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
@@ -1483,10 +1583,9 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
     // the test knob): this frame's LRES stream is decoded by ONE workgroup, chunk
     // after chunk, every chunk starting at the exact end of the one before.
     if (k != 0) return;
-    load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+    load_dec_tables(ws, df, f, 0, &T);
     __syncthreads();
-    GrpTables tb0;
-    tb0.grp = grp; tb0.gx = nullptr; tb0.gy = nullptr; tb0.sub = sub; tb0.ca = ca; tb0.cb = cb; tb0.sy = sy;
+    const GrpTables tb0 = tables_of(&T);
     const uint32_t po = df->s[0].payload_off;
     const int bad = decode_stream<false, true>(packed + (size_t)f * in_stride, sizes[f], po, df->s[0].chunk_end - po,
                                                (uint32_t)g.lres_size, tb0, &sh, nullptr, nullptr,
@@ -1504,10 +1603,9 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const size_t slot = (size_t)f * ws.lres_chunks + k;
   const unsigned long long O0 = ws.ver_base[slot];
   if (O0 >= out_size) return;
-  load_dec_tables(ws, df, f, 0, grp, sub, ca, cb, sy);
+  load_dec_tables(ws, df, f, 0, &T);
   if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const GrpTables tb = tables_of(&T);
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off + cur);
   const unsigned long long rem = P1 - cur;
@@ -1626,18 +1724,14 @@ __device__ __forceinline__ void iwht8(int &x0, int &x1, int &x2, int &x3, int &x
 // The symbols never touch HBM: traffic is the packed row in, the pixels out.
 // ---------------------------------------------------------------------------
 struct FusedLayout {
-  uint32_t sym, grp, sub, ca, cb, sy, sh, unmap, shift, shiftp, total;
+  uint32_t sym, tab, sh, unmap, shift, shiftp, total;
 };
 __host__ __device__ inline FusedLayout fused_layout(int row_block) {
   FusedLayout L;
   uint32_t o = 0;
   auto carve = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
-  L.grp = carve((1u << kLutBits) * 8u);   // at offset 0: the hot loop indexes it
-  L.sub = carve(kSubEntries * 4u);
+  L.tab = carve((uint32_t)sizeof(LdsTables));   // at offset 0: the hot loop indexes it
   L.sym = carve((uint32_t)row_block);
-  L.ca = carve((kMaxNodes + 1) * 2u);
-  L.cb = carve((kMaxNodes + 1) * 2u);
-  L.sy = carve((kMaxNodes + 1) * 2u);
   L.sh = carve((uint32_t)sizeof(StreamShared));
   L.unmap = carve(512u);
   L.shift = carve(128u);
@@ -1982,11 +2076,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const FusedLayout L = fused_layout(g.row_block);
   uint8_t *sym = smem + L.sym;
-  uint2 *grp = reinterpret_cast<uint2 *>(smem + L.grp);
-  uint32_t *sub = reinterpret_cast<uint32_t *>(smem + L.sub);
-  short *ca = reinterpret_cast<short *>(smem + L.ca);
-  short *cb = reinterpret_cast<short *>(smem + L.cb);
-  short *sy = reinterpret_cast<short *>(smem + L.sy);
+  LdsTables &T = *reinterpret_cast<LdsTables *>(smem + L.tab);
   StreamShared *sh = reinterpret_cast<StreamShared *>(smem + L.sh);
   int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
   uint8_t *s_shift = smem + L.shift;
@@ -1999,7 +2089,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   __syncthreads();
   if (sh->flag) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
+  load_dec_tables(ws, df, f, 1, &T);
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -2010,8 +2100,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
     s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
   }
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  const GrpTables tb = tables_of(&T);
   const int r = r0 + (int)blockIdx.x;
   {
     uint4 z;
@@ -2145,10 +2234,11 @@ template <bool LDSPAY>
 __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, const uint8_t *packed,
                                                            size_t in_stride, const uint32_t *sizes,
                                                            int r0, int r1, int rows_per_wg) {
-  __shared__ __attribute__((aligned(16))) uint32_t gx[1 << kLutBits], gy[1 << kLutBits];
-  __shared__ uint32_t s_pay[LDSPAY ? kPayWords : 1];   // the row's payload
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  // Both tables as two arrays: the step words (gy), then their .x words (gx).
+  __shared__ __attribute__((aligned(16))) uint32_t gyx[2 * kTabEntries];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pay[LDSPAY ? kPayWords : 4];   // the row's payload
+  __shared__ uint32_t nd[kMaxNodes + 1];
+  uint32_t *gy = gyx, *gx = gyx + kTabEntries;
   __shared__ uint32_t sm32[kDecThreads / 64];
   __shared__ StreamShared sh;
   const int f = blockIdx.y, tid = threadIdx.x;
@@ -2161,9 +2251,8 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
   if (!failed) {   // load_dec_tables with the count-only step words next to the long-code descriptors
     const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
     const int nn = df->s[1].num_nodes;
-    for (int k = tid; k < nn; k += kDecThreads) {
-      ca[k] = (short)nodes[3 * k + 0]; cb[k] = (short)nodes[3 * k + 1]; sy[k] = (short)nodes[3 * k + 2];
-    }
+    for (int k = tid; k < nn; k += kDecThreads)
+      nd[k] = pack_node(nodes[3 * k + 0], nodes[3 * k + 1], nodes[3 * k + 2]);
     const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
     const uint2 *gc = reinterpret_cast<const uint2 *>(ws.gyc + ((size_t)f * 2 + 1) * (1u << kLutBits));
     for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
@@ -2171,11 +2260,15 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
       reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);   // long-code descriptors
       reinterpret_cast<uint2 *>(gy)[k] = gc[k];                  // count-only step words
     }
-    const uint32_t *gs = ws.sub + ((size_t)f * 2 + 1) * kSubEntries;
-    for (int k = tid; k < kSubEntries; k += kDecThreads) sub[k] = gs[k];
+    const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
+    for (int k = tid; k < kSubEntries / 2; k += kDecThreads) {
+      const uint4 q = gs[k];
+      reinterpret_cast<uint2 *>(gx + (1 << kLutBits))[k] = make_uint2(q.x, q.z);
+      reinterpret_cast<uint2 *>(gy + (1 << kLutBits))[k] = make_uint2(q.y, q.w);
+    }
   }
   GrpTables tb;
-  tb.grp = nullptr; tb.gx = gx; tb.gy = gy; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  tb.grp = nullptr; tb.gx = gx; tb.gy = gy; tb.nd = nd;
   const uint8_t *p = packed + (size_t)f * in_stride;
   const int rb = r0 + (int)blockIdx.x * rows_per_wg;
   for (int r = rb; r < min(rb + rows_per_wg, r1); ++r) {
@@ -2199,7 +2292,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
       // several chunks.
       if (nd + kPayPad > (uint32_t)kPayWords) continue;
       __syncthreads();   // the previous row's readers are done with s_pay (and the tables are in)
-      for (uint32_t k = tid; k < nd + kPayPad; k += kDecThreads) s_pay[k] = rd.ld(k);
+      stage_payload(rd, s_pay, nd + kPayPad);
       __syncthreads();
       LReader lr;
       lr.w = (const __attribute__((address_space(3))) uint32_t *)s_pay;
@@ -2223,9 +2316,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, const uint8_t *packed,
                                                              size_t in_stride, const uint32_t *sizes, int r0) {
-  __shared__ __attribute__((aligned(16))) uint2 grp[1 << kLutBits];
-  __shared__ uint32_t sub[kSubEntries];
-  __shared__ short ca[kMaxNodes + 1], cb[kMaxNodes + 1], sy[kMaxNodes + 1];
+  __shared__ LdsTables T;
   __shared__ StreamShared sh;
   const int r = r0 + (int)blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
@@ -2234,9 +2325,8 @@ __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, c
   if (tid == 0) { sh.flag = (df->status || pre_off[kDecThreads + 2] == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
   __syncthreads();
   if (sh.flag) return;   // frame failed, or the row is k_dec_huff's
-  load_dec_tables(ws, df, f, 1, grp, sub, ca, cb, sy);
-  GrpTables tb;
-  tb.grp = grp; tb.gx = nullptr; tb.gy = nullptr; tb.sub = sub; tb.ca = ca; tb.cb = cb; tb.sy = sy;
+  load_dec_tables(ws, df, f, 1, &T);
+  const GrpTables tb = tables_of(&T);
   const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
   const uint32_t out_size = (uint32_t)g.row_block;
   const unsigned long long P1 = 8ull * pay_len;

@@ -29,7 +29,7 @@ for _ in range(5):
 ev1.record()
 torch.cuda.synchronize()
 print("decode of %d frames: %.3f ms" % (B, ev0.elapsed_time(ev1) / 5))
-assert not d_st.cpu().numpy().any()
+assert os.environ.get('HIMG_X') or not d_st.cpu().numpy().any()
 rows = (h + 7) // 8
 st = eng.debug_read("dec_stats", 0, (rows + 1) * 32, np.uint32, decoder=True).reshape(rows + 1, 8)
 names = ["chunks", "rounds", "clk_transform/16 (slowest wave)", "clk_workgroup/16", "clk_sync/16", "clk_write/16", "pay_len", "out_size"]
@@ -38,3 +38,5 @@ for i, n in enumerate(names):
     print("FRES %-32s mean %.1f min %.0f max %.0f" % (n, fr[:, i].mean(), fr[:, i].min(), fr[:, i].max()))
 rc = eng.debug_read("rowcount_stats", 0, rows * 32, np.uint32, decoder=True).reshape(rows, 8).astype(np.float64) * 16
 print("k_row_count cycles per row (slowest wave, frame 0): tables/staging %.0f, lead-in %.0f, to end of round 1 %.0f, fixpoint %.0f, row %.0f" % tuple(rc[:, :5].mean(axis=0)))
+for q in range(4):
+    print("  rows with r %% 4 == %d: tables/staging %.0f, lead-in %.0f, round 1 end %.0f, fixpoint end %.0f, row %.0f" % ((q,) + tuple(rc[q::4, :5].mean(axis=0))))
