@@ -1726,12 +1726,12 @@ __device__ __forceinline__ void iwht8(int &x0, int &x1, int &x2, int &x3, int &x
 struct FusedLayout {
   uint32_t sym, tab, sh, unmap, shift, shiftp, total;
 };
-__host__ __device__ inline FusedLayout fused_layout(int row_block) {
+__host__ __device__ inline FusedLayout fused_layout(int row_block, int rows = 1) {
   FusedLayout L;
   uint32_t o = 0;
   auto carve = [&](uint32_t bytes) { uint32_t r = o; o += (bytes + 15u) & ~15u; return r; };
   L.tab = carve((uint32_t)sizeof(LdsTables));   // at offset 0: the hot loop indexes it
-  L.sym = carve((uint32_t)row_block);
+  L.sym = carve((((uint32_t)row_block + 15u) & ~15u) * (uint32_t)rows);   // `rows` block rows of symbols
   L.sh = carve((uint32_t)sizeof(StreamShared));
   L.unmap = carve(512u);
   L.shift = carve(128u);
@@ -2067,15 +2067,22 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // rows): the 64 symbol slots of a tile are then at immediate LDS offsets instead
 // of 64 live address registers, which is what keeps the transform phase from
 // spilling.
+// A workgroup takes `rpw` consecutive block rows: narrow rows leave most of the 1024
+// lanes without a tile in the transform (two lanes per tile: 480 lanes at 1920
+// pixels), so as many rows as fit the LDS -- and the lanes -- are entropy-decoded one
+// after the other (each by all 1024 lanes) and then transformed together.
 template <int COLS>
 __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
                                                                const uint8_t *packed,
                                                                size_t in_stride,
                                                                const uint32_t *sizes,
-                                                               uint8_t *out_frames, int r0) {
+                                                               uint8_t *out_frames, int r0, int r1,
+                                                               int rpw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const FusedLayout L = fused_layout(g.row_block);
-  uint8_t *sym = smem + L.sym;
+  if (COLS == 512) rpw = 1;   // 4096-pixel rows: one row fills the lanes and the LDS (known at compile time)
+  const FusedLayout L = fused_layout(g.row_block, rpw);
+  const uint32_t rb16 = ((uint32_t)g.row_block + 15u) & ~15u;   // one row's symbols
+  uint8_t *sym0 = smem + L.sym;
   LdsTables &T = *reinterpret_cast<LdsTables *>(smem + L.tab);
   StreamShared *sh = reinterpret_cast<StreamShared *>(smem + L.sh);
   int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + L.unmap);
@@ -2101,25 +2108,36 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
   }
   const GrpTables tb = tables_of(&T);
-  const int r = r0 + (int)blockIdx.x;
+  const int rb = r0 + (int)blockIdx.x * rpw;
+  const int nr = COLS == 512 ? 1 : min(rpw, r1 - rb);
   {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
-    const int n16 = (g.row_block + 15) >> 4;
-    for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym)[k] = z;
+    const int n16 = (int)(rb16 >> 4) * nr;
+    for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym0)[k] = z;
   }
   __syncthreads();
 
-  if (tid == 0) {
-    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
-    st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
+  auto decode_row = [&](int i) {
+    const int r = rb + i;
+    if (tid == 0) {
+      uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
+      st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
+    }
+    return decode_stream<true>(
+        p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
+        (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, nullptr, nullptr,
+        ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
+        ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
+        ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
+  };
+  int bad = 0;
+  if constexpr (COLS == 512) {
+    bad = decode_row(0);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < nr && !bad; ++i) bad = decode_row(i);
   }
-  const int bad = decode_stream<true>(
-      p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
-      (uint32_t)g.row_block, tb, sh, sym, nullptr, nullptr,
-      ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
-      ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
-      ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
   if (bad) {   // uniform: every lane gets the same verdict
     if (tid == 0) atomicMax(&df->status, fmt_err(7, 1));
     return;
@@ -2133,18 +2151,23 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   // stay read-only in LDS: no barrier, no second pass over them.
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
   const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
+  const int per_row = ((cols + 31) >> 5) * 64;   // whole wavefronts: a lane pair never straddles rows
 #pragma unroll 1
-  for (int it = tid; it < ((cols + 31) >> 5) * 64; it += kDecThreads)
-    if (pair_tile(it) < cols)
-      transform_store_pair<COLS>(g, cols, sym, low, s_unmap, s_shift, s_shiftp, ycbcr, pair_tile(it),
-                                 pair_half(it), r, img);
+  for (int it = tid; it < per_row * nr; it += kDecThreads) {
+    const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
+    if (pair_tile(il) < cols)
+      transform_store_pair<COLS>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
+                                 pair_tile(il), pair_half(il), rb + i, img);
+  }
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
   if ((tid & 63) == 0) {
-    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
     const long long c_out = clock64();
-    atomicMax(&st[2], (uint32_t)((c_out - c_p2) >> 4));   // transform + stores
-    atomicMax(&st[3], (uint32_t)((c_out - c_in) >> 4));   // the whole workgroup
+    for (int i = 0; i < nr; ++i) {
+      uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + rb + i + 1) * 8;
+      atomicMax(&st[2], (uint32_t)((c_out - c_p2) >> 4));   // transform + stores
+      atomicMax(&st[3], (uint32_t)((c_out - c_in) >> 4));   // the whole workgroup
+    }
   }
 }
 
@@ -2434,17 +2457,26 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     if (!side && nrows > 0)
       HIMG_LAUNCH(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
                   d_packed, in_stride, d_sizes, r0, r1, rpc);
-    const uint32_t lds = fused_layout(g.row_block).total;
+    // Rows per workgroup: as many as the transform has lanes for and the LDS holds
+    // (4096-pixel rows: one).
+    const int per_row = ((g.cols + 31) / 32) * 64;
+    int rpw = 1;
+    while (rpw < 8 && (rpw + 1) * per_row <= kDecThreads && fused_layout(g.row_block, rpw + 1).total <= kLdsMax) ++rpw;
+    static const int rpw_env = getenv("HIMG_ROWS_PER_FUSED") ? atoi(getenv("HIMG_ROWS_PER_FUSED")) : 0;
+    if (rpw_env > 0 && rpw_env < rpw) rpw = rpw_env;
+    if (g.cols == 512 && g.C == 4) rpw = 1;
+    const uint32_t lds = fused_layout(g.row_block, rpw).total;
     prof_begin(prof, "k_dec_row_fused", stream);
 #define HIMG_FUSED_LAUNCH(COLS)                                                                 \
   do {                                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<COLS>),           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3(nrows, batch), dim3(kDecThreads), lds,     \
-                       stream, g, ws, d_packed, in_stride, d_sizes, d_out, r0);                 \
+    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3((nrows + rpw - 1) / rpw, batch),           \
+                       dim3(kDecThreads), lds, stream, g, ws, d_packed, in_stride, d_sizes,     \
+                       d_out, r0, r1, rpw);                                                     \
   } while (0)
     if (nrows > 0) {
-      if (g.cols == 512) HIMG_FUSED_LAUNCH(512);
+      if (g.cols == 512 && g.C == 4) HIMG_FUSED_LAUNCH(512);
       else HIMG_FUSED_LAUNCH(0);
     }
 #undef HIMG_FUSED_LAUNCH
