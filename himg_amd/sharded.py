@@ -122,6 +122,10 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=T
         return None
 
     total = layout[3]
+    if world == 1:
+        # One rank holds everything already: no copies (a 16384x16384 frame's packed rows
+        # are 275 MB).
+        return backend.assemble(low, all_bits, piece, host)
     rel_full = torch.empty(total, dtype=torch.uint8, device=piece.device)
     for pl, (s, e) in zip(piece_list, ranges):
         rel_full[s:e] = pl[: e - s]
