@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   // 0 where the pair is longer than 24 bits (then the tokens go one by one).
   __shared__ uint32_t s_pair[kPairRuns][256];
   __shared__ uint32_t s_run[kRunTab];   // run token of r zeros: bits | length << 24 (0: not representable)
-  __shared__ uint32_t s_priv[kPrivWords * 256];   // [word][lane]: the bits a lane assembled this iteration
+  __shared__ uint32_t s_priv[(kPrivWords + 1) * 256];   // [word][lane]: the bits a lane assembled this iteration (+ one row that absorbs an overflowing lane's stores)
   __shared__ ZR sm_zr[2][4];
   __shared__ uint32_t sm_u[2][4];
 
@@ -1416,15 +1416,16 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     {
       uint32_t nw = 0, ab = 0;
       unsigned long long a = 0;
+      // Branch free: the word in progress is stored after every token (the row past
+      // the last absorbs a lane that overflows), a completed word just moves on.
       auto lput = [&](uint32_t v, int n) {  // n <= 32
         a |= (unsigned long long)v << ab;
         ab += n;
-        if (ab >= 32) {
-          if (nw < (uint32_t)kPrivWords) s_priv[nw * 256 + tid] = (uint32_t)a;
-          ++nw;
-          a >>= 32;
-          ab -= 32;
-        }
+        s_priv[min(nw, (uint32_t)kPrivWords) * 256 + tid] = (uint32_t)a;
+        const uint32_t st = ab >> 5;   // 0 or 1
+        nw += st;
+        a >>= (st << 5);
+        ab &= 31u;
       };
       walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
                    [&](uint32_t pair) { lput(pair & 0xffffffu, (int)(pair >> 24)); },
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
                    });
       mybits = nw * 32u + ab;
       nwords = nw + (ab ? 1u : 0u);
-      if (ab && nw < (uint32_t)kPrivWords) s_priv[nw * 256 + tid] = (uint32_t)a;
+      s_priv[min(nw, (uint32_t)kPrivWords) * 256 + tid] = (uint32_t)a;   // the bits left of a word that completed
       ovf = nwords > (uint32_t)kPrivWords;
     }
     const uint32_t bincl = wave_scan_u32(mybits);
