@@ -778,6 +778,40 @@ __device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask,
   }
 }
 
+// The walk of k_emit's fast path: the same tokens as walk16_pairs, with as few
+// branches as the format allows (every divergent branch here is paid by the whole
+// wavefront on almost every token: some lane always takes it).  pair_tab has one row
+// more, all zero, for runs of kPairRuns zeros or more; run_tab one entry more (0).
+// put(bits, n) appends n <= 32 bits (n == 0 is a no-op); f as in walk16.
+template <class PUT, class F>
+__device__ __forceinline__ void walk16_emit(const uint32_t w[4], uint32_t mask, int nvalid, int run_in,
+                                            bool flush, const uint32_t *pair_tab, const uint32_t *run_tab,
+                                            const unsigned long long *code_len, PUT &&put, F &&f) {
+  int prev = -1;
+  uint32_t m = mask;
+  while (m) {
+    const int k = __ffs(m) - 1;
+    m &= m - 1;
+    const int run = k - prev - 1 + (prev < 0 ? run_in : 0);
+    const int sym = symbol_at(w, k);
+    prev = k;
+    const uint32_t pair = pair_tab[min(run, kPairRuns) * 256 + sym];
+    if (__builtin_expect(pair != 0, 1)) {
+      put(pair & 0xffffffu, (int)(pair >> 24));
+    } else {
+      const uint32_t rt = run_tab[min(run, kRunTab)];
+      if (__builtin_expect(rt == 0 && run != 0, 0)) emit_run(run, f);   // 279 zeros or more, or a token beyond 24 bits
+      put(rt & 0xffffffu, (int)(rt >> 24));
+      const unsigned long long cl = code_len[sym];
+      put((uint32_t)cl, (int)(cl >> 32));
+    }
+  }
+  if (flush) {
+    const int run = nvalid - 1 - prev + (prev < 0 ? run_in : 0);
+    if (run) emit_run(run, f);
+  }
+}
+
 // Zero-run summary of one thread's chunk.  Chunks with fewer than 16 valid
 // symbols only occur at the very end of a span; an empty chunk is the identity.
 __device__ __forceinline__ ZR summarize16(uint32_t mask, int nvalid) {
@@ -1311,8 +1345,8 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   // Merged token pairs: a zero run of r <= 6 zeros followed by the literal `sym`
   // (the common case by far) costs ONE lookup and ONE put: bits | length << 24,
   // 0 where the pair is longer than 24 bits (then the tokens go one by one).
-  __shared__ uint32_t s_pair[kPairRuns][256];
-  __shared__ uint32_t s_run[kRunTab];   // run token of r zeros: bits | length << 24 (0: not representable)
+  __shared__ uint32_t s_pair[kPairRuns + 1][256];   // row kPairRuns: zeros ("not merged")
+  __shared__ uint32_t s_run[kRunTab + 1];   // run token of r zeros: bits | length << 24 (0: not representable; [kRunTab] = 0)
   __shared__ uint32_t s_priv[(kPrivWords + 1) * 256];   // [word][lane]: the bits a lane assembled this iteration (+ one row that absorbs an overflowing lane's stores)
   __shared__ ZR sm_zr[2][4];
   __shared__ uint32_t sm_u[2][4];
@@ -1343,6 +1377,8 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     const int n = lr + eb + ls;
     s_pair[r][sym] = (sym != 0 && ls > 0 && (r == 0 || lr > 0) && n <= 24) ? ((uint32_t)bits | ((uint32_t)n << 24)) : 0u;
   }
+  s_pair[kPairRuns][tid] = 0;
+  if (tid == 0) s_run[kRunTab] = 0;
   for (int r = tid; r < kRunTab; r += 256) {
     const int rs = r == 1 ? 0 : r == 2 ? 256 : r <= 6 ? 257 : r <= 22 ? 258 : 259;
     const int eb = r <= 2 ? 0 : r <= 6 ? 2 : r <= 22 ? 4 : 8;
@@ -1427,13 +1463,12 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
         a >>= (st << 5);
         ab &= 31u;
       };
-      walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
-                   [&](uint32_t pair) { lput(pair & 0xffffffu, (int)(pair >> 24)); },
-                   [&](int sym, int eb, int ev) {
-                     const unsigned long long cl = s_cl[sym];
-                     lput((uint32_t)cl, (int)(cl >> 32));
-                     if (eb) lput((uint32_t)ev, eb);
-                   });
+      walk16_emit(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run, s_cl, lput,
+                  [&](int sym, int eb, int ev) {
+                    const unsigned long long cl = s_cl[sym];
+                    lput((uint32_t)cl, (int)(cl >> 32));
+                    if (eb) lput((uint32_t)ev, eb);
+                  });
       mybits = nw * 32u + ab;
       nwords = nw + (ab ? 1u : 0u);
       s_priv[min(nw, (uint32_t)kPrivWords) * 256 + tid] = (uint32_t)a;   // the bits left of a word that completed
