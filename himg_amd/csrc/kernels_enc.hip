@@ -1488,14 +1488,17 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
 
     if (!any_ovf && iter_bits <= kWindowBits) {
       // Fast path: shift the lane's words to its bit offset and OR them in.
+      // One OR per staging word: the part of word j that spills over is OR-ed in
+      // together with word j + 1.
       const uint32_t sh = my_pos & 31;
-      uint32_t widx = (my_pos >> 5) & (kStageWords - 1);
+      uint32_t widx = (my_pos >> 5) & (kStageWords - 1), carry = 0;
       for (uint32_t j = 0; j < nwords; ++j) {
         const unsigned long long v = (unsigned long long)s_priv[j * 256 + tid] << sh;
-        atomicOr(&stage[widx], (uint32_t)v);
+        atomicOr(&stage[widx], (uint32_t)v | carry);
+        carry = (uint32_t)(v >> 32);
         widx = (widx + 1) & (kStageWords - 1);
-        if (v >> 32) atomicOr(&stage[widx], (uint32_t)(v >> 32));
       }
+      if (carry) atomicOr(&stage[widx], carry);
       __syncthreads();   // (C)
       const uint32_t nw = iter_end >> 5;
       for (uint32_t k = fw + tid; k < nw; k += 256) {
