@@ -902,14 +902,14 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
 // the 261 token bins at the end.  Longer runs are counted token by token.
 __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
-  __shared__ uint32_t hist2[kPairRuns][256];
+  __shared__ uint32_t hist2[kPairRuns + 1][256];   // [zeros in front, kPairRuns = that many or more][literal]
   __shared__ uint32_t hrun[kRunTab + 1];   // runs of kPairRuns..278 zeros, by exact length
   __shared__ uint32_t s_sym[8 * 256];      // [word][lane]: the lane's 32 symbols of this iteration
   __shared__ ZR sm[4];
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
   for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
-  for (int k = threadIdx.x; k < kPairRuns * 256; k += 256) (&hist2[0][0])[k] = 0;
+  for (int k = threadIdx.x; k < (kPairRuns + 1) * 256; k += 256) (&hist2[0][0])[k] = 0;
   for (int k = threadIdx.x; k < kRunTab + 1; k += 256) hrun[k] = 0;
   ZR carry;
   carry.tz = span_carry_in(g, ws, sp, f);
@@ -946,12 +946,12 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
       const int run = k - prev - 1 + (prev < 0 ? ex.tz : 0);
       const int sym = mysym[(k >> 2) * 1024 + (k & 3)];
       prev = k;
-      if (__builtin_expect(run < kPairRuns, 1)) {
-        atomicAdd(&hist2[run][sym], 1u);
-      } else {
+      // The literal always counts in the 2-D histogram (row kPairRuns: after a longer
+      // run -- no branch around the common case); a longer run counts on its own.
+      atomicAdd(&hist2[min(run, kPairRuns)][sym], 1u);
+      if (__builtin_expect(run >= kPairRuns, 0)) {
         if (run < kRunTab) atomicAdd(&hrun[run], 1u);
         else emit_run(run, one);
-        atomicAdd(&hist[sym], 1u);
       }
     }
     if (flush) {
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
     const int sym = threadIdx.x;   // 256 threads = 256 literal values
     uint32_t lit = 0, r1 = hist2[1][sym], r2 = hist2[2][sym], r3 = 0;
 #pragma unroll
-    for (int r = 0; r < kPairRuns; ++r) lit += hist2[r][sym];
+    for (int r = 0; r <= kPairRuns; ++r) lit += hist2[r][sym];
 #pragma unroll
     for (int r = 3; r < kPairRuns; ++r) r3 += hist2[r][sym];
     if (lit) atomicAdd(&hist[sym], lit);
