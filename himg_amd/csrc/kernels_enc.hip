@@ -726,18 +726,18 @@ __device__ __forceinline__ int symbol_at(const uint32_t w[4], int k) {
 template <class F>
 __device__ __forceinline__ void walk16(const uint32_t w[4], uint32_t mask, int nvalid, int run_in,
                                        bool flush, F &&f) {
-  int prev = -1;
+  int prev = -1 - run_in;   // the zeros in front of the chunk count as positions before it
   uint32_t m = mask;
   while (m) {
     const int k = __ffs(m) - 1;
     m &= m - 1;
-    const int run = k - prev - 1 + (prev < 0 ? run_in : 0);
+    const int run = k - prev - 1;
     if (run) emit_run(run, f);
     f(symbol_at(w, k), 0, 0);
     prev = k;
   }
   if (flush) {
-    const int run = nvalid - 1 - prev + (prev < 0 ? run_in : 0);
+    const int run = nvalid - 1 - prev;
     if (run) emit_run(run, f);
   }
 }
@@ -752,12 +752,12 @@ template <class FP, class F>
 __device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask, int nvalid,
                                              int run_in, bool flush, const uint32_t *pair_tab,
                                              const uint32_t *run_tab, FP &&fp, F &&f) {
-  int prev = -1;
+  int prev = -1 - run_in;   // the zeros in front of the chunk count as positions before it
   uint32_t m = mask;
   while (m) {
     const int k = __ffs(m) - 1;
     m &= m - 1;
-    const int run = k - prev - 1 + (prev < 0 ? run_in : 0);
+    const int run = k - prev - 1;
     const int sym = symbol_at(w, k);
     prev = k;
     const uint32_t pair = run < kPairRuns ? pair_tab[run * 256 + sym] : 0u;
@@ -773,7 +773,7 @@ __device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask,
     }
   }
   if (flush) {
-    const int run = nvalid - 1 - prev + (prev < 0 ? run_in : 0);
+    const int run = nvalid - 1 - prev;
     if (run) emit_run(run, f);
   }
 }
@@ -787,12 +787,12 @@ template <class PUT, class F>
 __device__ __forceinline__ void walk16_emit(const uint32_t w[4], uint32_t mask, int nvalid, int run_in,
                                             bool flush, const uint32_t *pair_tab, const uint32_t *run_tab,
                                             const unsigned long long *code_len, PUT &&put, F &&f) {
-  int prev = -1;
+  int prev = -1 - run_in;   // the zeros in front of the chunk count as positions before it
   uint32_t m = mask;
   while (m) {
     const int k = __ffs(m) - 1;
     m &= m - 1;
-    const int run = k - prev - 1 + (prev < 0 ? run_in : 0);
+    const int run = k - prev - 1;
     const int sym = symbol_at(w, k);
     prev = k;
     const uint32_t pair = pair_tab[min(run, kPairRuns) * 256 + sym];
@@ -807,7 +807,7 @@ __device__ __forceinline__ void walk16_emit(const uint32_t w[4], uint32_t mask, 
     }
   }
   if (flush) {
-    const int run = nvalid - 1 - prev + (prev < 0 ? run_in : 0);
+    const int run = nvalid - 1 - prev;
     if (run) emit_run(run, f);
   }
 }
@@ -938,12 +938,12 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
     auto one = [&](int sym, int, int) { atomicAdd(&hist[sym], 1u); };
     const uint8_t *mysym = reinterpret_cast<const uint8_t *>(s_sym) + threadIdx.x * 4;
-    int prev = -1;
+    int prev = -1 - ex.tz;   // the zeros in front of the chunk count as positions before it
     uint32_t m = mask;
     while (m) {
       const int k = __ffs(m) - 1;
       m &= m - 1;
-      const int run = k - prev - 1 + (prev < 0 ? ex.tz : 0);
+      const int run = k - prev - 1;
       const int sym = mysym[(k >> 2) * 1024 + (k & 3)];
       prev = k;
       // The literal always counts in the 2-D histogram (row kPairRuns: after a longer
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
       }
     }
     if (flush) {
-      const int run = nvalid - 1 - prev + (prev < 0 ? ex.tz : 0);
+      const int run = nvalid - 1 - prev;
       if (run) emit_run(run, one);
     }
   }
