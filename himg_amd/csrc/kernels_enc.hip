@@ -634,24 +634,69 @@ __device__ __forceinline__ ZR zr_combine(ZR l, ZR r) {
   return o;
 }
 
+// Wavefront scans on the DPP path (one VALU operation per step where __shfl_up is a
+// ds_bpermute with its address arithmetic and a select): four row_shr steps scan the
+// rows of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across.  A lane
+// without a source keeps `identity` (bound_ctrl off / the row mask).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_from(uint32_t identity, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
+// Inclusive add scan over the wavefront; lane 63 ends up with the total.
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  v += dpp_from<kDppRowShr1, 0xf>(0, v);
+  v += dpp_from<kDppRowShr2, 0xf>(0, v);
+  v += dpp_from<kDppRowShr4, 0xf>(0, v);
+  v += dpp_from<kDppRowShr8, 0xf>(0, v);
+  v += dpp_from<kDppBcast15, 0xa>(0, v);
+  v += dpp_from<kDppBcast31, 0xc>(0, v);
+  return v;
+}
+
+// A zero-run summary in one word: trailing zeros | all-zero flag << 31; combining is
+// r + ((l + 2^31) & sign(r)): r on its own unless r is all zeros, else both counts and
+// l's flag.
+constexpr uint32_t kZrIdentity = 0x80000000u;
+__device__ __forceinline__ uint32_t zr_pack(ZR z) { return (uint32_t)z.tz | ((uint32_t)z.az << 31); }
+__device__ __forceinline__ ZR zr_unpack(uint32_t p) {
+  ZR z;
+  z.tz = (int)(p & 0x7fffffffu);
+  z.az = (int)(p >> 31);
+  return z;
+}
+__device__ __forceinline__ uint32_t zrp_combine(uint32_t l, uint32_t r) {
+  return r + ((l + 0x80000000u) & (uint32_t)((int)r >> 31));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t zrp_step(uint32_t v) {
+  return zrp_combine(dpp_from<CTRL, ROW_MASK>(kZrIdentity, v), v);
+}
+// Inclusive scan of packed summaries over the wavefront.
+__device__ __forceinline__ uint32_t wave_scan_zrp(uint32_t v) {
+  v = zrp_step<kDppRowShr1, 0xf>(v);
+  v = zrp_step<kDppRowShr2, 0xf>(v);
+  v = zrp_step<kDppRowShr4, 0xf>(v);
+  v = zrp_step<kDppRowShr8, 0xf>(v);
+  v = zrp_step<kDppBcast15, 0xa>(v);
+  v = zrp_step<kDppBcast31, 0xc>(v);
+  return v;
+}
+// The value of the lane before (lane 0: identity).
+__device__ __forceinline__ uint32_t wave_prev(uint32_t identity, uint32_t v) {
+  return dpp_from<kDppWaveShr1, 0xf>(identity, v);
+}
+
 // Exclusive block scan (256 threads) of zero-run summaries; `carry` is the state
 // before this block of symbols.  Returns the exclusive prefix; *total receives
 // the state after the block.  `sm` needs 4 entries.
 __device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total) {
   const int lane = lane_id(), wave = wave_id();
-  ZR incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    ZR t;
-    t.tz = __shfl_up(incl.tz, d);
-    t.az = __shfl_up(incl.az, d);
-    if (lane >= d) incl = zr_combine(t, incl);
-  }
-  if (lane == 63) sm[wave] = incl;
-  ZR ex;
-  ex.tz = __shfl_up(incl.tz, 1);
-  ex.az = __shfl_up(incl.az, 1);
-  if (lane == 0) { ex.tz = 0; ex.az = 1; }
+  const uint32_t inclp = wave_scan_zrp(zr_pack(mine));
+  if (lane == 63) sm[wave] = zr_unpack(inclp);
+  const ZR ex = zr_unpack(wave_prev(kZrIdentity, inclp));
   __syncthreads();
   ZR pre = carry, tot = carry;
   for (int w = 0; w < 4; ++w) {
@@ -666,12 +711,7 @@ __device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total
 // Exclusive block scan (256 threads) of a bit count; *total = block sum.
 __device__ __forceinline__ uint32_t block_scan_u32(uint32_t v, uint32_t *sm, uint32_t *total) {
   const int lane = lane_id(), wave = wave_id();
-  uint32_t incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
-  }
+  const uint32_t incl = wave_scan_add(v);
   if (lane == 63) sm[wave] = incl;
   __syncthreads();
   uint32_t pre = 0, tot = 0;
@@ -1311,26 +1351,8 @@ constexpr uint32_t kWindowBits = (uint32_t)(kStageWords - 4) * 32u; // + carry w
 constexpr int kPrivWords = 8;   // lane-private words per iteration (16 symbols: 256 bits cover all but 16+-bit codes)
 
 // Wave-level inclusive scans (no barrier); lane 63 holds the wave total.
-__device__ __forceinline__ ZR wave_scan_zr(ZR v) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    ZR t;
-    t.tz = __shfl_up(v.tz, d);
-    t.az = __shfl_up(v.az, d);
-    if (lane >= d) v = zr_combine(t, v);
-  }
-  return v;
-}
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
+__device__ __forceinline__ ZR wave_scan_zr(ZR v) { return zr_unpack(wave_scan_zrp(zr_pack(v))); }
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) { return wave_scan_add(v); }
 
 // Three barriers per 4096-symbol iteration: (A) after the waves publish their
 // zero-run totals, (B) after they publish their bit totals, (C) after the bits
@@ -1424,10 +1446,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     // (A) zero-run state in front of every lane.
     const ZR incl = wave_scan_zr(summarize16(mask, nvalid));
     if (lane == 63) sm_zr[par][wave] = incl;
-    ZR ex;
-    ex.tz = __shfl_up(incl.tz, 1);
-    ex.az = __shfl_up(incl.az, 1);
-    if (lane == 0) { ex.tz = 0; ex.az = 1; }
+    const ZR ex = zr_unpack(wave_prev(kZrIdentity, zr_pack(incl)));
     __syncthreads();
     ZR pre, tot;
     pre.tz = run_carry; pre.az = 0;
