@@ -88,6 +88,8 @@ struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
 
 struct DecFrame {            // written by k_dec_parse, read by later kernels
   int32_t status;
+  int32_t parse_status;      // k_dec_parse's own verdict (status collects the later kernels' as well)
+  int32_t walk_status;       // k_dec_rowwalk's verdict: it runs beside k_dec_parse, k_row_count merges it
   int32_t ycbcr;
   DecStream s[2];
   int16_t lmap[128];         // decoder-side companding tables (positive halves)

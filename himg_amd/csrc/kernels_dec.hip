@@ -306,6 +306,7 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
     for (int k = 0; k < cCount && !st; ++k) st = s_chk[k];
     s_status = st;
     df->status = st;
+    df->parse_status = st;
   }
   __syncthreads();
   if (s_status) return;
@@ -505,19 +506,66 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
 // k_dec_rowwalk: index of the FRES block rows (huffman_dec.cpp:232-248).  Every
 // row's size header sits right behind the previous row's payload, so this is a
 // chain of dependent loads (~1.4 us per hop from HBM) that nothing can
-// parallelise; it runs on a side stream, concurrently with the LRES kernels,
-// which do not need it.
+// parallelise; it runs on a side stream, beside k_dec_parse and the LRES kernels.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint8_t *packed,
-                                                    size_t in_stride) {
-  const int f = blockIdx.x;
-  if (threadIdx.x != 0) return;
+                                                    size_t in_stride, const uint32_t *sizes) {
+  // The walk needs where the FRES payload starts and ends -- which k_dec_parse knows
+  // only after 100 us of tree recovery.  It finds both by itself (the same chunk
+  // look-ups, then only the LENGTH of the serialised tree: a leaf is 1 + 9 bits, a
+  // branch 1 bit, pre-order, huffman_dec.cpp:152-229) and so runs beside k_dec_parse
+  // instead of behind it.  Whatever is wrong with the headers or the tree is
+  // k_dec_parse's to report; this kernel reports the row headers only, in
+  // walk_status, which k_row_count / k_dec_status merge once both kernels are done.
+  __shared__ uint32_t s_tree[(kTreeStride + 16) / 4];
+  __shared__ uint32_t s_hdr[2];
+  const int f = blockIdx.x, lane = threadIdx.x;
   DecFrame *df = ws.frames + f;
-  if (df->status) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
+  const uint32_t n = sizes[f];
+  if (lane == 0) {
+    uint32_t idx = 12, sz = 0;
+    bool ok = n >= 12;
+    const uint32_t tags[6] = {0x544d5246u /*FRMT*/, 0x50414d4cu /*LMAP*/, 0x5345524cu /*LRES*/,
+                              0x47464351u /*QCFG*/, 0x50414d46u /*FMAP*/, 0x53455246u /*FRES*/};
+    for (int t = 0; ok && t < 6; ++t) {   // the order of k_dec_parse (decoder.cpp:144-290)
+      ok = find_chunk(p, n, &idx, tags[t], &sz);
+      if (ok && t < 5) idx += sz;
+    }
+    s_hdr[0] = ok ? idx : 0u;
+    s_hdr[1] = ok ? sz : 0u;
+    df->walk_status = 0;
+  }
+  __syncthreads();
+  const uint32_t coff = s_hdr[0], csz = s_hdr[1];
+  if (coff == 0) return;
+  const uint32_t cnt = csz < (uint32_t)kTreeStride ? csz : (uint32_t)kTreeStride;
+  for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16u; k += 64u)
+    reinterpret_cast<uint8_t *>(s_tree)[k] = k < cnt ? p[coff + k] : (uint8_t)0;
+  __syncthreads();
+  if (lane != 0) return;
+  uint32_t bit = 0;
+  {
+    const uint8_t *t8 = reinterpret_cast<const uint8_t *>(s_tree);
+    const uint32_t bit_end = 8u * cnt;
+    int open = 1, count = 0;
+    while (open > 0) {
+      if (count >= kMaxNodes || bit >= bit_end) return;   // k_dec_parse rejects this tree
+      ++count;
+      if ((t8[bit >> 3] >> (bit & 7u)) & 1u) {
+        if (bit + 10u > bit_end) return;
+        bit += 10u;
+        --open;
+      } else {
+        bit += 1u;
+        ++open;
+      }
+    }
+  }
   int st = 0;
-  uint32_t q = df->s[1].payload_off;
-  const uint32_t end = df->s[1].chunk_end;
+  uint32_t q = coff + ((bit + 7u) >> 3);   // AlignToByte, huffman_dec.cpp:229
+  const uint32_t end = coff + csz;
+  if (q >= end) return;                    // nothing behind the tree: k_dec_parse's verdict
   uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
   if (g.fix_t2 && g.rows == 1) {   // the encoder writes one block row without a size header
     ro[0] = q;
@@ -540,7 +588,7 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
     q += len;
   }
   if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
-  if (st) atomicMax(&df->status, st);
+  df->walk_status = st;
 }
 
 // ---------------------------------------------------------------------------
@@ -2268,7 +2316,12 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
   DecFrame *df = ws.frames + f;
   // One read for the whole workgroup: the LRES kernels run concurrently on the
   // other stream and may flag the frame while this kernel starts.
-  if (tid == 0) sh.flag = df->status;
+  if (tid == 0) {
+    // The row walk ran beside k_dec_parse: its verdict counts if the parse passed.
+    const int w = df->parse_status == 0 ? df->walk_status : 0;
+    if (w && blockIdx.x == 0) atomicMax(&df->status, w);
+    sh.flag = df->status | w;
+  }
   __syncthreads();
   const int failed = sh.flag;
   if (!failed) {   // load_dec_tables with the count-only step words next to the long-code descriptors
@@ -2382,7 +2435,11 @@ __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, c
 // k_dec_status: copy the per-frame verdict out of the workspace.
 __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < batch) status[f] = ws.frames[f].status;
+  if (f < batch) {
+    const DecFrame *df = ws.frames + f;
+    const int w = df->parse_status == 0 ? df->walk_status : 0;   // (merged by k_row_count already unless no row was asked for)
+    status[f] = df->status > w ? df->status : w;
+  }
 }
 
 #define HIMG_LAUNCH(name, grid, block, ...)                    \
@@ -2406,18 +2463,27 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;
   const int wps = (allow_fused && fused_layout(g.row_block).total <= kLdsMax) ? 1 : 0;
-  HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
-  // Fork: the serial FRES row-header walk runs on the side stream while this
-  // stream decodes the LRES chain; they join before the first FRES row kernel.
-  // (side == nullptr: run it in line.)
+  // Diagnostics and the LRES symbols (k_lres_write stores the non-zero ones only) are
+  // cleared up front: k_row_count may start as soon as the parse and the walk are done.
+  (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
+  if (ws.rc_stats) (void)hipMemsetAsync(ws.rc_stats, 0, (size_t)batch * g.rows * 8 * sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(ws.lres_sym, 0, (size_t)batch * ws.lres_stride, stream);
+  // Fork: the serial FRES row-header walk runs on the side stream beside k_dec_parse.
   if (side) {
     (void)hipEventRecord(ev_fork, stream);
     (void)hipStreamWaitEvent(side, ev_fork, 0);
     prof_begin(prof, "k_dec_rowwalk", side);
-    hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride);
+    hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride, d_sizes);
     prof_end(prof, side);
-    // The FRES fixpoint rounds need the row offsets only, not the low-res plane:
-    // they fill the CUs the latency-bound LRES kernels leave idle.
+  }
+  HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
+  // The FRES fixpoint rounds need the decode tables (parse) and the row index (walk);
+  // they join this stream again before the first FRES row kernel.
+  // (side == nullptr: everything in line.)
+  if (side) {
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+    // They fill the CUs the latency-bound LRES kernels leave idle.
     if (nrows > 0) {
       prof_begin(prof, "k_row_count", side);
       if (wps)
@@ -2430,13 +2496,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     }
     (void)hipEventRecord(ev_join, side);
   } else {
-    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride);
+    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
   }
   // LRES: every chunk in parallel, chain verified, serial fallback if not.
-  (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
-  if (ws.rc_stats) (void)hipMemsetAsync(ws.rc_stats, 0, (size_t)batch * g.rows * 8 * sizeof(uint32_t), stream);
-  // k_lres_write stores the non-zero symbols only.
-  (void)hipMemsetAsync(ws.lres_sym, 0, (size_t)batch * ws.lres_stride, stream);
   static const int lres_stage = getenv("HIMG_LRES_STAGE") ? atoi(getenv("HIMG_LRES_STAGE")) : 3;
   if (lres_stage & 1)
     HIMG_LAUNCH(k_lres_spec<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
