@@ -1720,6 +1720,17 @@ static size_t lds_pad() {
     prof_end(prof, stream);                                    \
   } while (0)
 
+// Zero `n` dwords at the head of every row of a [batch][stride] dword array.
+__global__ __launch_bounds__(256) void k_zero_rows(uint32_t *base, size_t stride, uint32_t n) {
+  uint32_t *row = base + (size_t)blockIdx.y * stride;
+  const uint32_t k0 = blockIdx.x * (256u * 8u) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t k = k0 + (uint32_t)j * 256u;
+    if (k < n) row[k] = 0;
+  }
+}
+
 // The round-2 pixel stage (k_pix_fwd) serves full tiles of packed RGBA8.
 static bool use_pix_path(const Geom &g) {
   return g.W % 8 == 0 && g.H % 8 == 0 && g.stride == 4 && g.C == 4;
@@ -1756,7 +1767,11 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
     const size_t start = (size_t)(kHeadLen & ~3);
     size_t width = (size_t)g.lres_size + kTreeStride + 64;
     if (start + width > out_stride) width = out_stride - start;
-    (void)hipMemset2DAsync(d_out + start, out_stride, 0, width, (size_t)batch, stream);
+    // (hipMemset2DAsync takes 90 us for these 67 MB of a 64-frame batch; plain dword
+    // stores take a fifth of that.)
+    const uint32_t nd = (uint32_t)((width + 3) / 4);   // start is dword aligned, the rows lie out_stride apart
+    hipLaunchKernelGGL(k_zero_rows, dim3((nd + 256 * 8 - 1) / (256 * 8), batch), b256, 0, stream,
+                       reinterpret_cast<uint32_t *>(d_out + start), out_stride / 4, nd);
   }
   prof_end(prof, stream);
 
