@@ -2432,6 +2432,23 @@ __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, c
   }
 }
 
+// k_dec_zero: the LRES symbol planes (16-byte units) and the two diagnostics arrays,
+// one launch instead of three memsets in front of every decode.
+__global__ __launch_bounds__(256) void k_dec_zero(uint4 *sym, uint32_t n16, uint32_t *a, uint32_t na, uint32_t *b,
+                                                  uint32_t nb) {
+  uint4 z;
+  z.x = z.y = z.z = z.w = 0;
+  const uint32_t k0 = blockIdx.x * (256u * 4u) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t k = k0 + (uint32_t)j * 256u;
+    if (k < n16) sym[k] = z;
+  }
+  const uint32_t stride_t = gridDim.x * 256u, t0 = blockIdx.x * 256u + threadIdx.x;
+  for (uint32_t k = t0; k < na; k += stride_t) a[k] = 0;
+  for (uint32_t k = t0; k < nb; k += stride_t) b[k] = 0;
+}
+
 // k_dec_status: copy the per-frame verdict out of the workspace.
 __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2465,9 +2482,14 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   const int wps = (allow_fused && fused_layout(g.row_block).total <= kLdsMax) ? 1 : 0;
   // Diagnostics and the LRES symbols (k_lres_write stores the non-zero ones only) are
   // cleared up front: k_row_count may start as soon as the parse and the walk are done.
-  (void)hipMemsetAsync(ws.stats, 0, (size_t)batch * (g.rows + 1) * 8 * sizeof(uint32_t), stream);
-  if (ws.rc_stats) (void)hipMemsetAsync(ws.rc_stats, 0, (size_t)batch * g.rows * 8 * sizeof(uint32_t), stream);
-  (void)hipMemsetAsync(ws.lres_sym, 0, (size_t)batch * ws.lres_stride, stream);
+  {
+    const uint32_t n16 = (uint32_t)(((size_t)batch * ws.lres_stride + 15) / 16);   // (the stride is a multiple of 256)
+    const uint32_t ns = (uint32_t)((size_t)batch * (g.rows + 1) * 8), nr = ws.rc_stats ? (uint32_t)((size_t)batch * g.rows * 8) : 0u;
+    prof_begin(prof, "memset", stream);
+    hipLaunchKernelGGL(k_dec_zero, dim3((n16 + 256 * 4 - 1) / (256 * 4)), dim3(256), 0, stream,
+                       reinterpret_cast<uint4 *>(ws.lres_sym), n16, ws.stats, ns, ws.rc_stats, nr);
+    prof_end(prof, stream);
+  }
   // Fork: the serial FRES row-header walk runs on the side stream beside k_dec_parse.
   if (side) {
     (void)hipEventRecord(ev_fork, stream);
