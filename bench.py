@@ -595,7 +595,10 @@ def main():
         alg_bytes_launch = alg_bytes_side * G / B   # one launch processes G = B/streams frames
         enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_pix_fwd", "k_lres_summary",
                       "k_tok_hist", "k_tree", "k_sizes", "k_emit", "k_padfix", "memset"}
-        stages = {k: {"ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
+        # Per encode / decode call of one group (a kernel launched twice per call --
+        # k_tok_hist: LRES spans, then FRES rows -- counts with both launches).
+        calls = max(1, args.steps * len(engines))
+        stages = {k: {"ms": v[0] / calls, "launches": v[1] / calls} for k, v in prof.items()}
         dom = max(stages, key=lambda k: stages[k]["ms"]) if stages else None
         roofline = None
         if dom:

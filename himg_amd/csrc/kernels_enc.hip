@@ -744,10 +744,10 @@ __device__ __forceinline__ uint32_t nonzero_mask16(const uint32_t w[4], int nval
   uint32_t m = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    // Bit 7 of every byte = (byte != 0), then gather bits 7,15,23,31 into a nibble
-    // (the four partial products of the multiply land on distinct bits).
+    // Byte k of t = (byte k != 0), then the four flags as a nibble: a dot product with
+    // the bit weights 1, 2, 4, 8.
     const uint32_t t = ((((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u) >> 7;
-    m |= (((t * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+    m |= __builtin_amdgcn_udot4(t, 0x08040201u, 0u, false) << (4 * q);
   }
   return nvalid >= 16 ? m : (m & ((1u << nvalid) - 1u));
 }

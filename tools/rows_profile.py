@@ -32,6 +32,7 @@ for what in ("encode", "decode"):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n * 1e3
     eng.profile(False)
-    st = {k: round(v[0] / max(v[1], 1), 4) for k, v in sorted(eng.profile_read().items(), key=lambda kv: -kv[1][0] / max(kv[1][1], 1))}
+    # per frame (n profiled frames): a kernel launched twice per frame counts with both launches
+    st = {k: round(v[0] / n, 4) for k, v in sorted(eng.profile_read().items(), key=lambda kv: -kv[1][0])}
     res[what] = {"ms_per_frame": round(dt, 3), "stages_ms": st}
 print(json.dumps(res, indent=1))
