@@ -942,14 +942,16 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
 // the 261 token bins at the end.  Longer runs are counted token by token.
 __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
-  __shared__ uint32_t hist2[kPairRuns + 1][256];   // [zeros in front, kPairRuns = that many or more][literal]
+  // [zeros in front, kPairRuns = that many or more][literal]; rows 257 words apart: the
+  // hot literals (+-1, +-2) of the eight rows then lie in different banks.
+  __shared__ uint32_t hist2[kPairRuns + 1][257];
   __shared__ uint32_t hrun[kRunTab + 1];   // runs of kPairRuns..278 zeros, by exact length
   __shared__ uint32_t s_sym[8 * 256];      // [word][lane]: the lane's 32 symbols of this iteration
   __shared__ ZR sm[4];
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
   for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
-  for (int k = threadIdx.x; k < (kPairRuns + 1) * 256; k += 256) (&hist2[0][0])[k] = 0;
+  for (int k = threadIdx.x; k < (kPairRuns + 1) * 257; k += 256) (&hist2[0][0])[k] = 0;
   for (int k = threadIdx.x; k < kRunTab + 1; k += 256) hrun[k] = 0;
   ZR carry;
   carry.tz = span_carry_in(g, ws, sp, f);
