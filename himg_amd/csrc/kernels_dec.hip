@@ -1783,7 +1783,7 @@ __host__ __device__ inline FusedLayout fused_layout(int row_block, int rows = 1)
   L.sh = carve((uint32_t)sizeof(StreamShared));
   L.unmap = carve(512u);
   L.shift = carve(128u);
-  L.shiftp = carve(256u);
+  L.shiftp = carve(256u + 16u);   // 2 x 32 packed shift pairs, then kHfast words (tile_plane's identity test)
   L.total = o;
   return L;
 }
@@ -1862,24 +1862,76 @@ __device__ __forceinline__ void lowres_quads(uint32_t lr0, uint32_t lr8, uint32_
 // slot: the tile's first symbol (scan index k is at slot[k * cols]); shift: the
 // 64 per-position shifts; shiftp: the same as 32 packed pairs in V order; lr0 /
 // lr8: (left, right) low-res samples of this and the next block row in bytes 0, 1.
+// hfast (COLS only): {bias pair, mask pair} of the identity test below.
 template <int COLS>
 __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, const int16_t *s_unmap,
                                            const uint8_t *shift, const uint32_t *shiftp,
-                                           uint32_t lr0, uint32_t lr8, uint32_t O[16]) {
+                                           uint32_t lr0, uint32_t lr8, uint32_t O[16],
+                                           const uint32_t *hfast = nullptr) {
   const int cols = COLS ? COLS : cols_rt;
   // Gather + dequantise (quantize.cpp:153-165: int16 wrap == 16-bit shift left).
   dpk16 V[32];
   uint32_t acc = 0;
-  {
-    uint32_t W[32];
-    if (COLS) {
+  if (COLS) {
+    // The companding table is the identity for small codes (mapper.cpp:54-61: up to
+    // 49 in the encoder's table; the decoder derives the range from the stream's
+    // FMAP), and everything but the lowest frequencies of a tile IS small.  The 21
+    // register pairs that hold rows 2..7 of columns 1..7 (group H) are therefore
+    // loaded as sign-extended bytes straight into the packed halves
+    // (ds_read_i8_d16 / _d16_hi: no look-up, no address arithmetic, no v_perm) and
+    // tested ONCE per plane and wavefront: every code in [-B, B) with B a power of
+    // two inside the identity range and B << (largest H shift) <= 4096, so the test
+    // also stands for the 16-bit range check of these coefficients.  A wavefront
+    // with a larger code in H takes the look-ups for H as well.  Group L (rows 0, 1
+    // and column 0: the DC and first-order coefficients, large in most tiles)
+    // always goes through the table.
+    const uint32_t hb = hfast[0], hm = hfast[1];
+    uint32_t W[32], hacc = 0;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int x = e >> 2, j = e & 3, p0 = (2 * j) * 8 + x;
+      const uint8_t *q0 = slot + (size_t)kInvScanD[p0] * cols, *q1 = slot + (size_t)kInvScanD[p0 + 8] * cols;
+      if (x == 0 || j == 0) {
+        W[e] = (uint32_t)(uint16_t)s_unmap[*q0] | ((uint32_t)(uint16_t)s_unmap[*q1] << 16);
+      } else {
+        dpk16 w;
+        w.x = (short)(int8_t)*q0;
+        w.y = (short)(int8_t)*q1;
+        W[e] = __builtin_bit_cast(uint32_t, w);
+        hacc |= __builtin_bit_cast(uint32_t, (dupk16)(__builtin_bit_cast(dupk16, w) + __builtin_bit_cast(dupk16, hb)));
+      }
+    }
+    const bool hslow = __any((hacc & hm) != 0u);
+    if (__builtin_expect(hslow, 0)) {
 #pragma unroll
       for (int e = 0; e < 32; ++e) {
-        const int x = e >> 2, j = e & 3, p0 = (2 * j) * 8 + x;
-        const int c0 = slot[(size_t)kInvScanD[p0] * cols], c1 = slot[(size_t)kInvScanD[p0 + 8] * cols];
-        W[e] = (uint32_t)(uint16_t)s_unmap[c0] | ((uint32_t)(uint16_t)s_unmap[c1] << 16);
+        const int x = e >> 2, j = e & 3;
+        if (x == 0 || j == 0) continue;
+        W[e] = (uint32_t)(uint16_t)s_unmap[W[e] & 255u] | ((uint32_t)(uint16_t)s_unmap[(W[e] >> 16) & 255u] << 16);
       }
-    } else {
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int x = e >> 2, j = e & 3;
+      const dupk16 d = __builtin_bit_cast(dupk16, W[e]) << __builtin_bit_cast(dupk16, shiftp[e]);
+      V[e] = __builtin_bit_cast(dpk16, d);
+      if (x == 0 || j == 0) {
+        const dupk16 bias = {0x1000, 0x1000};
+        acc |= __builtin_bit_cast(uint32_t, (dupk16)(d + bias));
+      }
+    }
+    if (__builtin_expect(hslow, 0)) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const int x = e >> 2, j = e & 3;
+        if (x == 0 || j == 0) continue;
+        const dupk16 bias = {0x1000, 0x1000};
+        acc |= __builtin_bit_cast(uint32_t, (dupk16)(__builtin_bit_cast(dupk16, V[e]) + bias));
+      }
+    }
+  } else {
+    uint32_t W[32];
+    {
       // Run-time column count: walk the slots in scan order with one running
       // pointer (64 separate offsets would not stay in registers).
 #pragma unroll
@@ -1980,12 +2032,15 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
 __device__ __forceinline__ int pair_tile(int it) { return (it >> 6) * 32 + (it & 31); }
 __device__ __forceinline__ int pair_half(int it) { return (it >> 5) & 1; }
 
-template <int COLS>
+// FULL4: four channels, whole tiles only (W and H multiples of 8) -- the ragged-edge
+// stores and the channel-count tests are compiled out.
+template <int COLS, bool FULL4 = false>
 __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt, const uint8_t *sym,
                                                      const uint8_t *low, const int16_t *s_unmap,
                                                      const uint8_t *s_shift, const uint32_t *s_shiftp,
                                                      int ycbcr, int u, int s, int v, uint8_t *img) {
   const int cols = COLS ? COLS : cols_rt;
+  const int C = FULL4 ? 4 : g.C;
   const int v2 = min(v + 1, g.rows - 1);
     const int u2 = min(u + 1, cols - 1);
     uint32_t QA[16], QB[16];
@@ -1993,13 +2048,13 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
     for (int cc = 0; cc < 2; ++cc) {
       const int c = 2 * s + cc;
       uint32_t O[16];
-      if (c < g.C) {
+      if (FULL4 || c < C) {
         const uint8_t *m = low + (size_t)c * g.rows * cols;
         const int chroma = (ycbcr && (c == 1 || c == 2)) ? 1 : 0;  // decoder.cpp:376
         uint32_t lr0 = (uint32_t)m[(size_t)v * cols + u] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
         uint32_t lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
         tile_plane<COLS>(sym + (size_t)c * 64 * cols + u, cols, s_unmap, s_shift + chroma * 64,
-                         s_shiftp + chroma * 32, lr0, lr8, O);
+                         s_shiftp + chroma * 32, lr0, lr8, O, COLS ? s_shiftp + 64 + 2 * chroma : nullptr);
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = 0;
@@ -2024,8 +2079,8 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
       ch0[i] = ra[0]; ch2[i] = ra[1];
       ch1[i] = rb[0]; ch3[i] = rb[1];
     }
-    const int bw = min(8, g.W - 8 * u);
-    const int bh = min(8, g.H - 8 * v);
+    const int bw = FULL4 ? 8 : min(8, g.W - 8 * u);
+    const int bh = FULL4 ? 8 : min(8, g.H - 8 * v);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int y = 4 * s + rr;
@@ -2061,9 +2116,9 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
           px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
         }
       }
-      if (y < bh) {
-        uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * g.C;
-        if (g.C == 4 && bw == 8) {
+      if (FULL4 || y < bh) {
+        uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * C;
+        if (FULL4 || (C == 4 && bw == 8)) {
           uint4 o0, o1;
           o0.x = px[0]; o0.y = px[1]; o0.z = px[2]; o0.w = px[3];
           o1.x = px[4]; o1.y = px[5]; o1.z = px[6]; o1.w = px[7];
@@ -2073,7 +2128,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
 #pragma unroll
           for (int x = 0; x < 8; ++x)
             if (x < bw)
-              for (int c = 0; c < g.C; ++c) dst[x * g.C + c] = (uint8_t)(px[x] >> (8 * c));
+              for (int c = 0; c < C; ++c) dst[x * C + c] = (uint8_t)(px[x] >> (8 * c));
         }
       }
     }
@@ -2154,6 +2209,28 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     // The same shifts as packed pairs in tile_plane's register order.
     const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
     s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
+  } else if (tid < 512) {
+    // tile_plane's identity test (one wavefront).  n = the largest code with
+    // fmap[i] == i for all i <= n (mapper.h:33-35: a code unmaps to itself there);
+    // B = the largest power of two <= n, lowered until B << (largest shift of group H:
+    // rows 2..7 of columns 1..7) <= 4096.  Words: (B, B), then the mask of the bits
+    // that a sum code + B outside [0, 2B) sets.  No usable range: the test always fails.
+    const int l = tid - 448;
+    const unsigned long long ne = __ballot(df->fmap[l] != l), ne2 = __ballot(df->fmap[64 + l] != 64 + l);
+    const int n = ne ? __ffsll((long long)ne) - 2 : (ne2 ? 62 + __ffsll((long long)ne2) : 127);
+    if (l < 2) {
+      int smax = 0;
+      for (int y = 2; y < 8; ++y)
+        for (int x = 1; x < 8; ++x) smax = max(smax, (int)df->shift[l][y * 8 + x]);
+      int B = 0;
+      if (n >= 1) {
+        B = 1 << (31 - __clz(n));
+        while (B && ((long long)B << smax) > 4096) B >>= 1;
+      }
+      const uint32_t b16 = B ? (uint32_t)B : 0x4000u, m16 = B ? (uint32_t)(0xffffu & ~(2u * B - 1u)) : 0xffffu;
+      s_shiftp[64 + 2 * l] = b16 | (b16 << 16);
+      s_shiftp[64 + 2 * l + 1] = m16 | (m16 << 16);
+    }
   }
   const GrpTables tb = tables_of(&T);
   const int rb = r0 + (int)blockIdx.x * rpw;
@@ -2204,8 +2281,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   for (int it = tid; it < per_row * nr; it += kDecThreads) {
     const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
     if (pair_tile(il) < cols)
-      transform_store_pair<COLS>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
-                                 pair_tile(il), pair_half(il), rb + i, img);
+      transform_store_pair<COLS, COLS == 512>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
+                                              pair_tile(il), pair_half(il), rb + i, img);
   }
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
@@ -2548,7 +2625,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     while (rpw < 8 && (rpw + 1) * per_row <= kDecThreads && fused_layout(g.row_block, rpw + 1).total <= kLdsMax) ++rpw;
     static const int rpw_env = getenv("HIMG_ROWS_PER_FUSED") ? atoi(getenv("HIMG_ROWS_PER_FUSED")) : 0;
     if (rpw_env > 0 && rpw_env < rpw) rpw = rpw_env;
-    if (g.cols == 512 && g.C == 4) rpw = 1;
+    if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) rpw = 1;
     const uint32_t lds = fused_layout(g.row_block, rpw).total;
     prof_begin(prof, "k_dec_row_fused", stream);
 #define HIMG_FUSED_LAUNCH(COLS)                                                                 \
@@ -2560,7 +2637,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                        d_out, r0, r1, rpw);                                                     \
   } while (0)
     if (nrows > 0) {
-      if (g.cols == 512 && g.C == 4) HIMG_FUSED_LAUNCH(512);
+      if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) HIMG_FUSED_LAUNCH(512);   // whole tiles only (FULL4)
       else HIMG_FUSED_LAUNCH(0);
     }
 #undef HIMG_FUSED_LAUNCH

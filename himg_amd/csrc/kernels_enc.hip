@@ -23,11 +23,13 @@
 namespace himg_dev {
 
 // L-shell coefficient scan order (reference common.cpp:13-22; part of the format).
-__device__ static constexpr uint8_t kScan[64] = {
-    0,  1,  9,  8,  16, 17, 18, 10, 2,  3,  11, 19, 27, 26, 25, 24,
-    32, 33, 34, 35, 36, 28, 20, 12, 4,  5,  13, 21, 29, 37, 45, 44,
-    43, 42, 41, 40, 48, 49, 50, 51, 52, 53, 54, 46, 38, 30, 22, 14,
-    6,  7,  15, 23, 31, 39, 47, 55, 63, 62, 61, 60, 59, 58, 57, 56};
+#define HIMG_SCAN_ORDER                                                  \
+    0,  1,  9,  8,  16, 17, 18, 10, 2,  3,  11, 19, 27, 26, 25, 24,     \
+    32, 33, 34, 35, 36, 28, 20, 12, 4,  5,  13, 21, 29, 37, 45, 44,     \
+    43, 42, 41, 40, 48, 49, 50, 51, 52, 53, 54, 46, 38, 30, 22, 14,     \
+    6,  7,  15, 23, 31, 39, 47, 55, 63, 62, 61, 60, 59, 58, 57, 56
+__device__ static constexpr uint8_t kScan[64] = {HIMG_SCAN_ORDER};
+static constexpr uint8_t kScanHost[64] = {HIMG_SCAN_ORDER};   // the same for host code
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -501,12 +503,31 @@ __device__ __forceinline__ pk16 pix_pair(uint32_t px) {
 constexpr int kPixThreads = 256;
 constexpr int kPixLut = 8192;
 
+// The quantiser's per-coefficient constants as packed pairs in SCAN order, [0] luma /
+// [1] chroma (quantize.cpp:127-151): rounding term r = s ? 1 << (s - 1) : 0, sign
+// factor k = [s > 0], shift s -- each in both halves of a word.  Kernel arguments:
+// scalar loads, nothing derived per coefficient in the kernel.
+struct PixQuant {
+  uint32_t rr[2][64], kk[2][64], ss[2][64];
+};
+static PixQuant make_pix_quant(const ShiftTables &st) {
+  PixQuant pq;
+  for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t sft = st.s[t][kScanHost[i]], r = sft ? 1u << (sft - 1) : 0u, k = sft ? 1u : 0u;
+      pq.rr[t][i] = r | (r << 16);
+      pq.kk[t][i] = k | (k << 16);
+      pq.ss[t][i] = sft | (sft << 16);
+    }
+  return pq;
+}
+
 template <bool YCBCR, int COLS, bool FULL>
 __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_t *frames,
                                                             const uint8_t *low, size_t plane_stride,
                                                             uint8_t *fres_sym, size_t fres_stride,
                                                             const uint8_t *__restrict__ fmap_lut,
-                                                            ShiftTables st, int v0) {
+                                                            PixQuant pq, int v0) {
   // Companding LUT for magnitudes below kPixLut (every larger one maps to 127:
   // the full-res table tops out at 8039, mapper.cpp:54-71,159-182).
   __shared__ __attribute__((aligned(16))) uint8_t s_lut[kPixLut];
@@ -557,8 +578,6 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
     // Channels in the low / high half of this pair, and their shift table.
     const int cA = YCBCR ? (pr == 0 ? 2 : 0) : (pr == 0 ? 0 : 1);
     const int cB = YCBCR ? (pr == 0 ? 1 : 3) : (pr == 0 ? 2 : 3);
-    const uint8_t *sh = st.s[(YCBCR && pr == 0) ? 1 : 0];
-
     pk16 b[64];
     {
       uint32_t LA[2][8], LB[2][8];
@@ -585,37 +604,65 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
       wht8_pk(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
 
     const uint32_t offA = row_off + (uint32_t)(cA * 64 * cols), offB = row_off + (uint32_t)(cB * 64 * cols);
-    for_seq<64>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      constexpr int pos = kScan[i];
-      const int s = sh[pos];                                  // wave-uniform
-      const short r = (short)(s ? (1 << (s - 1)) : 0);
-      const short adj = (short)(s ? -1 : 0);
-      const pk16 x = b[pos];
-      const pk16 fifteen = {15, 15};
-      const pk16 sign = x >> fifteen;                         // 0 or -1 per half
-      const pk16 rr = {r, r}, aa = {adj, adj}, ss = {(short)s, (short)s};
-      pk16 q = (x + rr + (sign & aa)) >> ss;                  // sign * ((|x| + r) >> s)
-      // Companding (mapper.cpp:159-182): the identity while |q| <= 50.  t = q + 50 as
-      // unsigned is <= 100 exactly then; the saturating subtract leaves a non-zero
-      // dword iff a half is beyond -- one wave-uniform branch per coefficient, taken
-      // for the few low-frequency coefficients of high-contrast tiles.
-      const upk16 fifty = {50, 50}, hundred = {100, 100};
-      const upk16 over = __builtin_elementwise_sub_sat((upk16)(__builtin_bit_cast(upk16, q) + fifty), hundred);
-      if (__builtin_expect(__any(__builtin_bit_cast(uint32_t, over) != 0u), 0)) {
-        const pk16 mag = (q ^ sign) - sign;
-        const uint32_t ma = min((uint32_t)(uint16_t)mag.x, (uint32_t)(kPixLut - 1));
-        const uint32_t mb = min((uint32_t)(uint16_t)mag.y, (uint32_t)(kPixLut - 1));
-        pk16 code;                                            // the LUT is the identity below 51
-        code.x = (short)s_lut[ma];
-        code.y = (short)s_lut[mb];
-        q = (code ^ sign) - sign;
+    // Quantise (quantize.cpp:127-151), compand (mapper.cpp:159-182) and store, in
+    // groups of coefficients in scan order.  sign * ((|x| + r) >> s) is branch free:
+    // (x + r + sign * k) >> s with sign = x >> 15 and k = [s > 0]; r, k and s come
+    // as packed pairs from the kernel arguments (pq, scan order).  Companding is the
+    // identity while |q| <= 50; the group keeps the largest q + 50 (as unsigned: <=
+    // 100 exactly then) and ONE wave-uniform branch per group sends the group
+    // through the LUT -- the first sixteen coefficients (DC and first order, the
+    // ones high-contrast tiles push beyond 50) in groups of four, the rest in
+    // sixteens.  (A test per coefficient was 128 compare + branch pairs per tile,
+    // each behind hazard no-ops, and 128 basic blocks the scheduler could not
+    // interleave across.)
+    const int qt = (YCBCR && pr == 0) ? 1 : 0;
+    auto group = [&](auto i0c, auto nc) {
+      constexpr int I0 = decltype(i0c)::value, N = decltype(nc)::value;
+      pk16 q[N];
+      upk16 top = {0, 0};
+      for_seq<N>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, i = I0 + k, pos = kScan[i];
+        const pk16 x = b[pos];
+        const pk16 fifteen = {15, 15};
+        const pk16 sign = x >> fifteen;                       // 0 or -1 per half
+        const pk16 rr = __builtin_bit_cast(pk16, pq.rr[qt][i]), kk = __builtin_bit_cast(pk16, pq.kk[qt][i]);
+        const pk16 ss = __builtin_bit_cast(pk16, pq.ss[qt][i]);
+        q[k] = (sign * kk + x + rr) >> ss;
+        const upk16 fifty = {50, 50};
+        top = __builtin_elementwise_max(top, (upk16)(__builtin_bit_cast(upk16, q[k]) + fifty));
+      });
+      const upk16 hundred = {100, 100};
+      const uint32_t over = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(top, hundred));
+      if (__builtin_expect(__any(over != 0u), 0)) {
+        for_seq<N>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          const pk16 fifteen = {15, 15};
+          const pk16 sign = q[k] >> fifteen;
+          const pk16 mag = (q[k] ^ sign) - sign;
+          const uint32_t ma = min((uint32_t)(uint16_t)mag.x, (uint32_t)(kPixLut - 1));
+          const uint32_t mb = min((uint32_t)(uint16_t)mag.y, (uint32_t)(kPixLut - 1));
+          pk16 code;                                          // the LUT is the identity below 51
+          code.x = (short)s_lut[ma];
+          code.y = (short)s_lut[mb];
+          q[k] = (code ^ sign) - sign;
+        });
       }
       if (valid) {
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q.x, sym_rsrc, lane_off, offA + (uint32_t)(i * cols), 0);
-        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q.y, sym_rsrc, lane_off, offB + (uint32_t)(i * cols), 0);
+        for_seq<N>([&](auto kc) {
+          constexpr int k = decltype(kc)::value, i = I0 + k;
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q[k].x, sym_rsrc, lane_off, offA + (uint32_t)(i * cols), 0);
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q[k].y, sym_rsrc, lane_off, offB + (uint32_t)(i * cols), 0);
+        });
       }
-    });
+    };
+    using std::integral_constant;
+    group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+    group(integral_constant<int, 4>{}, integral_constant<int, 4>{});
+    group(integral_constant<int, 8>{}, integral_constant<int, 4>{});
+    group(integral_constant<int, 12>{}, integral_constant<int, 4>{});
+    group(integral_constant<int, 16>{}, integral_constant<int, 16>{});
+    group(integral_constant<int, 32>{}, integral_constant<int, 16>{});
+    group(integral_constant<int, 48>{}, integral_constant<int, 16>{});
   }
 }
 
@@ -1751,9 +1798,10 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
                        Profiler *prof) {
   const unsigned gxt = (unsigned)((g.cols + kPixThreads - 1) / kPixThreads);
   const dim3 grid(gxt, n, batch), block(kPixThreads);
+  const PixQuant pq = make_pix_quant(st);
 #define HIMG_PIX(Y, COLS, FULL)                                                                  \
   HIMG_LAUNCH_PAD((k_pix_fwd<Y, COLS, FULL>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
-              ws.fres_stride, d_fmap_lut, st, r0)
+              ws.fres_stride, d_fmap_lut, pq, r0)
   const bool full = g.cols % 64 == 0;
   if (g.ycbcr) { if (g.cols == 512) HIMG_PIX(true, 512, true); else if (full) HIMG_PIX(true, 0, true); else HIMG_PIX(true, 0, false); }
   else { if (full) HIMG_PIX(false, 0, true); else HIMG_PIX(false, 0, false); }

@@ -1,6 +1,9 @@
 // Issue rate of the VALU instructions the codec kernels lean on (MI355X).
-// Each wave runs 8 independent dependency chains of one opcode; with 8 waves per
-// SIMD the result is wave-instructions per SIMD-cycle (1/4 = full rate for wave64).
+// Each wave runs 8 independent dependency chains of one opcode.  For 1, 2, 4 and 8
+// waves per SIMD the program prints the SIMD's issue interval in SHADER CYCLES per
+// wave64 instruction, measured inside the kernel with s_memtime (clock64: one tick
+// per shader cycle, so DVFS does not enter), and beside it the same figure from the
+// wall clock at a nominal 2.4 GHz.  2.0 = the SIMD-32 rate of MI355X_MICROARCH.md.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/micro/valu_rate.hip -o tools/micro/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -70,7 +73,8 @@
 #define OP_X52(x) asm volatile("v_ashrrev_i16 %0, 3, %0" : "+v"(x));
 
 template <int WHICH>
-__global__ __launch_bounds__(512) void k_rate(uint32_t *out, int iters, uint32_t k, uint32_t sel) {
+__global__ __launch_bounds__(256) void k_rate(uint32_t *out, int iters, uint32_t k, uint32_t sel, unsigned long long *cyc) {
+  const long long c0 = clock64();
   unsigned long long ya0 = threadIdx.x, ya1 = ya0 * 3, ya2 = ya0 * 5, ya3 = ya0 * 7, ya4 = ya0 * 9, ya5 = ya0 * 11, ya6 = ya0 * 13, ya7 = ya0 * 17;
   uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   if (WHICH == 0) { CHAIN8(OP_ADD) }
@@ -126,29 +130,46 @@ __global__ __launch_bounds__(512) void k_rate(uint32_t *out, int iters, uint32_t
   if (WHICH == 50) { CHAIN8(OP_X50) }
   if (WHICH == 51) { CHAIN8(OP_X51) }
   if (WHICH == 52) { CHAIN8(OP_X52) }
+  const long long c1 = clock64();
+  if ((threadIdx.x & 63) == 0) atomicMax(cyc, (unsigned long long)(c1 - c0));
   out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(ya0 ^ ya1 ^ ya2 ^ ya3 ^ ya4 ^ ya5 ^ ya6 ^ ya7) ^ a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
 template <int WHICH>
 static void run(const char *name, uint32_t *d_out) {
-  const int iters = 2000, blocks = 256 * 4, threads = 512;   // 4 x 8 waves per CU = 8 per SIMD
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, d_out, 10, 3u, 0x05040100u);
-  hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 3u, 0x05040100u);
-  hipEventRecord(e1, 0);
-  hipEventSynchronize(e1);
-  float ms = 0;
-  hipEventElapsedTime(&ms, e0, e1);
-  const double winstr = (double)blocks * (threads / 64) * iters * 64.0;   // wave-instructions
-  const double per_simd_cycle = winstr / (ms * 1e-3 * 2.4e9 * 256 * 4);
-  printf("%-20s %.3f ms  %.3f wave-instr per SIMD-cycle (at 2.4 GHz; 0.25 = full rate)\n", name, ms, per_simd_cycle);
+  // Blocks of 256 threads = one wave per SIMD; W blocks per CU = W waves per SIMD.
+  const int iters = 2000;
+  unsigned long long *d_cyc;
+  hipMalloc(&d_cyc, 8);
+  printf("%-24s", name);
+  for (int W = 1; W <= 8; W *= 2) {
+    const int blocks = 256 * W, threads = 256;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, d_out, 10, 3u, 0x05040100u, d_cyc);
+    hipMemset(d_cyc, 0, 8);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_rate<WHICH>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 3u, 0x05040100u, d_cyc);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long cyc = 0;
+    hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost);
+    const double per_wave = (double)iters * 64.0;              // instructions of one wave
+    const double in_kernel = (double)cyc / (per_wave * W);     // shader cycles per SIMD issue (slowest wave)
+    const double wall = ms * 1e-3 * 2.4e9 / (per_wave * W);    // the same from the wall clock at 2.4 GHz
+    printf("  W=%d: %5.2f cyc (wall %5.2f)", W, in_kernel, wall);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  printf("\n");
+  hipFree(d_cyc);
 }
 
 int main() {
   uint32_t *d_out;
-  hipMalloc(&d_out, 256 * 4 * 512 * 4);
+  hipMalloc(&d_out, 256 * 8 * 256 * 4);
+  printf("# SIMD issue interval per wave64 instruction, shader cycles (s_memtime), W waves per SIMD; 8 independent chains per wave\n");
   run<0>("v_add_u32", d_out);
   run<1>("v_pk_add_u16", d_out);
   run<2>("v_pk_sub_i16", d_out);
