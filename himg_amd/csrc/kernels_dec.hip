@@ -1209,6 +1209,12 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
   if (bad) sh->err = 1;
 }
 
+// k_row_count's record of one lane of a row (see decode_stream's pre_start / pre_off),
+// in registers.
+struct PreLane {
+  uint32_t start, off, nxt, tot, endrel, valid, rounds;
+};
+
 // Decode one whole stream with one workgroup, chunk after chunk (each chunk's
 // first token position is exact because the previous chunk has finished).  The
 // sub-sequence length is chosen so that the 1024 lanes cover the remaining payload
@@ -1226,7 +1232,8 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
                              uint32_t *stats, uint32_t max_sub, uint32_t lead_bits,
-                             const uint32_t *pre_start = nullptr, const uint32_t *pre_off = nullptr) {
+                             const uint32_t *pre_start = nullptr, const uint32_t *pre_off = nullptr,
+                             const PreLane *pl = nullptr) {
   const int tid = threadIdx.x;
   if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
   __syncthreads();
@@ -1256,8 +1263,16 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
 
     uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0;
     unsigned long long tot, off;
-    const bool pre = pre_off && cur == 0 && pre_off[kDecThreads + 2] != 0;
-    if (pre) {
+    const bool pre = cur == 0 && (pl ? pl->valid != 0 : (pre_off && pre_off[kDecThreads + 2] != 0));
+    if (pre && pl) {
+      // The same record, loaded by the caller before its first barrier.
+      start = rel0 + pl->start;
+      off = pl->off;
+      cnt = pl->nxt - pl->off;
+      tot = pl->tot;
+      if (tid == last_active) endpos = rel0 + pl->endrel;
+      st_rounds += pl->rounds;
+    } else if (pre) {
       // One chunk, fixpoint done by k_row_count at twice the occupancy.
       start = rel0 + pre_start[tid];
       off = pre_off[tid];
@@ -1325,7 +1340,7 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
                                                 LdsTables *T) {
   const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
-  const int nn = df->s[strm].num_nodes;
+  const int nn = min(df->s[strm].num_nodes, kMaxNodes + 1);   // (a frame that failed to parse holds anything)
   for (int k = threadIdx.x; k < nn; k += kDecThreads)
     T->nd[k] = pack_node(nodes[3 * k + 0], nodes[3 * k + 1], nodes[3 * k + 2]);
   const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + strm) * (1u << kLutBits));
@@ -2038,7 +2053,8 @@ template <int COLS, bool FULL4 = false>
 __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt, const uint8_t *sym,
                                                      const uint8_t *low, const int16_t *s_unmap,
                                                      const uint8_t *s_shift, const uint32_t *s_shiftp,
-                                                     int ycbcr, int u, int s, int v, uint8_t *img) {
+                                                     int ycbcr, int u, int s, int v, uint8_t *img,
+                                                     const uint32_t *pre_lr = nullptr) {
   const int cols = COLS ? COLS : cols_rt;
   const int C = FULL4 ? 4 : g.C;
   const int v2 = min(v + 1, g.rows - 1);
@@ -2051,8 +2067,13 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
       if (FULL4 || c < C) {
         const uint8_t *m = low + (size_t)c * g.rows * cols;
         const int chroma = (ycbcr && (c == 1 || c == 2)) ? 1 : 0;  // decoder.cpp:376
-        uint32_t lr0 = (uint32_t)m[(size_t)v * cols + u] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
-        uint32_t lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
+        uint32_t lr0, lr8;
+        if (pre_lr) {   // (inlined: a compile-time choice)
+          lr0 = pre_lr[2 * cc]; lr8 = pre_lr[2 * cc + 1];
+        } else {
+          lr0 = (uint32_t)m[(size_t)v * cols + u] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
+          lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
+        }
         tile_plane<COLS>(sym + (size_t)c * 64 * cols + u, cols, s_unmap, s_shift + chroma * 64,
                          s_shiftp + chroma * 32, lr0, lr8, O, COLS ? s_shiftp + 64 + 2 * chroma : nullptr);
       } else {
@@ -2195,9 +2216,34 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const int f = blockIdx.y, tid = threadIdx.x;
   const long long c_in = clock64();
   DecFrame *df = ws.frames + f;
+  const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
+  // 4096-pixel rows: one row per workgroup, every lane knows its tile from the start.
+  // Everything the row needs from global memory is requested HERE, in front of the
+  // first barrier -- the frame's verdict, k_row_count's lane record, the row index,
+  // the low-res corners of the lane's two planes, the tables -- so that the round
+  // trips overlap instead of following each other (each is 1-2 us of a 43 us row).
+  PreLane pl = {};
+  uint32_t pre_lr[4] = {0, 0, 0, 0}, pre_off0 = 0, pre_len0 = 0;
+  if constexpr (COLS == 512) {
+    const size_t ri = (size_t)f * g.rows + (size_t)(r0 + (int)blockIdx.x);
+    const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + 4);
+    pl.start = ps[tid]; pl.off = po[tid]; pl.nxt = po[tid + 1];
+    pl.tot = po[kDecThreads]; pl.endrel = po[kDecThreads + 1]; pl.valid = po[kDecThreads + 2]; pl.rounds = po[kDecThreads + 3];
+    pre_off0 = ws.row_off[ri]; pre_len0 = ws.row_len[ri];
+    const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + (int)blockIdx.x;
+    const int u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const uint8_t *m = low + (size_t)(2 * hs + cc) * g.rows * COLS;
+      pre_lr[2 * cc] = (uint32_t)m[(size_t)v * COLS + u] | ((uint32_t)m[(size_t)v * COLS + u2] << 8);
+      pre_lr[2 * cc + 1] = (uint32_t)m[(size_t)v2 * COLS + u] | ((uint32_t)m[(size_t)v2 * COLS + u2] << 8);
+    }
+  }
   if (tid == 0) sh->flag = df->status;
-  __syncthreads();
-  if (sh->flag) return;
+  if constexpr (COLS != 512) {
+    __syncthreads();
+    if (sh->flag) return;
+  }
   const uint8_t *p = packed + (size_t)f * in_stride;
   load_dec_tables(ws, df, f, 1, &T);
   if (tid < 256) {
@@ -2242,6 +2288,9 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym0)[k] = z;
   }
   __syncthreads();
+  if constexpr (COLS == 512) {
+    if (sh->flag) return;   // (uniform: one read, in front of the barrier above)
+  }
 
   auto decode_row = [&](int i) {
     const int r = rb + i;
@@ -2249,6 +2298,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
       st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
     }
+    if constexpr (COLS == 512)
+      return decode_stream<true>(
+          p, sizes[f], pre_off0, pre_len0, (uint32_t)g.row_block, tb, sh, sym0, nullptr, nullptr,
+          ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
+          nullptr, nullptr, &pl);
     return decode_stream<true>(
         p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
         (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, nullptr, nullptr,
@@ -2275,14 +2329,14 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   // Two adjacent lanes share a tile (transform_store_pair).  The decoded symbols
   // stay read-only in LDS: no barrier, no second pass over them.
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
-  const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
   const int per_row = ((cols + 31) >> 5) * 64;   // whole wavefronts: a lane pair never straddles rows
 #pragma unroll 1
   for (int it = tid; it < per_row * nr; it += kDecThreads) {
     const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
     if (pair_tile(il) < cols)
       transform_store_pair<COLS, COLS == 512>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
-                                              pair_tile(il), pair_half(il), rb + i, img);
+                                              pair_tile(il), pair_half(il), rb + i, img,
+                                              COLS == 512 ? pre_lr : nullptr);
   }
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
