@@ -1094,6 +1094,28 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
   if (!(bp < lim) || op >= out_size) return true;
   rd.init(bp);
   bool bad = false;
+  // Whole groups first, as long as the block stays incomplete behind them: this lane is
+  // alone on its path while fifteen wavefronts wait at the barrier behind the write
+  // pass -- token by token over its whole range (~50 tokens, each a dependent LDS
+  // round trip) it was HALF of that pass.  The group that completes (or overruns) the
+  // block is not taken: the reader is put back in front of it and the loop below goes
+  // through it token by token with the reference's checks.
+  {
+    const int limk = (int)lim - kLutBits;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
+    while ((int)bp <= limk) {
+      const GReader saved = rd;
+      uint32_t nbits, cnt, by;
+      bool gbad = false;
+      lean_step<true>(rd, t, false, &nbits, &cnt, &by, &gbad);
+      if (gbad || op + cnt >= out_size) { rd = saved; break; }
+      const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
+      atomicOr(&o32[op >> 2], (uint32_t)v);
+      atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      op += cnt;
+      bp += nbits;
+    }
+  }
   for (;;) {
     uint32_t nbits, cnt, by;
     lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
