@@ -1231,6 +1231,32 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
   if (bad) sh->err = 1;
 }
 
+// The kDecThreads sub-sequences of one chunk of `bits` payload bits (`sb` bits each,
+// bits <= kDecThreads * sb).  The boundaries lie at k * sb - S: the whole grid is moved
+// to the left so that the LAST active lane is left with kTailBits -- that lane ends up
+// alone on the token-by-token path that completes the block (exact_write) while every
+// other wavefront of the row waits for it, so its range is kept as short as the grid
+// allows (lane 0 takes what is cut off; no shift when that would need a 1025th lane).
+// Every kernel that walks a chunk derives the same grid from (bits, sb).
+constexpr uint32_t kTailBits = 48;
+struct SubGrid {
+  uint32_t b0, lim;     // this lane's range [b0, lim), window bit positions
+  bool active;
+  int last_active;
+};
+__device__ __forceinline__ SubGrid sub_grid(uint32_t rel0, uint32_t bits, uint32_t sb, int tid) {
+  SubGrid q;
+  const uint32_t la = (bits - 1u) / sb, L = bits - la * sb;
+  const uint32_t S = (L > kTailBits && la + 1u < (uint32_t)kDecThreads) ? sb - (L - kTailBits) : 0u;
+  const uint32_t rel_end = rel0 + bits;
+  q.b0 = tid ? rel0 + (uint32_t)tid * sb - S : rel0;
+  q.lim = rel0 + (uint32_t)(tid + 1) * sb - S;
+  if (q.lim > rel_end) q.lim = rel_end;
+  q.active = q.b0 < rel_end;
+  q.last_active = (int)((bits - 1u + S) / sb);
+  return q;
+}
+
 // k_row_count's record of one lane of a row (see decode_stream's pre_start / pre_off),
 // in registers.
 struct PreLane {
@@ -1277,11 +1303,10 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     sub = sub < kMinSubBits ? kMinSubBits : (sub > max_sub ? max_sub : sub);
     const unsigned long long chunk_bits = (unsigned long long)sub * kDecThreads;
     const uint32_t rel_end = rel0 + (uint32_t)(rem < chunk_bits ? rem : chunk_bits);
-    const uint32_t my_b0 = rel0 + (uint32_t)tid * sub;
-    uint32_t lim = my_b0 + sub;
-    if (lim > rel_end) lim = rel_end;
-    const bool active = my_b0 < rel_end;
-    const int last_active = (int)((rel_end - rel0 - 1u) / sub);
+    const SubGrid sg = sub_grid(rel0, rel_end - rel0, sub, tid);
+    const uint32_t my_b0 = sg.b0, lim = sg.lim;
+    const bool active = sg.active;
+    const int last_active = sg.last_active;
 
     uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0;
     unsigned long long tot, off;
@@ -2418,11 +2443,10 @@ __device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, Strea
                                               uint32_t *l_start, uint32_t *l_off, uint32_t *rc, long long c_in) {
   const int tid = threadIdx.x;
   const uint32_t rel_end = rel0 + rem;
-  const uint32_t my_b0 = rel0 + (uint32_t)tid * sb;
-  uint32_t lim = my_b0 + sb;
-  if (lim > rel_end) lim = rel_end;
-  const bool active = my_b0 < rel_end;
-  const int last_active = (int)((rel_end - rel0 - 1u) / sb);
+  const SubGrid sg = sub_grid(rel0, rem, sb, tid);
+  const uint32_t my_b0 = sg.b0, lim = sg.lim;
+  const bool active = sg.active;
+  const int last_active = sg.last_active;
   uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
   long long c_phase[2] = {0, 0};
   const long long c_fix0 = clock64();
@@ -2564,9 +2588,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, c
   sb = sb < kMinSubBits ? kMinSubBits : sb;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off);
-  const uint32_t rel_end = rel0 + (uint32_t)P1;
-  uint32_t lim = rel0 + (uint32_t)(tid + 1) * sb;
-  if (lim > rel_end) lim = rel_end;
+  const uint32_t lim = sub_grid(rel0, (uint32_t)P1, sb, tid).lim;
   const uint32_t start = rel0 + pre_start[tid];
   const uint32_t off = pre_off[tid], cnt = pre_off[tid + 1] - off;   // [kDecThreads] holds the total
   const uint32_t tot = pre_off[kDecThreads];
