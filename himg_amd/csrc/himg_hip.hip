@@ -102,6 +102,12 @@ struct himg_hip_ctx {
   // Side stream + events: the decoder forks its serial row-header walk onto it.
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // The encoder's side stream carries its LRES branch, which is on the critical path
+  // (k_tree waits for it): default priority, its own events -- not the decoder's
+  // lowest-priority stream, behind whose wide k_row_count launches of other contexts it
+  // would queue.
+  hipStream_t side_enc = nullptr;
+  hipEvent_t ev_fork_e = nullptr, ev_join_e = nullptr;
 
   // Fixed table: LUT of the full-res companding search (FullResMapper is the
   // same for every quality, mapper.cpp:213-223), 32769 entries.
@@ -253,8 +259,11 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-    delete ctx;
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side_enc, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork_e, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join_e, hipEventDisableTiming) != hipSuccess) {
+    himg_hip_destroy(ctx);
     return HIMG_ERR_HIP;
   }
   *out = ctx;
@@ -268,6 +277,9 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->side) hipStreamDestroy(ctx->side);
+  if (ctx->ev_fork_e) hipEventDestroy(ctx->ev_fork_e);
+  if (ctx->ev_join_e) hipEventDestroy(ctx->ev_join_e);
+  if (ctx->side_enc) hipStreamDestroy(ctx->side_enc);
   for (int k = 0; k < himg_hip_ctx::SizeRing::kSlots; ++k) {
     if (ctx->sizes_ring.ev[k]) hipEventDestroy(ctx->sizes_ring.ev[k]);
     if (ctx->sizes_ring.h[k]) hipHostFree(ctx->sizes_ring.h[k]);
@@ -558,7 +570,7 @@ extern "C" int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, i
   ctx->last_stream = s;
   launch_encode(g, ctx->enc_ws, batch, (const uint8_t *)d_frames, (uint8_t *)d_out, out_stride,
                 d_sizes, sc, st, lt, (const uint8_t *)ctx->fmap_lut.p, s, &ctx->prof,
-                ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join);
+                ctx->use_side ? ctx->side_enc : nullptr, ctx->ev_fork_e, ctx->ev_join_e);
   if (d_status)
     hipLaunchKernelGGL(k_copy_status, dim3((batch + 63) / 64), dim3(64), 0, s, ctx->enc_ws.status,
                        d_status, batch);
