@@ -84,6 +84,9 @@ def lib():
     L.himg_hip_encode_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]
     L.himg_hip_decode_device.argtypes = [vp, vp, sz, vp, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_decode_rows_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_decode_index_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp, vp]
+    L.himg_hip_decode_rows_indexed_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.himg_hip_index_host.argtypes = [vp, sz, i32, P(i32), P(i32), P(i32), vp, sz, P(C.c_uint32)]
     L.himg_hip_shard_stats.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_shard_row_bits.argtypes = [vp, vp, vp, vp]
     L.himg_hip_shard_emit.argtypes = [vp, vp, vp, sz, vp, vp]
@@ -295,6 +298,24 @@ class Engine:
                                                _ptr(d_status), C.c_void_p(stream))
         self._check(rc, "decode_rows_device")
 
+    def decode_index_device(self, d_packed, packed_size, width, height, channels, d_row_index,
+                            d_rows_first, d_status, stream=0):
+        """Row index of a stream in HBM: [rows] payload offsets + [rows] lengths (uint32) and
+        the offset of the first row header (rank 0 of a row-sharded decode)."""
+        rc = lib().himg_hip_decode_index_device(self._ctx, _ptr(d_packed), int(packed_size), width, height,
+                                                channels, _ptr(d_row_index), _ptr(d_rows_first),
+                                                _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "decode_index_device")
+
+    def decode_rows_indexed_device(self, d_packed, packed_size, width, height, channels, row0, row1,
+                                   d_row_index, d_out_rows, d_status, stream=0):
+        """Block rows [row0, row1) from a buffer that holds only the bytes in front of the first
+        row header and these rows' payloads, with the row index supplied."""
+        rc = lib().himg_hip_decode_rows_indexed_device(self._ctx, _ptr(d_packed), int(packed_size), width,
+                                                       height, channels, row0, row1, _ptr(d_row_index),
+                                                       _ptr(d_out_rows), _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "decode_rows_indexed_device")
+
     # row-sharded encode (see himg_amd/sharded.py) --------------------------------------
     def shard_stats(self, d_frame_base, width, height, pixel_stride, channels, quality, use_ycbcr,
                     row0, row1, d_hist, d_low_rows, stream=0):
@@ -343,6 +364,25 @@ class Engine:
         rc = lib().himg_hip_profile_read(self._ctx, C.byref(n), names, ms, cnt)
         self._check(rc, "profile_read")
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+
+def index_host(packed, fix_t2=False):
+    """Row index of a stream in host memory (no GPU): (width, height, channels, offsets
+    uint32[rows], lengths uint32[rows], rows_first).  Raises HimgError on a stream whose
+    container or row headers the decoder would reject."""
+    a = np.ascontiguousarray(packed, np.uint8)
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = lib().himg_hip_peek(a.ctypes.data, a.size, C.byref(w), C.byref(h), C.byref(c))
+    if rc != 0:
+        raise HimgError(rc, "index_host: not a HIMG stream")
+    rows = (h.value + 7) // 8
+    idx = np.zeros(2 * rows, np.uint32)
+    first = C.c_uint32()
+    rc = lib().himg_hip_index_host(a.ctypes.data, a.size, 1 if fix_t2 else 0, C.byref(w), C.byref(h),
+                                   C.byref(c), idx.ctypes.data, rows, C.byref(first))
+    if rc != 0:
+        raise HimgError(rc, "index_host")
+    return w.value, h.value, c.value, idx[:rows], idx[rows:], first.value
 
 
 def _ptr(x):

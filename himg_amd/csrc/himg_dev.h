@@ -90,6 +90,7 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
   int32_t status;
   int32_t parse_status;      // k_dec_parse's own verdict (status collects the later kernels' as well)
   int32_t walk_status;       // k_dec_rowwalk's verdict: it runs beside k_dec_parse, k_row_count merges it
+  uint32_t rows_first;       // k_dec_rowwalk: byte offset of the first FRES row header (0: not found)
   int32_t ycbcr;
   DecStream s[2];
   int16_t lmap[128];         // decoder-side companding tables (positive halves)
@@ -143,7 +144,8 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
-                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1);
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1,
+                   const uint32_t *d_row_index = nullptr, bool index_only = false);
 
 // Row-sharded encode of one frame (multi-GPU): phases between the collectives.
 void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,

@@ -645,6 +645,150 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
   return HIMG_OK;
 }
 
+// Row index of one stream in HBM (rank 0 of a row-sharded decode): container parse and
+// the serial row-header walk only.  d_row_index: [rows] payload offsets then [rows]
+// lengths; d_rows_first: offset of the first row header (everything in front of it --
+// container chunks, LRES stream, FRES tree -- is what every rank needs).
+extern "C" int himg_hip_decode_index_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                            int width, int height, int num_channels,
+                                            uint32_t *d_row_index, uint32_t *d_rows_first,
+                                            int32_t *d_status, void *stream) {
+  if (!ctx || !d_packed || !d_row_index || !d_rows_first || !d_status) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
+  if (g.rows + 1 > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if ((uintptr_t)d_packed & 15) return fail(ctx, HIMG_ERR_ARG, "buffers must be 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, 1);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  rc = stage_sizes(ctx, &packed_size, 1, s);
+  if (rc) return rc;
+  launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
+                (const uint32_t *)ctx->d_sizes.p, nullptr, d_status, s, &ctx->prof, ctx->allow_fused,
+                nullptr, ctx->ev_fork, ctx->ev_join, 0, g.rows, nullptr, true);
+  HIP_TRY(ctx, hipMemcpyAsync(d_row_index, ctx->dec_ws.row_off, (size_t)g.rows * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(d_row_index + g.rows, ctx->dec_ws.row_len, (size_t)g.rows * 4,
+                              hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(d_rows_first, &ctx->dec_ws.frames[0].rows_first, 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+// Block rows [row0, row1) with the row index supplied (no header walk: the buffer
+// only has to hold the bytes in front of the first row header and the payloads of
+// these rows, each at its offset in the stream).
+extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void *d_packed,
+                                                   uint32_t packed_size, int width, int height,
+                                                   int num_channels, int row0, int row1,
+                                                   const uint32_t *d_row_index, void *d_out_rows,
+                                                   int32_t *d_status, void *stream) {
+  if (!ctx || !d_packed || !d_out_rows || !d_status || !d_row_index) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
+  g.max_sub = ctx->max_sub;
+  g.lead_bits = ctx->lead_bits;
+  g.lres_serial = ctx->lres_serial;
+  if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
+  if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))
+    return fail(ctx, HIMG_ERR_ARG, "buffers must be 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, 1);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  rc = stage_sizes(ctx, &packed_size, 1, s);
+  if (rc) return rc;
+  uint8_t *base = (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C;
+  launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
+                (const uint32_t *)ctx->d_sizes.p, base, d_status, s, &ctx->prof, ctx->allow_fused,
+                ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, row0, row1, d_row_index);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+// The same index on the host, for a stream in host memory (no GPU): chunk search
+// (decoder.cpp:428-461), length of the serialised FRES tree (huffman_dec.cpp:152-229),
+// row headers (huffman_dec.cpp:232-248).  A serial walk over a few thousand headers is
+// microseconds on a CPU and 1 ms of dependent loads on the GPU.
+static bool host_find_chunk(const uint8_t *p, size_t n, size_t *idx, uint32_t tag, uint32_t *size) {
+  for (;;) {
+    if (*idx + 8 > n) return false;
+    uint32_t t, sz;
+    memcpy(&t, p + *idx, 4);
+    memcpy(&sz, p + *idx + 4, 4);
+    *idx += 8;
+    if (sz > 0x7fffffffu || *idx + sz > n) return false;
+    if (t == tag) { *size = sz; return true; }
+    *idx += sz;
+  }
+}
+
+extern "C" int himg_hip_index_host(const uint8_t *packed, size_t packed_size, int fix_t2, int *width,
+                                   int *height, int *num_channels, uint32_t *row_index,
+                                   size_t index_rows, uint32_t *rows_first) {
+  if (!packed || !width || !height || !num_channels || !rows_first) return HIMG_ERR_ARG;
+  int rc = himg_hip_peek(packed, packed_size, width, height, num_channels);
+  if (rc) return rc;
+  const size_t rows = ((size_t)*height + 7) / 8;
+  if (!row_index || index_rows < rows) return HIMG_ERR_CAPACITY;
+  static const uint32_t tags[6] = {0x544d5246u, 0x50414d4cu, 0x5345524cu, 0x47464351u, 0x50414d46u, 0x53455246u};
+  size_t idx = 12;
+  uint32_t sz = 0;
+  for (int t = 0; t < 6; ++t) {
+    if (!host_find_chunk(packed, packed_size, &idx, tags[t], &sz)) return HIMG_ERR_FORMAT;
+    if (t < 5) idx += sz;
+  }
+  const size_t coff = idx, end = idx + sz;
+  size_t bit = 0;
+  {
+    const size_t bit_end = 8 * (size_t)(sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride);
+    int open = 1, count = 0;
+    while (open > 0) {
+      if (count >= 2 * kNumSym - 1 || bit >= bit_end) return HIMG_ERR_FORMAT;
+      ++count;
+      if ((packed[coff + (bit >> 3)] >> (bit & 7)) & 1) {
+        if (bit + 10 > bit_end) return HIMG_ERR_FORMAT;
+        bit += 10;
+        --open;
+      } else {
+        bit += 1;
+        ++open;
+      }
+    }
+  }
+  size_t q = coff + ((bit + 7) >> 3);
+  if (q >= end) return HIMG_ERR_FORMAT;
+  *rows_first = (uint32_t)q;
+  if (fix_t2 && rows == 1) {
+    row_index[0] = (uint32_t)q;
+    row_index[rows] = (uint32_t)(end - q);
+    return HIMG_OK;
+  }
+  size_t r = 0;
+  while (q != end) {
+    if (q + 2 > end) return HIMG_ERR_FORMAT;
+    uint32_t len = packed[q] | (packed[q + 1] << 8);
+    q += 2;
+    if (len & 0x8000u) {
+      if (q + 2 > end) return HIMG_ERR_FORMAT;
+      len = (len & 0x7fffu) | ((uint32_t)(packed[q] | (packed[q + 1] << 8)) << 15);
+      q += 2;
+    }
+    if (len > end - q) return HIMG_ERR_FORMAT;
+    if (r < rows) { row_index[r] = (uint32_t)q; row_index[rows + r] = len; }
+    ++r;
+    q += len;
+  }
+  return r < rows ? HIMG_ERR_FORMAT : HIMG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Host-buffer API.
 // ---------------------------------------------------------------------------

@@ -535,6 +535,7 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
     s_hdr[0] = ok ? idx : 0u;
     s_hdr[1] = ok ? sz : 0u;
     df->walk_status = 0;
+    df->rows_first = 0;
   }
   __syncthreads();
   const uint32_t coff = s_hdr[0], csz = s_hdr[1];
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
   const uint32_t end = coff + csz;
   if (q >= end) return;                    // nothing behind the tree: k_dec_parse's verdict
   uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
+  df->rows_first = q;
   if (g.fix_t2 && g.rows == 1) {   // the encoder writes one block row without a size header
     ro[0] = q;
     rl[0] = end - q;
@@ -589,6 +591,25 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
   }
   if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
   df->walk_status = st;
+}
+
+// k_dec_set_index: the row index comes from the caller (row-sharded decode: the rank
+// that holds the whole stream walked the headers once, the others hold only their own
+// rows' bytes and cannot) -- [rows] payload offsets, then [rows] lengths.  Rows whose
+// payload would leave the stream are flagged like a damaged header.
+__global__ __launch_bounds__(256) void k_dec_set_index(Geom g, DecWs ws, const uint32_t *index,
+                                                       const uint32_t *sizes, int r0, int r1) {
+  DecFrame *df = ws.frames;   // (one frame)
+  const uint32_t n = sizes[0];
+  int bad = 0;
+  for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
+    const uint32_t off = index[r], len = index[g.rows + r];
+    ws.row_off[r] = off;
+    ws.row_len[r] = len;
+    if (off > n || len > n - off) bad = 1;
+  }
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) { df->walk_status = bad ? fmt_err(7, 1) : 0; df->rows_first = 0; }
 }
 
 // ---------------------------------------------------------------------------
@@ -2644,7 +2665,18 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
-                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1) {
+                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1,
+                   const uint32_t *d_row_index, bool index_only) {
+  // d_row_index: the FRES row index is given (k_dec_set_index instead of the serial
+  // header walk; one frame).  index_only: container parse and row-header walk only --
+  // the caller reads ws.row_off / ws.row_len / DecFrame::rows_first (rank 0 of a
+  // row-sharded decode).
+  if (index_only) {
+    HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
+    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
+    HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
+    return;
+  }
   // Block rows [r0, r1) only (row-sharded decode: every rank decodes the small
   // LRES stream and walks all row headers, then its own FRES rows).
   const int nrows = r1 - r0;
@@ -2669,8 +2701,13 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   if (side) {
     (void)hipEventRecord(ev_fork, stream);
     (void)hipStreamWaitEvent(side, ev_fork, 0);
-    prof_begin(prof, "k_dec_rowwalk", side);
-    hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride, d_sizes);
+    if (d_row_index) {
+      prof_begin(prof, "k_dec_set_index", side);
+      hipLaunchKernelGGL(k_dec_set_index, dim3(1), dim3(256), 0, side, g, ws, d_row_index, d_sizes, r0, r1);
+    } else {
+      prof_begin(prof, "k_dec_rowwalk", side);
+      hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride, d_sizes);
+    }
     prof_end(prof, side);
   }
   HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
@@ -2692,6 +2729,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       prof_end(prof, side);
     }
     (void)hipEventRecord(ev_join, side);
+  } else if (d_row_index) {
+    HIMG_LAUNCH(k_dec_set_index, dim3(1), dim3(256), g, ws, d_row_index, d_sizes, r0, r1);
   } else {
     HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
   }

@@ -7,10 +7,10 @@ collectives of SURVEY.md 8(e) between the device phases of the C ABI
 (include/himg_hip.h, himg_hip_shard_*):
 
     stats      -> all-reduce(sum) 261-bin FRES token histogram   (1 KiB, latency bound)
-               -> gather low-res rows to rank 0                  (1/64 of the pixels)
+               -> low-res rows to rank 0, point to point         (1/64 of the pixels)
     row_bits   -> all-gather payload bits of every block row     (rows x u32)
-    emit       -> gather the packed rows to rank 0               (the only large message;
-                                                                   each peer -> rank 0 over
+    emit       -> the packed rows to rank 0, point to point,     (the only large message;
+                  exact sizes, received in place                  each peer -> rank 0 over
                                                                    its own xGMI link)
     assemble   (rank 0) LRES stream, container, FRES tree, rows, stale pad bits
 
@@ -90,13 +90,19 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=T
     hist, low = backend.stats(r0, r1)
     if world > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)        # 261 x i64, latency bound
-    # Low-res rows to rank 0 (1/64 of the pixels): padded gather.
-    low_pad = _pad(low, channels * max_rows * cols)
+    # Low-res rows to rank 0 (1/64 of the pixels), exact sizes, point to point.
+    low_list = [low]
     if world > 1:
-        low_list = [torch.empty_like(low_pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(low_pad, low_list, dst=0, group=group)
+        ops = []
+        if rank == 0:
+            low_list += [torch.empty(channels * (p1 - p0) * cols, dtype=torch.uint8, device=low.device)
+                         for p0, p1 in parts[1:]]
+            ops = [dist.P2POp(dist.irecv, t, peer, group) for peer, t in enumerate(low_list) if peer and t.numel()]
+        elif low.numel():
+            ops = [dist.P2POp(dist.isend, low.contiguous(), 0, group)]
+        low_reqs = dist.batch_isend_irecv(ops) if ops else []
     else:
-        low_list = [low_pad]
+        low_reqs = []
 
     bits = backend.row_bits(hist)
     bits_pad = _pad(bits, max_rows)
@@ -106,29 +112,32 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=T
     else:
         bits_list = [bits_pad]
     all_bits = torch.cat([b[: (p1 - p0)] for b, (p0, p1) in zip(bits_list, parts)])
+    # The one value the host needs: the sizes of the pieces that travel (rows x 4 bytes).
     layout = fres_layout(all_bits.cpu().numpy(), use_blocks)
     ranges = [piece_range(layout, p0, p1) for p0, p1 in parts]
-    max_piece = max(e - s for s, e in ranges)
+    total = layout[3]
 
     start, end = ranges[rank]
     piece = backend.emit(all_bits, start, end)
-    piece_pad = _pad(piece, max_piece)
-    if world > 1:
-        piece_list = [torch.empty_like(piece_pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(piece_pad, piece_list, dst=0, group=group)           # the large message
-    else:
-        piece_list = [piece_pad]
-    if rank != 0:
-        return None
-
-    total = layout[3]
     if world == 1:
         # One rank holds everything already: no copies (a 16384x16384 frame's packed rows
         # are 275 MB).
         return backend.assemble(low, all_bits, piece, host)
-    rel_full = torch.empty(total, dtype=torch.uint8, device=piece.device)
-    for pl, (s, e) in zip(piece_list, ranges):
-        rel_full[s:e] = pl[: e - s]
+    # The packed rows -- the only large message -- go straight to their place in rank
+    # 0's relative FRES buffer: exact sizes, every peer over its own link, no staging
+    # copy on either side.
+    ops, rel_full = [], None
+    if rank == 0:
+        rel_full = torch.empty(total, dtype=torch.uint8, device=piece.device)
+        rel_full[start:end] = piece
+        ops = [dist.P2POp(dist.irecv, rel_full[s:e], peer, group)
+               for peer, (s, e) in enumerate(ranges) if peer and e > s]
+    elif end > start:
+        ops = [dist.P2POp(dist.isend, piece.contiguous(), 0, group)]
+    for req in list(low_reqs) + (dist.batch_isend_irecv(ops) if ops else []):
+        req.wait()
+    if rank != 0:
+        return None
     low_full = torch.empty(channels * rows * cols, dtype=torch.uint8, device=low.device)
     lf = low_full.view(channels, rows, cols)
     for ll, (p0, p1) in zip(low_list, parts):
@@ -149,7 +158,7 @@ class EngineBackend:
     pieces that travel to rank 0)."""
 
     def __init__(self, engine, d_frame, y_first, width, height, quality=50, use_ycbcr=True,
-                 comm_device=None, stream=0):
+                 comm_device=None, stream=None):
         import torch
         import himg_amd
         self.eng, self.W, self.H, self.q, self.ycbcr = engine, width, height, quality, use_ycbcr
@@ -173,6 +182,16 @@ class EngineBackend:
     def _to_comm(self, t):
         return t.to(self.comm) if t.device != self.comm else t
 
+    def _s(self):
+        """The stream the engine's kernels go to: torch's CURRENT stream of the device
+        unless one was given -- so that the torch copies and the collectives around the
+        phases, which torch issues on that stream, are ordered with them whatever stream
+        context the caller is in."""
+        if self.stream is not None:
+            return self.stream
+        import torch
+        return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
+
     def stats(self, r0, r1):
         import torch
         if self._low is None or (r0, r1) != (self.r0, self.r1):
@@ -183,7 +202,7 @@ class EngineBackend:
         # phase (and rank 0's assemble) relies on.
         base = self.d_frame.data_ptr() - self.y_first * self.W * 4   # virtual frame base
         self.eng.shard_stats(base, self.W, self.H, 4, 4, self.q, self.ycbcr, r0, r1, self._hist32, self._low,
-                             self.stream)
+                             self._s())
         h64 = (self._hist32[:261].to(torch.int64) & 0xFFFFFFFF)    # i64: 8 ranks x 2^31 tokens cannot wrap
         return self._to_comm(h64), self._to_comm(self._low[: self.C * (r1 - r0) * self.cols])
 
@@ -191,7 +210,7 @@ class EngineBackend:
         import torch
         n = self.r1 - self.r0
         self._hist_g[:261] = hist_global.to(self.dev).to(torch.int32)
-        self.eng.shard_row_bits(self._hist_g, self._bits, self.stream)   # every rank builds the (identical) tree
+        self.eng.shard_row_bits(self._hist_g, self._bits, self._s())   # every rank builds the (identical) tree
         return self._to_comm(self._bits[:n])
 
     def emit(self, all_bits, start, end):
@@ -201,7 +220,7 @@ class EngineBackend:
         if self._rel is None:
             self._rel = torch.empty(self._rel_cap, dtype=torch.uint8, device=self.dev)
         self._all_bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
-        self.eng.shard_emit(self._all_bits_dev, self._rel, self._rel_cap, self._size, self.stream)
+        self.eng.shard_emit(self._all_bits_dev, self._rel, self._rel_cap, self._size, self._s())
         return self._to_comm(self._rel[start:end])
 
     def assemble(self, low_full, all_bits, rel_full, host=True):
@@ -212,11 +231,13 @@ class EngineBackend:
         bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
         rel_dev = rel_full.to(self.dev).contiguous()
         self.eng.shard_assemble(low_full.to(self.dev).contiguous(), bits_dev, rel_dev, rel_dev.numel(),
-                                self._out, self._out_cap, self._size, self._status, self.stream)
+                                self._out, self._out_cap, self._size, self._status, self._s())
         st = torch.stack([self._size[0], self._status[0]]).cpu()       # the one wait of this phase
         if int(st[1]) != 0:
             raise himg_amd.HimgError(-int(st[1]), "sharded assemble failed")
         out = self._out[: int(st[0])]
+        # host=False: a VIEW of this backend's output buffer -- the next encode on the
+        # same backend overwrites it; clone it to keep it.
         return out.cpu().numpy() if host else out
 
 
@@ -224,76 +245,218 @@ class EngineBackend:
 # Row-sharded DECODE of one frame.
 # ---------------------------------------------------------------------------
 
-def decode_sharded(engine, packed, width, height, channels=4, group=None, gather=True, device=None,
-                   comm_device=None, stream=0):
-    """Decode one frame with its block rows sharded over the ranks of `group`.
+def slice_ranges(offsets, lengths, rows_first, size, parts, margin=16):
+    """Byte range [lo, hi) of the stream that the rank decoding block rows [r0, r1)
+    needs besides the head [0, rows_first): its rows' payloads (the row kernels read
+    whole dwords and a few dwords ahead, hence the margin), 16-byte aligned, clipped to
+    [rows_first & ~15, size rounded up to 16).  Empty shares get (0, 0)."""
+    cap = (int(size) + 15) // 16 * 16
+    out = []
+    for r0, r1 in parts:
+        if r1 <= r0:
+            out.append((0, 0))
+            continue
+        lo = max(int(offsets[r0]) - margin, int(rows_first)) // 16 * 16
+        hi = min((int(offsets[r1 - 1]) + int(lengths[r1 - 1]) + margin + 15) // 16 * 16, cap)
+        out.append((lo, max(hi, lo)))
+    return out
 
-    `packed` (uint8 numpy array or tensor) is the whole stream on rank 0; it is
-    broadcast (the only exchange before the kernels -- the stream is ~4x smaller
-    than the pixels).  Every rank decodes the LRES stream and its own block rows
-    (reference decoder.cpp:292-326 hands block rows to worker threads the same
-    way).  Returns (ok, pixels): `ok` is the AND over the ranks (a stream the
-    reference rejects is rejected); with gather=True rank 0 gets the whole
-    H x W x C image (None elsewhere), otherwise every rank gets its own pixel rows.
-    `engine` provides decode_rows_device (himg_amd.Engine); `comm_device` is where
-    the process group can move tensors (CUDA for nccl/RCCL, "cpu" for gloo).
-    """
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    comm = torch.device(comm_device) if comm_device is not None else dev
-    rows = (height + 7) // 8
-    parts = shard_rows(rows, world)
-    r0, r1 = parts[rank]
+class ShardedDecoder:
+    """Row-sharded decode of frames of one geometry (reference
+    decoder.cpp:292-326 hands block rows to worker threads the same way).
 
-    def bcast(t):
+    Rank 0 holds the stream.  It indexes the block rows ONCE (container parse + the
+    serial walk over the row size headers: on the host for a stream in host memory, on
+    its GPU otherwise), then
+        broadcast   a small record: stream size, verdict, first-row offset, row index
+        broadcast   the head of the stream [0, first row header): container chunks,
+                    LRES stream, FRES tree -- 1/20 of a 16384 x 16384 stream
+        send/recv   to every other rank ONLY the bytes of its own block rows, each over
+                    that peer's own link
+    and every rank decodes the LRES stream and its rows from a buffer that holds just
+    those two ranges at their stream offsets (himg_hip_decode_rows_indexed_device: no
+    rank repeats the header walk).  All buffers are allocated once.
+    `bytes_from_rank0` of the last call = what left rank 0 (the tests bound it by
+    1.2 x the stream)."""
+
+    def __init__(self, engine, width, height, channels=4, group=None, device=None, comm_device=None,
+                 stream=None, fix_t2=False):
+        import torch
+        import torch.distributed as dist
+        self.eng, self.W, self.H, self.C, self.group, self.stream = engine, width, height, channels, group, stream
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.comm = torch.device(comm_device) if comm_device is not None else self.dev
+        self.rows = (height + 7) // 8
+        self.parts = shard_rows(self.rows, self.world)
+        self.fix_t2 = fix_t2
+        r0, r1 = self.parts[self.rank]
+        y0, y1 = min(8 * r0, height), min(8 * r1, height)
+        self.r0, self.r1, self.y0, self.y1 = r0, r1, y0, y1
+        dev = self.dev
+        self.d_rows = torch.empty((max(y1 - y0, 1), width, channels), dtype=torch.uint8, device=dev)
+        self.d_status = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.d_index = torch.zeros(2 * self.rows + 2, dtype=torch.int32, device=dev)   # offsets, lengths, first
+        self.meta = torch.zeros(4 + 2 * self.rows, dtype=torch.int64, device=self.comm)
+        self.d_packed = None      # grown on demand, never zeroed: only the two ranges are read
+        self.bytes_from_rank0 = 0
+
+    def _s(self):
+        """torch's current stream of the device unless one was given (see EngineBackend._s)."""
+        if self.stream is not None:
+            return self.stream
+        import torch
+        return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
+
+    def _buffer(self, size):
+        import torch
+        cap = (int(size) + 15) // 16 * 16 + 64
+        if self.d_packed is None or self.d_packed.numel() < cap:
+            self.d_packed = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        return self.d_packed
+
+    def _index_rank0(self, packed):
+        """-> (size, ok, rows_first, offsets, lengths, d_src or None)."""
+        import torch
+        import himg_amd
+        rows = self.rows
+        if torch.is_tensor(packed) and packed.device.type != "cpu":
+            size = int(packed.numel())
+            src = packed
+            if src.data_ptr() % 16 or src.numel() % 4:
+                buf = self._buffer(size)
+                buf[:size] = src
+                src = buf
+            self.eng.decode_index_device(src, size, self.W, self.H, self.C, self.d_index, self.d_index[2 * rows:],
+                                         self.d_status[1:], self._s())
+            host = torch.cat([self.d_index, self.d_status[1:2]]).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            ok = int(host[-1]) == 0
+            return size, ok, int(host[2 * rows]), host[:rows], host[rows:2 * rows], src
+        a = packed.numpy() if torch.is_tensor(packed) else np.ascontiguousarray(packed, np.uint8)
+        try:
+            w, h, c, off, ln, first = himg_amd.index_host(a, self.fix_t2)
+            ok = (w, h, c) == (self.W, self.H, self.C)
+        except himg_amd.HimgError:
+            ok, off, ln, first = False, np.zeros(rows, np.uint32), np.zeros(rows, np.uint32), 0
+        return int(a.size), ok, int(first), off.astype(np.int64), ln.astype(np.int64), None
+
+    def decode(self, packed=None, gather=True):
+        """packed: the stream on rank 0 (numpy array, CPU or CUDA tensor), ignored
+        elsewhere.  Returns (ok, pixels) like decode_sharded."""
+        import torch
+        import torch.distributed as dist
+        world, rank, rows, group = self.world, self.rank, self.rows, self.group
+        self.bytes_from_rank0 = 0
+        d_src = None
+        if rank == 0:
+            size, ok, first, off, ln, d_src = self._index_rank0(packed)
+            m = np.zeros(4 + 2 * rows, np.int64)
+            m[0], m[1], m[2] = size, 1 if ok else 0, first
+            m[4:4 + rows], m[4 + rows:] = off, ln
+            self.meta.copy_(torch.from_numpy(m))
         if world > 1:
-            c = t.to(comm)
-            dist.broadcast(c, src=0, group=group)
-            if c is not t:
-                t.copy_(c)
+            dist.broadcast(self.meta, src=0, group=group)
+            self.bytes_from_rank0 += (world - 1) * self.meta.numel() * 8
+        m = self.meta.cpu().numpy()
+        size, ok, first = int(m[0]), bool(m[1]), int(m[2])
+        if not ok:
+            return False, None          # the container or a row header is damaged: every rank agrees
+        off, ln = m[4:4 + rows], m[4 + rows:]
+        ranges = slice_ranges(off, ln, first, size, self.parts)
+        head16 = min((first + 15) // 16 * 16, (size + 15) // 16 * 16)
 
-    # The stream, padded to a multiple of 16 bytes, on every rank.
-    n = torch.zeros(1, dtype=torch.int64, device=dev)
-    if rank == 0:
-        n[0] = int(packed.numel() if torch.is_tensor(packed) else len(packed))
-    bcast(n)
-    size = int(n.item())
-    d_packed = torch.zeros((size + 15) // 16 * 16, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
-        d_packed[:size] = src.to(dev)
-    bcast(d_packed)
+        if world == 1 and d_src is not None:
+            buf = d_src                  # one rank, stream already in HBM: decode in place
+        else:
+            buf = self._buffer(size)
+            if rank == 0 and d_src is None:
+                src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
+                buf[:size] = src.to(self.dev)
+            elif rank == 0 and d_src.data_ptr() != buf.data_ptr():
+                buf[:size] = d_src[:size]
+        if world > 1:
+            # Head to everybody, then each peer's own rows to that peer only.
+            head = buf[:head16]
+            if self.comm != self.dev:
+                hc = head.to(self.comm)
+                dist.broadcast(hc, src=0, group=group)
+                if rank != 0:
+                    head.copy_(hc)
+            else:
+                dist.broadcast(head, src=0, group=group)
+            self.bytes_from_rank0 += (world - 1) * head16
+            ops, staged = [], []
+            if rank == 0:
+                for peer in range(1, world):
+                    lo, hi = ranges[peer]
+                    if hi > lo:
+                        t = buf[lo:hi] if self.comm == self.dev else buf[lo:hi].to(self.comm)
+                        ops.append(dist.P2POp(dist.isend, t, peer, group))
+                        self.bytes_from_rank0 += hi - lo
+            else:
+                lo, hi = ranges[rank]
+                if hi > lo:
+                    t = buf[lo:hi] if self.comm == self.dev else torch.empty(hi - lo, dtype=torch.uint8, device=self.comm)
+                    ops.append(dist.P2POp(dist.irecv, t, 0, group))
+                    staged.append((lo, hi, t))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            if self.comm != self.dev:
+                for lo, hi, t in staged:
+                    buf[lo:hi] = t.to(self.dev)
+        idx32 = torch.from_numpy(np.concatenate([off, ln]).astype(np.uint32).view(np.int32))
+        self.d_index[: 2 * rows] = idx32.to(self.dev)
+        self.d_status.zero_()
+        self.eng.decode_rows_indexed_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
+                                            self.d_rows, self.d_status, self._s())
+        bad = (self.d_status[:1] != 0).to(torch.int32).to(self.comm)    # (the transfer waits for the kernels)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        ok = int(bad.item()) == 0
+        d_rows = self.d_rows[: self.y1 - self.y0]
+        if not gather:
+            return ok, (d_rows if ok else None)
+        if world == 1:
+            return ok, (d_rows.cpu().numpy() if ok else None)
+        # Pixel rows to rank 0, exact sizes.
+        H, W, C = self.H, self.W, self.C
+        ops, out = [], None
+        if rank == 0:
+            out = torch.empty((H, W, C), dtype=torch.uint8, device=self.comm)
+            out[self.y0:self.y1] = d_rows.to(self.comm)
+            for peer in range(1, world):
+                a, b = self.parts[peer]
+                ya, yb = min(8 * a, H), min(8 * b, H)
+                if yb > ya:
+                    ops.append(dist.P2POp(dist.irecv, out[ya:yb], peer, group))
+        elif self.y1 > self.y0:
+            ops.append(dist.P2POp(dist.isend, d_rows.to(self.comm).contiguous(), 0, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if rank != 0 or not ok:
+            return ok, None
+        return ok, out.cpu().numpy()
 
-    y0, y1 = min(8 * r0, height), min(8 * r1, height)
-    d_rows = torch.empty((max(y1 - y0, 1), width, channels), dtype=torch.uint8, device=dev)
-    d_status = torch.zeros(1, dtype=torch.int32, device=dev)
-    engine.decode_rows_device(d_packed, size, width, height, channels, r0, r1, d_rows, d_status, stream)
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
-    bad = (d_status != 0).to(torch.int32).to(comm)
-    if world > 1:
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-    ok = int(bad.item()) == 0
-    d_rows = d_rows[: y1 - y0]
-    if not gather:
-        return ok, (d_rows if ok else None)
-    if world == 1:
-        return ok, (d_rows.cpu().numpy() if ok else None)
-    # Gather the pixel rows on rank 0 (padded to the largest shard).
-    max_rows = max(min(8 * b, height) - min(8 * a, height) for a, b in parts)
-    pad = torch.zeros((max_rows, width, channels), dtype=torch.uint8, device=comm)
-    pad[: y1 - y0] = d_rows.to(comm)
-    lst = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad, lst, dst=0, group=group)
-    if rank != 0 or not ok:
-        return ok, None
-    out = torch.empty((height, width, channels), dtype=torch.uint8, device=comm)
-    for t, (a, b) in zip(lst, parts):
-        ya, yb = min(8 * a, height), min(8 * b, height)
-        out[ya:yb] = t[: yb - ya]
-    return ok, out.cpu().numpy()
+
+def decode_sharded(engine, packed, width, height, channels=4, group=None, gather=True, device=None,
+                   comm_device=None, stream=None):
+    """Decode one frame with its block rows sharded over the ranks of `group`
+    (ShardedDecoder; the decoder and its buffers are kept on `engine` between calls).
+    Returns (ok, pixels): `ok` is the AND over the ranks (a stream the reference rejects
+    is rejected); with gather=True rank 0 gets the whole H x W x C image (None
+    elsewhere), otherwise every rank gets its own pixel rows as a tensor.
+    `engine` provides decode_index_device / decode_rows_indexed_device
+    (himg_amd.Engine); `comm_device` is where the process group can move tensors
+    (CUDA for nccl/RCCL, "cpu" for gloo)."""
+    key = (width, height, channels, id(group), str(device), str(comm_device), stream)
+    cache = getattr(engine, "_sharded_decoders", None)
+    if cache is None:
+        cache = engine._sharded_decoders = {}
+    dec = cache.get(key)
+    if dec is None:
+        dec = cache[key] = ShardedDecoder(engine, width, height, channels, group, device, comm_device, stream)
+    return dec.decode(packed, gather)

@@ -210,6 +210,31 @@ int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_packed, uint32_
                                 int width, int height, int num_channels, int row0, int row1,
                                 void *d_out_rows, int32_t *d_status, void *stream);
 
+/* The same with the stream SCATTERED instead of replicated ("rank 0 parses
+ * headers/row index, broadcasts tree + low-res plane ..., scatters row payload slices"):
+ *   himg_hip_decode_index_device   on the rank that holds the stream: container parse and
+ *       the serial walk over the row size headers (huffman_dec.cpp:232-248), nothing
+ *       else.  d_row_index receives [rows] payload byte offsets, then [rows] payload
+ *       lengths; *d_rows_first the offset of the first row header.  Bytes
+ *       [0, rows_first) -- container chunks, LRES stream, FRES tree -- go to every rank,
+ *       bytes [offset[row0] - 4, offset[row1-1] + length[row1-1]) only to the rank that
+ *       decodes rows [row0, row1).
+ *   himg_hip_index_host            the same index for a stream in host memory (no GPU).
+ *   himg_hip_decode_rows_indexed_device   decode rows [row0, row1) from a buffer that holds
+ *       those two byte ranges at their offsets in the stream (packed_size is still the
+ *       size of the whole stream; nothing else of it is read), with the row index
+ *       supplied: no rank repeats the header walk. */
+int himg_hip_decode_index_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                 int width, int height, int num_channels, uint32_t *d_row_index,
+                                 uint32_t *d_rows_first, int32_t *d_status, void *stream);
+int himg_hip_index_host(const uint8_t *packed, size_t packed_size, int fix_t2, int *width, int *height,
+                        int *num_channels, uint32_t *row_index, size_t index_rows,
+                        uint32_t *rows_first);
+int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                        int width, int height, int num_channels, int row0, int row1,
+                                        const uint32_t *d_row_index, void *d_out_rows,
+                                        int32_t *d_status, void *stream);
+
 /* ---- introspection for parity tests and bench.py ------------------------ */
 
 /* Intermediate device buffers of the LAST encode/decode on this context

@@ -100,12 +100,27 @@ class StubBackend:
 
 
 class StubDecodeEngine:
-    """decode_rows_device answered by the oracle (CPU tensors): block rows
-    [r0, r1) of the decoded frame, or a non-zero status when the reference rejects
-    the stream."""
+    """decode_rows_indexed_device answered by the oracle (CPU tensors).  The rank only
+    holds the head of the stream and the bytes of its own block rows; the stub checks
+    exactly that against the whole stream (which every rank can regenerate), checks the
+    row index it was handed, and returns block rows [r0, r1) of the oracle's picture --
+    or a non-zero status when the reference rejects the stream."""
 
-    def decode_rows_device(self, d_packed, size, w, h, c, r0, r1, d_rows, d_status, stream=0):
-        rc, pix = ol.oracle_decode(d_packed[:size].numpy())
+    def __init__(self, full_stream):
+        self.full = np.ascontiguousarray(full_stream, np.uint8)
+
+    def decode_rows_indexed_device(self, d_packed, size, w, h, c, r0, r1, d_index, d_rows, d_status, stream=0):
+        full, rows = self.full, (h + 7) // 8
+        assert size == full.size
+        _, _, _, off, ln, first = himg_amd.index_host(full)
+        idx = d_index.numpy().view(np.uint32)
+        assert np.array_equal(idx[:rows], off) and np.array_equal(idx[rows:2 * rows], ln), "row index differs"
+        buf = d_packed.numpy()
+        assert np.array_equal(buf[:first], full[:first]), "head of the stream differs"
+        if r1 > r0:
+            lo, hi = int(off[r0]), int(off[r1 - 1]) + int(ln[r1 - 1])
+            assert np.array_equal(buf[lo:hi], full[lo:hi]), "this rank's row bytes differ"
+        rc, pix = ol.oracle_decode(full)
         if rc != 0:
             d_status[0] = 4
             return
@@ -116,19 +131,24 @@ class StubDecodeEngine:
 
 def main_decode(mode, kind, seed, W, H, q, outfile):
     """Row-sharded decode: rank 0 owns the stream; the assembled pixels (or the
-    word REJECTED) go to outfile."""
+    word REJECTED) go to outfile, what left rank 0 to outfile.stats."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    packed = ol.oracle_encode(himg_amd.synth(kind, seed, W, H), q, True) if rank == 0 else None
+    full = ol.oracle_encode(himg_amd.synth(kind, seed, W, H), q, True)
+    packed = full if rank == 0 else None
     if mode == "dstub":
-        ok, pix = sharded.decode_sharded(StubDecodeEngine(), packed, W, H, 4, device="cpu", comm_device="cpu")
+        eng = StubDecodeEngine(full)
+        ok, pix = sharded.decode_sharded(eng, packed, W, H, 4, device="cpu", comm_device="cpu")
     else:
-        ok, pix = sharded.decode_sharded(himg_amd.Engine(0), packed, W, H, 4, device="cuda:0", comm_device="cpu")
+        eng = himg_amd.Engine(0)
+        ok, pix = sharded.decode_sharded(eng, packed, W, H, 4, device="cuda:0", comm_device="cpu")
     if rank == 0:
         if ok:
             np.asarray(pix, np.uint8).tofile(outfile)
         else:
             open(outfile, "w").write("REJECTED")
+        dec = list(eng._sharded_decoders.values())[0]
+        open(str(outfile) + ".stats", "w").write("%d %d" % (dec.bytes_from_rank0, full.size))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -136,11 +136,13 @@ def test_sharded_encode_two_processes(tmp_path):
 # ---- row-sharded decode ---------------------------------------------------------
 
 @pytest.mark.parametrize("world,kind,w,h,q", [(2, "randtile", 256, 512, 90), (3, "gradn", 128, 520, 50),
-                                               (2, "grad", 512, 512, 50)])
+                                               (2, "grad", 512, 512, 50), (8, "randtile", 512, 2048, 70)])
 def test_sharded_decode_orchestration_gloo_cpu(tmp_path, world, kind, w, h, q):
-    """world_size > 1 over gloo on CPU: broadcast of the stream, per-rank row
-    ranges, status reduction and the gather; the device phase is answered by the
-    oracle.  The `grad` case is a stream the reference rejects (trap T2)."""
+    """world_size > 1 over gloo on CPU: rank 0 indexes the rows once, broadcasts the
+    head of the stream and sends every rank only its own rows' bytes (the stub checks
+    what each rank holds), status reduction and the gather of the pixels; the device
+    phase is answered by the oracle.  The `grad` case is a stream the reference rejects
+    (trap T2).  With 8 ranks: what leaves rank 0 stays below 1.2 x the stream."""
     out = tmp_path / "out.bin"
     _run_ranks(world, ["dstub", kind, 4, w, h, q, out])
     rc, pix = ol.oracle_decode(ol.oracle_encode(himg_amd.synth(kind, 4, w, h), q, True))
@@ -148,6 +150,34 @@ def test_sharded_decode_orchestration_gloo_cpu(tmp_path, world, kind, w, h, q):
         assert open(out).read() == "REJECTED"
     else:
         assert np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
+    sent, size = (int(x) for x in open(str(out) + ".stats").read().split())
+    assert sent <= 1.2 * size, (sent, size)
+
+
+def test_index_host_matches_stream_layout():
+    """himg_hip_index_host (no GPU): offsets / lengths of the FRES rows and the first
+    row header agree with the oracle's per-row byte counts and the chunk layout."""
+    img = himg_amd.synth("randtile", 1, 512, 256)
+    packed, tr = ol.oracle_encode(img, 90, True, trace=True)
+    w, h, c, off, ln, first = himg_amd.index_host(packed)
+    assert (w, h, c) == (512, 256, 4)
+    assert np.array_equal(ln, tr["fres_row_bytes"])
+    lay = sharded.fres_layout(tr["fres_row_bytes"].astype(np.int64) * 8, True)
+    assert np.array_equal(off - first, lay[1])
+    assert int(off[-1]) + int(ln[-1]) == packed.size
+    bad = packed.copy()
+    bad[first] ^= 0x40          # the first row's size header now points past the chunk
+    bad[first + 1] |= 0x7f
+    with pytest.raises(himg_amd.HimgError):
+        himg_amd.index_host(bad)
+    # slices: the head plus every rank's slice cover each row's payload, nothing else is needed
+    parts = sharded.shard_rows(32, 3)
+    rng = sharded.slice_ranges(off, ln, first, packed.size, parts)
+    for (r0, r1), (lo, hi) in zip(parts, rng):
+        if r1 > r0:
+            assert lo % 16 == 0 and lo >= first // 16 * 16 and lo <= off[r0] and hi >= off[r1 - 1] + ln[r1 - 1]
+        else:
+            assert (lo, hi) == (0, 0)
 
 
 @pytest.mark.gpu
@@ -177,6 +207,55 @@ def test_sharded_decode_simulated_ranks(kind, w, h, q, parts):
         if y1 > y0:
             assert np.array_equal(d_rows[: y1 - y0].cpu().numpy(), pix[y0:y1]), (r0, r1)
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,w,h,q,parts", [
+    ("randtile", 256, 512, 90, 2), ("randtile", 4096, 256, 50, 2), ("gradn", 256, 261, 90, 3),
+    ("randtile", 8192, 128, 50, 2), ("rand", 512, 1024, 50, 4)])
+def test_sharded_decode_scattered_stream(kind, w, h, q, parts):
+    """The scattered form: the row index from the GPU equals the host's; every simulated
+    rank decodes its block rows from a buffer that holds ONLY the head of the stream and
+    its own rows' bytes (everything else poisoned), with the index supplied."""
+    import torch
+    packed = ol.oracle_encode(himg_amd.synth(kind, 2, w, h), q, True)
+    rc, pix = ol.oracle_decode(packed)
+    assert rc == 0
+    pix = pix.reshape(h, w, 4)
+    rows = (h + 7) // 8
+    _, _, _, off, ln, first = himg_amd.index_host(packed)
+    cap = (packed.size + 15) // 16 * 16 + 64
+    d_full = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+    d_full[: packed.size] = torch.from_numpy(packed).to("cuda:0")
+    eng = himg_amd.Engine(0)
+    d_idx = torch.zeros(2 * rows + 2, dtype=torch.int32, device="cuda:0")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    eng.decode_index_device(d_full, packed.size, w, h, 4, d_idx, d_idx[2 * rows:], st)
+    got = d_idx.cpu().numpy().view(np.uint32)
+    assert int(st.item()) == 0 and int(got[2 * rows]) == first
+    assert np.array_equal(got[:rows], off) and np.array_equal(got[rows:2 * rows], ln)
+    ranges = sharded.shard_rows(rows, parts)
+    for (r0, r1), (lo, hi) in zip(ranges, sharded.slice_ranges(off, ln, first, packed.size, ranges)):
+        d_part = torch.full((cap,), 0xAA, dtype=torch.uint8, device="cuda:0")
+        head = (first + 15) // 16 * 16
+        d_part[:head] = d_full[:head]
+        d_part[lo:hi] = d_full[lo:hi]
+        y0, y1 = min(8 * r0, h), min(8 * r1, h)
+        d_rows = torch.full((max(y1 - y0, 1), w, 4), 77, dtype=torch.uint8, device="cuda:0")
+        st.zero_()
+        eng.decode_rows_indexed_device(d_part, packed.size, w, h, 4, r0, r1, d_idx, d_rows, st)
+        torch.cuda.synchronize()
+        assert int(st.item()) == 0
+        if y1 > y0:
+            assert np.array_equal(d_rows[: y1 - y0].cpu().numpy(), pix[y0:y1]), (r0, r1)
+    # a row index that points outside the stream is refused like a damaged header
+    bad = d_idx.clone()
+    bad[0] = packed.size + 100
+    d_rows = torch.zeros((min(8, h), w, 4), dtype=torch.uint8, device="cuda:0")
+    eng.decode_rows_indexed_device(d_full, packed.size, w, h, 4, 0, 1, bad, d_rows, st)
+    torch.cuda.synchronize()
+    assert int(st.item()) != 0
+    eng.close()
 
 
 @pytest.mark.gpu
