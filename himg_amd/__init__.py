@@ -87,6 +87,17 @@ def lib():
     L.himg_hip_decode_index_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp, vp]
     L.himg_hip_decode_rows_indexed_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.himg_hip_index_host.argtypes = [vp, sz, i32, P(i32), P(i32), P(i32), vp, sz, P(C.c_uint32)]
+    L.himg_hip_create_multi.argtypes = [vp, i32, P(vp)]
+    L.himg_hip_destroy_multi.argtypes = [vp]
+    L.himg_hip_destroy_multi.restype = None
+    L.himg_hip_multi_count.argtypes = [vp]
+    L.himg_hip_multi_last_error.argtypes = [vp]
+    L.himg_hip_multi_last_error.restype = C.c_char_p
+    L.himg_hip_multi_set_option.argtypes = [vp, i32, i32]
+    L.himg_hip_multi_encode_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_multi_decode_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.himg_hip_multi_encode.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, P(vp), P(sz)]
+    L.himg_hip_multi_decode.argtypes = [vp, vp, sz, P(vp), P(i32), P(i32), P(i32)]
     L.himg_hip_shard_stats.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_shard_row_bits.argtypes = [vp, vp, vp, vp]
     L.himg_hip_shard_emit.argtypes = [vp, vp, vp, sz, vp, vp]
@@ -130,31 +141,18 @@ def max_packed_size(width, height, channels):
     return int(lib().himg_hip_max_packed_size(width, height, channels))
 
 
-class _Pinned:
-    def __init__(self, ptr):
-        self.ptr = ptr
-
-    def __del__(self):
-        try:
-            lib().himg_hip_host_free(self.ptr)
-        except Exception:
-            pass
-
-
 def pinned_empty(nbytes):
     """uint8 numpy array in page-locked host memory (himg_hip_host_alloc): the host
-    API's transfers from / to it are asynchronous DMA.  Freed with the array."""
+    API's transfers from / to it are asynchronous DMA.  The allocation is released when
+    the ctypes buffer behind the array -- which every view of it keeps alive -- is
+    collected."""
+    import weakref
     ptr = lib().himg_hip_host_alloc(int(nbytes))
     if not ptr:
         raise MemoryError("himg_hip_host_alloc(%d)" % nbytes)
-    owner = _Pinned(ptr)
     buf = (C.c_uint8 * int(nbytes)).from_address(ptr)
-    a = np.frombuffer(buf, np.uint8)
-    _PIN_OWNERS[a.__array_interface__["data"][0]] = owner   # keep the allocation alive as long as the module
-    return a
-
-
-_PIN_OWNERS = {}
+    weakref.finalize(buf, lib().himg_hip_host_free, ptr)
+    return np.frombuffer(buf, np.uint8)
 
 
 def psnr(a, b):
@@ -364,6 +362,97 @@ class Engine:
         rc = lib().himg_hip_profile_read(self._ctx, C.byref(n), names, ms, cnt)
         self._check(rc, "profile_read")
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n.value)}
+
+
+class MultiEngine:
+    """himg_hip_create_multi: several device slots behind one handle (the same device may
+    be named more than once).  encode() / decode() shard ONE frame by block rows over the
+    slots; encode_batch() / decode_batch() deal independent frames over them."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._m = C.c_void_p()
+        rc = lib().himg_hip_create_multi(devs, len(devices), C.byref(self._m))
+        if rc:
+            raise HimgError(rc, "himg_hip_create_multi (no usable GPU? there is no CPU fallback)")
+        self.devices = list(devices)
+
+    def close(self):
+        if self._m:
+            lib().himg_hip_destroy_multi(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise HimgError(rc, "%s: %s" % (what, lib().himg_hip_multi_last_error(self._m).decode()))
+
+    def set_option(self, option, value):
+        opt = {"fix_t2": 1}[option] if isinstance(option, str) else int(option)
+        self._check(lib().himg_hip_multi_set_option(self._m, opt, int(value)), "set_option")
+
+    def encode(self, img, quality=50, use_ycbcr=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]
+        ch = img.shape[2] if img.ndim == 3 else 1
+        out, n = C.c_void_p(), C.c_size_t()
+        rc = lib().himg_hip_multi_encode(self._m, img.ctypes.data, w, h, ch, ch, quality, 1 if use_ycbcr else 0,
+                                         C.byref(out), C.byref(n))
+        self._check(rc, "multi_encode")
+        a = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), (n.value,)).copy()
+        lib().himg_hip_free(out)
+        return a
+
+    def decode(self, packed):
+        packed = np.ascontiguousarray(np.frombuffer(packed, np.uint8) if isinstance(packed, (bytes, bytearray)) else packed)
+        out = C.c_void_p()
+        w, h, c = C.c_int(), C.c_int(), C.c_int()
+        rc = lib().himg_hip_multi_decode(self._m, packed.ctypes.data, packed.nbytes, C.byref(out), C.byref(w),
+                                         C.byref(h), C.byref(c))
+        if rc:
+            raise HimgError(rc, "multi_decode")
+        n = w.value * h.value * c.value
+        a = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), (n,)).copy().reshape(h.value, w.value, c.value)
+        lib().himg_hip_free(out)
+        return a
+
+    def encode_batch(self, frames, quality=50, use_ycbcr=True):
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        n = len(frames)
+        h, w = frames[0].shape[:2]
+        ch = frames[0].shape[2] if frames[0].ndim == 3 else 1
+        cap = max_packed_size(w, h, ch)
+        outs = [np.empty(cap, np.uint8) for _ in range(n)]
+        src = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+        sizes = (C.c_size_t * n)()
+        rc = lib().himg_hip_multi_encode_batch(self._m, src, n, w, h, ch, ch, quality, 1 if use_ycbcr else 0,
+                                               dst, caps, sizes)
+        self._check(rc, "multi_encode_batch")
+        return [o[: sizes[i]] for i, o in enumerate(outs)]
+
+    def decode_batch(self, streams):
+        streams = [np.ascontiguousarray(s, np.uint8) for s in streams]
+        n = len(streams)
+        outs = []
+        for s_ in streams:
+            w, h, c = C.c_int(), C.c_int(), C.c_int()
+            ok = lib().himg_hip_peek(s_.ctypes.data, s_.nbytes, C.byref(w), C.byref(h), C.byref(c)) == HIMG_OK
+            outs.append(np.empty(w.value * h.value * c.value if ok else 1, np.uint8))
+        src = (C.c_void_p * n)(*[s_.ctypes.data for s_ in streams])
+        szs = (C.c_size_t * n)(*[s_.nbytes for s_ in streams])
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        caps = (C.c_size_t * n)(*[o.nbytes for o in outs])
+        ws, hs, cs = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+        rc = lib().himg_hip_multi_decode_batch(self._m, src, szs, n, dst, caps, ws, hs, cs)
+        self._check(rc, "multi_decode_batch")
+        return [o[: ws[i] * hs[i] * cs[i]].reshape(hs[i], ws[i], cs[i]) for i, o in enumerate(outs)]
 
 
 def index_host(packed, fix_t2=False):

@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "himg_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "himg_amd", "lib")
 LIB = os.path.join(LIBDIR, "libhimg_hip.so")
 
-HIP_SOURCES = ["kernels_enc.hip", "kernels_dec.hip", "himg_hip.hip"]
+HIP_SOURCES = ["kernels_enc.hip", "kernels_dec.hip", "himg_hip.hip", "himg_multi.hip"]
 CXX_SOURCES = ["encoder.cpp", "decoder.cpp"]
 C_SOURCES = ["himg_tables.c", "himg_synth.c"]
 HEADERS = ["himg_dev.h", "himg_tables.h", "ctx_pool.h", "../../include/himg_hip.h",
@@ -40,6 +40,13 @@ def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES + CXX_SOURCES + C_SOURCES
             if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    # Experimental -D flags are part of the rebuild decision: a library built with
+    # them is not silently reused by a run without them (and vice versa).
+    extra = os.environ.get("HIMG_EXTRA_HIPCC_FLAGS", "").strip()
+    stamp = os.path.join(LIBDIR, "hipcc_flags.stamp")
+    old_extra = open(stamp).read() if os.path.exists(stamp) else ""
+    if extra != old_extra:
+        force = True
     if not force and not _stale(LIB, deps):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
@@ -65,6 +72,8 @@ def build_lib(force=False, verbose=False):
     subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs
                    + ["-lpthread"], check=True)
     os.replace(tmp, LIB)
+    with open(stamp, "w") as fh:
+        fh.write(extra)
     return LIB
 
 

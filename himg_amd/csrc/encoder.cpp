@@ -24,16 +24,51 @@ long ChunkSize(const uint8_t *s, size_t size, const char tag[4]) {
 }
 }  // namespace
 
-Encoder::Encoder() : m_ctx(nullptr), m_packed_size(0) {}
+Encoder::Encoder() : m_ctx(nullptr), m_multi(nullptr), m_packed_size(0) {}
 
 Encoder::~Encoder() {
   detail::release_ctx(m_ctx);
+  detail::release_multi(m_multi);
+}
+
+Encoder::Encoder(const Encoder &other) : m_ctx(nullptr), m_multi(nullptr), m_packed_size(0) { *this = other; }
+
+Encoder &Encoder::operator=(const Encoder &other) {
+  if (this != &other) {
+    m_packed_data.reset(other.m_packed_size ? new uint8_t[other.m_packed_size] : nullptr);
+    m_packed_size = other.m_packed_size;
+    if (m_packed_size) std::memcpy(m_packed_data.get(), other.m_packed_data.get(), m_packed_size);
+  }
+  return *this;
 }
 
 bool Encoder::Encode(const uint8_t *data, int width, int height, int pixel_stride,
                      int num_channels, int quality, bool use_ycbcr) {
   m_packed_data.reset();
   m_packed_size = 0;
+  if (detail::use_multi()) {
+    // Several devices (HIMG_DEVICES): one frame, block rows sharded over them.
+    if (!m_multi) m_multi = detail::acquire_multi();
+    if (!m_multi) {
+      std::cout << "Error: no usable MI355X devices (the HIMG engine has no CPU fallback).\n";
+      return false;
+    }
+    uint8_t *out = nullptr;
+    size_t n = 0;
+    const int rc = himg_hip_multi_encode(m_multi, data, width, height, pixel_stride, num_channels, quality,
+                                         use_ycbcr ? 1 : 0, &out, &n);
+    if (rc != HIMG_OK) {
+      std::cout << "Error: " << himg_hip_multi_last_error(m_multi) << "\n";
+      return false;
+    }
+    m_packed_data.reset(new uint8_t[n]);
+    std::memcpy(m_packed_data.get(), out, n);
+    himg_hip_free(out);
+    m_packed_size = n;
+    std::cout << "Low resolution data: " << ChunkSize(m_packed_data.get(), n, "LRES") << " bytes.\n";
+    std::cout << "Full resolution data: " << ChunkSize(m_packed_data.get(), n, "FRES") << " bytes.\n";
+    return true;
+  }
   if (!m_ctx) m_ctx = detail::acquire_ctx();
   if (!m_ctx) {
     std::cout << "Error: no usable MI355X device (the HIMG engine has no CPU fallback).\n";

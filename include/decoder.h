@@ -12,6 +12,7 @@
 #include <vector>  // the reference's headers pull it in (encoder.h:13, decoder.h:13) and its callers rely on that
 
 struct himg_hip_ctx;
+struct himg_hip_multi;
 
 namespace himg {
 
@@ -21,8 +22,10 @@ class Decoder {
   // block rows are decoded in parallel on the GPU regardless of its value.
   Decoder(int max_threads = 0);
   ~Decoder();
-  Decoder(const Decoder &) = delete;
-  Decoder &operator=(const Decoder &) = delete;
+  // Copyable like the reference's class (decoder.h:22-67): a copy holds a copy of the
+  // unpacked picture; engine contexts are borrowed per object.
+  Decoder(const Decoder &other);
+  Decoder &operator=(const Decoder &other);
 
   // Same contract as the reference (decoder.cpp:87-138): the input is borrowed
   // for the call, the output is owned by the object until the next Decode.
@@ -39,6 +42,7 @@ class Decoder {
 
  private:
   himg_hip_ctx *m_ctx;
+  himg_hip_multi *m_multi;   // HIMG_DEVICES names several devices
   int m_max_threads;
   // Kept (and its pages kept mapped) across Decode calls: the copy from the GPU
   // then runs at PCIe speed instead of page-faulting through a fresh allocation.

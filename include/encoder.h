@@ -14,6 +14,7 @@
 #include <vector>  // the reference's headers pull it in (encoder.h:13, decoder.h:13) and its callers rely on that
 
 struct himg_hip_ctx;
+struct himg_hip_multi;
 
 namespace himg {
 
@@ -21,8 +22,10 @@ class Encoder {
  public:
   Encoder();
   ~Encoder();
-  Encoder(const Encoder &) = delete;
-  Encoder &operator=(const Encoder &) = delete;
+  // Copyable like the reference's class (its members are plain vectors, encoder.h:36-64):
+  // a copy holds a copy of the packed stream; engine contexts are borrowed per object.
+  Encoder(const Encoder &other);
+  Encoder &operator=(const Encoder &other);
 
   // Same contract as the reference (encoder.cpp:59-109): `data` is read during
   // the call only; rows are tightly packed width*pixel_stride bytes.  Prints the
@@ -44,6 +47,7 @@ class Encoder {
 
  private:
   himg_hip_ctx *m_ctx;
+  himg_hip_multi *m_multi;                    // HIMG_DEVICES names several devices
   std::unique_ptr<uint8_t[]> m_packed_data;  // uninitialised storage, exactly the stream
   size_t m_packed_size;
 };

@@ -235,6 +235,49 @@ int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void *d_packed,
                                         const uint32_t *d_row_index, void *d_out_rows,
                                         int32_t *d_status, void *stream);
 
+/* ---- multi-device: several GPUs of one node behind this ABI ------------------- */
+/*
+ * One handle over n device slots (one engine context, one stream and one host thread
+ * per slot; the same device may be named more than once).  What it replaces in the
+ * reference is the decoder's worker pool (decoder.cpp:292-326: block rows handed to
+ * threads) -- here the workers are GPUs -- and nothing on the encoder side, which is
+ * single-threaded (encoder.cpp:258-335).
+ *   himg_hip_multi_encode_batch / _decode_batch   independent frames dealt over the slots
+ *       (contiguous shares); per-frame semantics of himg_hip_encode_batch / _decode_batch.
+ *       No exchange step.
+ *   himg_hip_multi_encode   ONE frame, block rows sharded (multiples of 16 rows): the
+ *       histograms (261 x u32) and the row bit counts (rows x u32) meet on the host, the
+ *       low-res rows go to slot 0 by peer copy, and every slot packs its rows straight
+ *       into slot 0's buffer through peer access (xGMI; without peer access: packed
+ *       locally, then one peer copy per slot).  Byte-identical to himg_hip_encode.
+ *   himg_hip_multi_decode   ONE frame: the host indexes the block rows
+ *       (himg_hip_index_host), every slot receives the head of the stream and only its
+ *       own rows' bytes, decodes them and copies its pixel rows into the result.
+ *       Accepts and rejects exactly like himg_hip_decode.
+ * Frames of fewer than 32 block rows and handles with one slot take the single-device
+ * path.  *out of the two one-frame calls is malloc'ed (himg_hip_free).
+ * himg::Encoder / himg::Decoder use such a handle when HIMG_DEVICES names more than one
+ * device ("0-7", "0,2,4", "0,0": slots on one GPU).
+ */
+typedef struct himg_hip_multi himg_hip_multi;
+int himg_hip_create_multi(const int *devices, int n, himg_hip_multi **out);
+void himg_hip_destroy_multi(himg_hip_multi *m);
+int himg_hip_multi_count(const himg_hip_multi *m);
+const char *himg_hip_multi_last_error(const himg_hip_multi *m);
+int himg_hip_multi_set_option(himg_hip_multi *m, int option, int value);
+int himg_hip_multi_encode_batch(himg_hip_multi *m, const uint8_t *const *frames, int n, int width,
+                                int height, int pixel_stride, int num_channels, int quality,
+                                int use_ycbcr, uint8_t *const *dst, const size_t *dst_cap,
+                                size_t *out_sizes);
+int himg_hip_multi_decode_batch(himg_hip_multi *m, const uint8_t *const *packed,
+                                const size_t *packed_sizes, int n, uint8_t *const *dst,
+                                const size_t *dst_cap, int *widths, int *heights, int *channels);
+int himg_hip_multi_encode(himg_hip_multi *m, const uint8_t *data, int width, int height,
+                          int pixel_stride, int num_channels, int quality, int use_ycbcr,
+                          uint8_t **out, size_t *out_size);
+int himg_hip_multi_decode(himg_hip_multi *m, const uint8_t *packed, size_t packed_size, uint8_t **out,
+                          int *width, int *height, int *num_channels);
+
 /* ---- introspection for parity tests and bench.py ------------------------ */
 
 /* Intermediate device buffers of the LAST encode/decode on this context
