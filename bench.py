@@ -619,13 +619,13 @@ def main():
                     traffic = per_frame[key] * G
                     traffic_src = "profiles/traffic.json (PMC passes at commit %s, not this run)" % tj.get("git_sha", "?")
                 pmc = tj.get("valu", {})
-            # VALU issue of that kernel from the same PMC passes: wave-instructions per
-            # symbol and the fraction of the chip's issue peak (256 CUs x 1 wave-instruction
-            # per cycle x 2.4 GHz = 6.1e11 /s) -- what actually bounds these kernels.
+            # VALU issue of that kernel from the same PMC passes: the SIMD issue time of its
+            # instruction count at the kernel's class-weighted measured cost
+            # (profiles/r03_isa_mix.json over profiles/r03_valu_rate.txt) over its duration.
             valu_busy = None
             for k, v in pmc.items():
                 if k.split("<")[0] == key:
-                    valu_busy = v.get("issue_frac")
+                    valu_busy = v.get("issue_frac_measured_mix", v.get("issue_frac"))
             roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom.strip("()").split("<")[0] in enc_stages else "decode",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -658,7 +658,12 @@ def main():
                 "encode_frac": round(alg_bytes_side / t_enc / 1e9 / HBM_PEAK_GBS, 4),
                 "decode_frac": round(alg_bytes_side / t_dec / 1e9 / HBM_PEAK_GBS, 4)},
             "roofline": roofline,
-            "roofline_valu": ({"peak_wave_insts_per_s": 6.144e11, "source": traffic_src, "kernels": pmc} if pmc else None),
+            "roofline_valu": ({"note": "per kernel: SQ_INSTS_VALU per symbol and the fraction of its duration the "
+                                       "1024 SIMDs need to ISSUE that count -- at the guide's 2 cycles per wave64 "
+                                       "instruction (SIMD-32) and at the kernel's class-weighted measured cost "
+                                       "(plain VOP1/VOP2 ~2.2, VOP3 / packed / DPP / compares ~4.1 cycles: "
+                                       "profiles/r03_valu_rate.txt, profiles/r03_isa_mix.json)",
+                               "source": traffic_src, "kernels": pmc} if pmc else None),
             "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_extras:
@@ -680,11 +685,14 @@ def main():
         # rank leaves.
         import threading
 
+        # Neither way out is a success: the line is printed so that the frames result is not
+        # lost, and the process ends NON-ZERO -- a rank hung in a collective or a stream
+        # that differs from the reference must not look like a clean run.
         def give_up():
             if rank == 0:
                 out["rows"] = {"error": "rows leg did not finish within %d s" % args.rows_timeout}
                 print(json.dumps(out), flush=True)
-            os._exit(0 if rank == 0 else 3)
+            os._exit(4 if rank == 0 else 3)
 
         dog = threading.Timer(args.rows_timeout + (0 if rank == 0 else 5), give_up)
         dog.daemon = True
@@ -697,7 +705,7 @@ def main():
             rows_obj = {"error": "%s: %s" % (type(e).__name__, e)}
             out["rows"] = rows_obj
             print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(4)
         dog.cancel()
         if rank == 0:
             out["rows"] = rows_obj

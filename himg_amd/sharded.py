@@ -349,6 +349,23 @@ class ShardedDecoder:
         import torch.distributed as dist
         world, rank, rows, group = self.world, self.rank, self.rows, self.group
         self.bytes_from_rank0 = 0
+        if world == 1 and hasattr(self.eng, "decode_rows_device"):
+            # One rank: nothing to scatter -- the plain row-range decode, whose header walk
+            # runs beside the container parse instead of in front of it.
+            size = int(packed.numel() if torch.is_tensor(packed) else len(packed))
+            if torch.is_tensor(packed) and packed.device == self.dev and packed.data_ptr() % 16 == 0 \
+                    and packed.numel() % 4 == 0:
+                buf = packed
+            else:
+                buf = self._buffer(size)
+                src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
+                buf[:size] = src.to(self.dev)
+            self.d_status.zero_()
+            self.eng.decode_rows_device(buf, size, self.W, self.H, self.C, 0, rows, self.d_rows, self.d_status, self._s())
+            ok = int(self.d_status[0].item()) == 0
+            if not gather:
+                return ok, (self.d_rows if ok else None)
+            return ok, (self.d_rows.cpu().numpy() if ok else None)
         d_src = None
         if rank == 0:
             size, ok, first, off, ln, d_src = self._index_rank0(packed)

@@ -96,3 +96,58 @@ def test_oracle_accepts_nonzero_pad_bits():
     # flipping a pad bit never changes the decode; if it was a data bit the
     # stream may be rejected -- either way the decoder must not crash.
     assert rc2 != 0 or pix2.shape == ref_pix.shape
+
+
+def test_oracle_under_sanitizers():
+    """the restatement under ASan + UBSan (the reference itself trips
+    UBSan at quantize.cpp:163 and ASan at decoder.cpp:354; the restatement must be clean).
+    The golden 64x64 cases plus ragged shapes go through libhimg_oracle_asan.so in a
+    child process (the sanitizer runtime has to be loaded first)."""
+    import os
+    import subprocess
+    import sys
+    so = os.path.join(ol.ORACLE_DIR, "libhimg_oracle_asan.so")
+    subprocess.run(["make", "-s", "-C", ol.ORACLE_DIR, "libhimg_oracle_asan.so"], check=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    assert os.path.exists(asan), asan
+    code = r'''
+import sys, os, ctypes as C
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import himg_amd
+from golden_util import GOLDEN, cases, fixture, make_input
+L = C.CDLL(%r)
+L.himg_oracle_free.restype = None
+def enc(img, q, ycbcr, ch, st):
+    h, w = img.shape[:2]
+    out, n = C.POINTER(C.c_uint8)(), C.c_int()
+    rc = L.himg_oracle_encode(img.ctypes.data_as(C.c_void_p), w, h, st, ch, q, 1 if ycbcr else 0, C.byref(out), C.byref(n), None)
+    assert rc == 0
+    a = np.ctypeslib.as_array(out, (n.value,)).copy(); L.himg_oracle_free(out); return a
+def dec(p, threads):
+    out = C.POINTER(C.c_uint8)(); w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = L.himg_oracle_decode(p.ctypes.data_as(C.c_void_p), p.nbytes, threads, C.byref(out), C.byref(w), C.byref(h), C.byref(c))
+    if rc == 0:
+        L.himg_oracle_free(out)
+    return rc
+n = 0
+for name in cases(max_pixels=64 * 64):
+    rec = GOLDEN[name]
+    img = make_input(rec)
+    p = enc(img, rec["quality"], bool(rec["ycbcr"]), img.shape[2], img.shape[2])
+    assert himg_amd.fnv1a64(p) == rec["stream_fnv"], name
+    assert (dec(p, 2) == 0) == bool(rec["decodes"]), name
+    n += 1
+for (w, h, ch, q) in ((72, 40, 4, 20), (13, 21, 3, 90), (8, 8, 1, 50), (136, 9, 4, 100)):
+    img = np.ascontiguousarray(himg_amd.synth("rand", 7, w, h)[:, :, :ch])
+    p = enc(img, q, True, ch, ch)
+    dec(p, 1)
+    bad = p.copy(); bad[len(bad) // 2] ^= 0x55
+    dec(bad, 1)          # a damaged stream must not read or write out of bounds either
+    n += 1
+print("sanitizer run ok:", n, "cases")
+''' % (os.path.dirname(ol.ROOT) if False else ol.ROOT, os.path.join(ol.ROOT, "tests"), so)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sanitizer run ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
