@@ -1705,8 +1705,17 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   __shared__ StreamShared sh;
   const int k = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
+  // Everything the common path reads from global memory is requested in front of the
+  // first barrier (the verdict, the chunk's output base, the lane's start and count,
+  // the tables), so that the round trips overlap: the kernel is a handful of dependent
+  // round trips long and runs on an empty GPU in front of the row kernel.
+  const size_t slot = (size_t)f * ws.lres_chunks + k;
+  const unsigned long long O0 = ws.ver_base[slot];
+  const uint32_t start_rel = ws.spec_start[slot * kDecThreads + tid];
+  const unsigned long long cnt = ws.spec_cnt[slot * kDecThreads + tid];
   // One read for the whole workgroup (other kernels may flag the frame meanwhile).
   if (tid == 0) sh.flag = df->status ? 1 : (ws.ver_ok[f] ? 0 : 2);
+  load_dec_tables(ws, df, f, 0, &T);
   __syncthreads();
   if (sh.flag == 1) return;
   if (sh.flag == 2) {
@@ -1714,8 +1723,6 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
     // the test knob): this frame's LRES stream is decoded by ONE workgroup, chunk
     // after chunk, every chunk starting at the exact end of the one before.
     if (k != 0) return;
-    load_dec_tables(ws, df, f, 0, &T);
-    __syncthreads();
     const GrpTables tb0 = tables_of(&T);
     const uint32_t po = df->s[0].payload_off;
     const int bad = decode_stream<false, true>(packed + (size_t)f * in_stride, sizes[f], po, df->s[0].chunk_end - po,
@@ -1731,10 +1738,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const unsigned long long cur = (unsigned long long)k * kLresChunkBits;
   if (cur >= P1) return;
   const uint32_t out_size = (uint32_t)g.lres_size;
-  const size_t slot = (size_t)f * ws.lres_chunks + k;
-  const unsigned long long O0 = ws.ver_base[slot];
   if (O0 >= out_size) return;
-  load_dec_tables(ws, df, f, 0, &T);
   if (tid == 0) { sh.err = 0; sh.endbit = ~0ull; }
   const GrpTables tb = tables_of(&T);
   GReader rd;
@@ -1743,8 +1747,7 @@ __global__ __launch_bounds__(kDecThreads) void k_lres_write(Geom g, DecWs ws, co
   const uint32_t rel_end = rel0 + (uint32_t)(rem < (unsigned long long)kLresChunkBits ? rem : kLresChunkBits);
   uint32_t lim = rel0 + (tid + 1) * kLresSubBits;
   if (lim > rel_end) lim = rel_end;
-  const uint32_t start = rel0 + ws.spec_start[slot * kDecThreads + tid];
-  const unsigned long long cnt = ws.spec_cnt[slot * kDecThreads + tid];
+  const uint32_t start = rel0 + start_rel;
   __syncthreads();
   unsigned long long tot;
   const unsigned long long off = block_scan_u64(cnt, sh.sm64, &tot);
@@ -1786,19 +1789,32 @@ __device__ __forceinline__ int predict_d(int s1, int s2, int s3, int p) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
-  // Four macro blocks per wavefront, 16 lanes each (see k_lres_predict).
-  __shared__ uint8_t rec[4][16][17];
+// LDS exchange inside ONE wavefront: its LDS operations execute in order, so the
+// fences only keep the compiler from moving them.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Sixteen macro blocks per workgroup: four wavefronts, each on its own (four blocks of
+// 16 lanes, see k_lres_predict) -- one-wavefront workgroups made this kernel a test of
+// the dispatcher (65 536 workgroups for 64 frames of 4096 x 4096), and it sits on the
+// critical path between k_row_count and the row kernel.
+constexpr int kUnpredWaves = 4;
+__global__ __launch_bounds__(64 * kUnpredWaves) void k_lres_unpredict(Geom g, DecWs ws) {
+  __shared__ uint8_t rec_s[kUnpredWaves][4][16][17];
+  __shared__ uint8_t dl_s[kUnpredWaves][4][16][16];   // the blocks' deltas: the chain below reads one per step
   __shared__ int16_t s_lmap[128];   // the chain below looks a delta up per step: LDS, not global
-  const int lane = threadIdx.x, b = lane >> 4, dv = lane & 15;
-  const int mu = blockIdx.x * 4 + b, mv = blockIdx.y;
+  __shared__ int s_status;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = lane >> 4, dv = lane & 15;
+  uint8_t (*rec)[16][17] = rec_s[wv];
+  uint8_t (*dl)[16][16] = dl_s[wv];
+  const int mu = (blockIdx.x * kUnpredWaves + wv) * 4 + b, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
   const DecFrame *df = ws.frames + f;
-  // A single wavefront: the read is one scalar load, uniform by construction.
-  if (__builtin_amdgcn_readfirstlane(df->status)) return;
-  s_lmap[lane] = df->lmap[lane];
-  s_lmap[lane + 64] = df->lmap[lane + 64];
-  __syncthreads();
+  if (threadIdx.x == 0) s_status = df->status;
+  if (threadIdx.x < 128) s_lmap[threadIdx.x] = df->lmap[threadIdx.x];
   const uint8_t *in = ws.lres_sym + (size_t)f * ws.lres_stride + (size_t)c * g.chan_size;
   uint8_t *m = ws.low + (size_t)f * ws.plane_stride + (size_t)c * g.rows * g.cols;
   const bool live = mu < g.mcols;
@@ -1808,6 +1824,15 @@ __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
   // stored 254/255 come back as 256/257 and fall into PredictSample's default.
   const int pc = live ? (int)in[mv * g.mcols + mu] + 2 : 0;
   const uint8_t *src = in + g.mrows * g.mcols + (size_t)v0 * g.cols + (size_t)bh * u0;
+  // The lane's row of deltas goes to LDS up front (sixteen loads in flight at once)
+  // instead of one dependent global load per step of the chain.
+  if (dv < bh) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < bw) dl[b][dv][k] = src[dv * bw + k];
+  }
+  __syncthreads();
+  if (s_status) return;
   for (int d = 0; d < 31; ++d) {
     const int du = d - dv;
     if (dv < bh && du >= 0 && du < bw) {
@@ -1817,14 +1842,14 @@ __global__ __launch_bounds__(64) void k_lres_unpredict(Geom g, DecWs ws) {
       else if (dv > 0) { s1 = s2 = s3 = rec[b][dv - 1][du]; }
       else { s1 = s2 = s3 = 128; }
       const int predicted = predict_d(s1, s2, s3, pc);
-      const int sc = (int8_t)src[dv * bw + du];
+      const int sc = (int8_t)dl[b][dv][du];
       // mapper.h:33-35 with the mirrored table (mapper.cpp:148-154).
       const int un = sc >= 0 ? s_lmap[sc] : (sc == -128 ? -s_lmap[127] : -s_lmap[-sc]);
       const int val = clamp255d((int)(int16_t)(predicted + un));
       rec[b][dv][du] = (uint8_t)val;
       m[(size_t)(v0 + dv) * g.cols + u0 + du] = (uint8_t)val;
     }
-    __syncthreads();
+    wave_lds_sync();   // (the exchange is inside the wavefront)
   }
 }
 
@@ -2750,7 +2775,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
               in_stride, d_sizes);
   HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);
   if (wps) {
-    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 3) / 4, g.mrows, batch * g.C), dim3(64), g, ws);
+    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
+                dim3(64 * kUnpredWaves), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (!side && nrows > 0)
       HIMG_LAUNCH(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
@@ -2796,7 +2822,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, 1 + r0, 1, 2);
     }
-    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 3) / 4, g.mrows, batch * g.C), dim3(64), g, ws);
+    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
+                dim3(64 * kUnpredWaves), g, ws);
     if (nrows > 0) HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
   }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
