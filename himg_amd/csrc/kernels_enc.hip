@@ -1560,6 +1560,10 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
       // together with word j + 1.
       const uint32_t sh = my_pos & 31;
       uint32_t widx = (my_pos >> 5) & (kStageWords - 1), carry = 0;
+      // (Not unrolled: fully unrolled to kPrivWords it is 103 instructions every iteration,
+      // whatever the lanes hold -- and a third of the iterations, in the sparse
+      // high-frequency rows, have one word per lane at most.)
+#pragma unroll 1
       for (uint32_t j = 0; j < nwords; ++j) {
         const unsigned long long v = (unsigned long long)s_priv[j * 256 + tid] << sh;
         atomicOr(&stage[widx], (uint32_t)v | carry);
