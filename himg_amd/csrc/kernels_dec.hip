@@ -2338,7 +2338,20 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     if (sh->flag) return;
   }
   const uint8_t *p = packed + (size_t)f * in_stride;
-  load_dec_tables(ws, df, f, 1, &T);
+  // The decode tables: the loads first (one group-table and one sub-table quad-word
+  // per lane, a tree node for the first 522 -- every slot of the workspace, so that the
+  // node count need not be known), then the clear of the symbol area below while they
+  // are in flight, then the stores.
+  static_assert((1 << kLutBits) / 2 == kDecThreads && kSubEntries / 2 <= kDecThreads && kMaxNodes + 1 <= kDecThreads,
+                "one table element per lane");
+  const uint4 t_grp = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits))[tid];
+  uint4 t_sub = make_uint4(0, 0, 0, 0);
+  if (tid < kSubEntries / 2) t_sub = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries)[tid];
+  int t_n0 = 0, t_n1 = 0, t_n2 = 0;
+  if (tid < kMaxNodes + 1) {
+    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
+    t_n0 = nodes[3 * tid]; t_n1 = nodes[3 * tid + 1]; t_n2 = nodes[3 * tid + 2];
+  }
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -2380,6 +2393,9 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     const int n16 = (int)(rb16 >> 4) * nr;
     for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym0)[k] = z;
   }
+  reinterpret_cast<uint4 *>(T.grp)[tid] = t_grp;
+  if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(T.grp + (1 << kLutBits))[tid] = t_sub;
+  if (tid < kMaxNodes + 1) T.nd[tid] = pack_node(t_n0, t_n1, t_n2);
   __syncthreads();
   if constexpr (COLS == 512) {
     if (sh->flag) return;   // (uniform: one read, in front of the barrier above)
@@ -2806,25 +2822,30 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
 #undef HIMG_FUSED_LAUNCH
     prof_end(prof, stream);
   } else {
+    // Symbols through HBM: the write pass stores the non-zero literals into the zeroed
+    // plane.  The clear (1 GiB for a 16384 x 16384 frame) and the predictor inverse go
+    // in FRONT of the join: the side stream is still walking the row headers and
+    // counting (a serial 1.1 ms walk at that size), this stream has nothing else to do.
+    if (nrows > 0) {
+      prof_begin(prof, "memset", stream);
+      (void)hipMemset2DAsync(ws.fres_sym + (size_t)r0 * g.row_block, ws.fres_stride, 0,
+                             (size_t)nrows * g.row_block, (size_t)batch, stream);
+      prof_end(prof, stream);
+    }
+    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
+                dim3(64 * kUnpredWaves), g, ws);
     if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (!side && nrows > 0)
       HIMG_LAUNCH(k_row_count<false>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
                   d_packed, in_stride, d_sizes, r0, r1, rpc);
     if (nrows > 0) {
-      // Symbols through HBM: the write pass stores the non-zero literals into the
-      // zeroed plane; rows without a usable fixpoint (several chunks) take the window
-      // path of k_dec_huff, which skips the others.
-      prof_begin(prof, "memset", stream);
-      (void)hipMemset2DAsync(ws.fres_sym + (size_t)r0 * g.row_block, ws.fres_stride, 0,
-                             (size_t)nrows * g.row_block, (size_t)batch, stream);
-      prof_end(prof, stream);
+      // Rows without a usable fixpoint (several chunks) take the window path of
+      // k_dec_huff, which skips the others.
       HIMG_LAUNCH(k_row_write_g, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, r0);
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, 1 + r0, 1, 2);
+      HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
     }
-    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
-                dim3(64 * kUnpredWaves), g, ws);
-    if (nrows > 0) HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
   }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
 }
