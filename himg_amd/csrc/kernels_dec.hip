@@ -1054,8 +1054,15 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
 // two aligned ds_or (the bytes past the group are zeros, so neighbours are never
 // disturbed).  The caller guarantees that all of the lane's symbols lie strictly
 // inside the block.  Same two loops as lean_count.
+// CLIP: lds_out is a WINDOW of the block (k_row_window): op counts from kWinGuard
+// bytes in front of the window's first symbol and the lane's symbols may lie before,
+// inside or behind it; a group is OR-ed in when its first byte is less than 8 bytes in
+// front of the window or inside it (win_span = window bytes + kWinGuard: one unsigned
+// compare), so the two dwords it touches stay inside [0, win_span + 8).
+constexpr uint32_t kWinGuard = 16;
+template <bool CLIP = false>
 __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint32_t bp,
-                                           uint32_t lim, uint32_t op, uint8_t *lds_out) {
+                                           uint32_t lim, uint32_t op, uint8_t *lds_out, uint32_t win_span = 0) {
   bool bad = false;
   if (bp < lim) {
     rd.init(bp);
@@ -1085,9 +1092,11 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
       const uint32_t n = y >> 27;
       rd.consume((int)n);
-      const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
-      atomicOr(&o32[op >> 2], (uint32_t)v);
-      atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      if (!CLIP || op - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
+        const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
+        atomicOr(&o32[op >> 2], (uint32_t)v);
+        atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      }
       op += ((y >> 10) & 511u) + extra;
       bp += adv + n;
     };
@@ -1096,7 +1105,7 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
     while (bp < lim) {
       uint32_t nbits, cnt, by;
       lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
-      if (by) lds_out[op] = (uint8_t)by;
+      if (by && (!CLIP || op - kWinGuard < win_span - kWinGuard)) lds_out[op] = (uint8_t)by;
       op += cnt;
       bp += nbits;
     }
@@ -1108,11 +1117,16 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
 // the reference's end-of-block checks (huffman_dec.cpp:353-354,361-417).
 // Returns false on a stream error; *end_bp = bit position where the block became
 // complete (~0u if it did not).
+// CLIP: as in lean_write; op and out_size then both count from the window's guard.
+template <bool CLIP = false>
 __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uint32_t bp,
                                             uint32_t lim, uint32_t op, uint32_t out_size,
-                                            uint8_t *lds_out, uint32_t *end_bp) {
+                                            uint8_t *lds_out, uint32_t *end_bp, uint32_t win_span = 0) {
   *end_bp = ~0u;
-  if (!(bp < lim) || op >= out_size) return true;
+  // Positions are compared as SIGNED numbers: in a window (CLIP) a lane may start in
+  // front of it, its position then lies below zero (everything is far below 2^31).
+  const auto before = [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; };
+  if (!(bp < lim) || !before(op, out_size)) return true;
   rd.init(bp);
   bool bad = false;
   // Whole groups first, as long as the block stays incomplete behind them: this lane is
@@ -1129,10 +1143,12 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
       uint32_t nbits, cnt, by;
       bool gbad = false;
       lean_step<true>(rd, t, false, &nbits, &cnt, &by, &gbad);
-      if (gbad || op + cnt >= out_size) { rd = saved; break; }
-      const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
-      atomicOr(&o32[op >> 2], (uint32_t)v);
-      atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      if (gbad || !before(op + cnt, out_size)) { rd = saved; break; }
+      if (!CLIP || op - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
+        const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
+        atomicOr(&o32[op >> 2], (uint32_t)v);
+        atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+      }
       op += cnt;
       bp += nbits;
     }
@@ -1141,11 +1157,11 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
     uint32_t nbits, cnt, by;
     lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
     if (bad) return false;
-    if (op + cnt > out_size) return false;  // a zero run overruns the block
-    if (by) lds_out[op] = (uint8_t)by;
+    if (before(out_size, op + cnt)) return false;  // a zero run overruns the block
+    if (by && (!CLIP || op - kWinGuard < win_span - kWinGuard)) lds_out[op] = (uint8_t)by;
     op += cnt;
     bp += nbits;
-    if (op >= out_size) { *end_bp = bp; return true; }
+    if (!before(op, out_size)) { *end_bp = bp; return true; }
     if (!(bp < lim)) return true;
   }
 }
@@ -2669,6 +2685,89 @@ __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, c
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_row_window: write pass of rows whose symbols do not fit the LDS (wider than 4224
+// pixels), one workgroup per 128 KiB WINDOW of a row's symbols (a channel plane of a
+// 16384-pixel row).  Every lane looks at its own record from k_row_count and decodes its
+// sub-sequence if its symbols touch the window -- about a quarter of the lanes of a
+// 16384-pixel row, the two at the edges for both neighbours --, OR-ing the literals
+// into the zeroed window in LDS exactly like the fused row kernel; the window then
+// leaves as 16-byte stores.  (k_row_write_g stores every group straight to HBM: 64
+// different cache lines per wave instruction, 3.5 ms for a 16384 x 16384 frame against
+// 1.0 ms for the same walk without the stores, plus 0.4 ms to clear the plane first.)
+// Rows without a usable fixpoint from k_row_count are k_dec_huff's, as before.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRowWindow = 128u * 1024u;
+struct WinShared { int flag, err; unsigned long long endbit; };
+__global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, const uint8_t *packed,
+                                                            size_t in_stride, const uint32_t *sizes, int r0) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  LdsTables &T = *reinterpret_cast<LdsTables *>(smem);
+  WinShared &sh = *reinterpret_cast<WinShared *>(smem + sizeof(LdsTables));
+  uint8_t *win = smem + sizeof(LdsTables) + 64;          // kWinGuard + window + kWinGuard
+  const int wi = blockIdx.x, r = r0 + (int)blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
+  DecFrame *df = ws.frames + f;
+  const size_t ri = (size_t)f * g.rows + r;
+  const uint32_t *pre_start = ws.lane_start + ri * kDecThreads, *pre_off = ws.lane_off + ri * (kDecThreads + 4);
+  // Everything from global memory in front of the first barrier.
+  const uint32_t st_rel = pre_start[tid], off = pre_off[tid], nxt = pre_off[tid + 1];
+  const uint32_t tot = pre_off[kDecThreads], usable = pre_off[kDecThreads + 2];
+  const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
+  if (tid == 0) { sh.flag = (df->status || usable == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
+  load_dec_tables(ws, df, f, 1, &T);
+  const uint32_t out_size = (uint32_t)g.row_block;
+  const uint32_t w0 = (uint32_t)wi * kRowWindow, w1 = min(w0 + kRowWindow, out_size);
+  const uint32_t span = (w1 - w0) + kWinGuard;           // guard + window bytes
+  {
+    uint4 z;
+    z.x = z.y = z.z = z.w = 0;
+    for (uint32_t k = tid; k < (span + kWinGuard + 15u) / 16u; k += kDecThreads) reinterpret_cast<uint4 *>(win)[k] = z;
+  }
+  __syncthreads();
+  if (sh.flag) return;   // frame failed, or the row is k_dec_huff's
+  const GrpTables tb = tables_of(&T);
+  const unsigned long long P1 = 8ull * pay_len;
+  uint32_t sb = (uint32_t)((P1 + kDecThreads - 1) / kDecThreads);
+  sb = (sb + 31u) & ~31u;
+  sb = sb < kMinSubBits ? kMinSubBits : sb;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, ssize, 8ull * pay_off);
+  const uint32_t lim = sub_grid(rel0, (uint32_t)P1, sb, tid).lim;
+  const uint32_t cnt = nxt - off;
+  // The lane's symbols [off, off + cnt) against the window; positions are handed to the
+  // write loops relative to the window's guard (they wrap below zero in front of it:
+  // the clip test is one unsigned compare).
+  const bool inside = off + cnt < out_size, exact = !inside && off < out_size;
+  const bool touches = cnt > 0 && off < w1 && off + cnt > w0;
+  const uint32_t rel_out = out_size - w0 + kWinGuard;    // the block's end, same origin
+  if (touches || (exact && wi == (int)((out_size - 1u) / kRowWindow))) {
+    uint32_t end_bp = ~0u;
+    const uint32_t op = off - w0 + kWinGuard;
+    if (inside) {
+      if (!lean_write<true>(rd, tb, rel0 + st_rel, lim, op, win, span)) sh.err = 1;
+    } else if (exact) {
+      if (!exact_write<true>(rd, tb, rel0 + st_rel, lim, op, rel_out, win, &end_bp, span)) sh.err = 1;
+      if (end_bp != ~0u) sh.endbit = (unsigned long long)(end_bp - rel0);
+    }
+  }
+  __syncthreads();
+  // The window leaves as 16-byte stores (row blocks and windows are multiples of 16).
+  uint8_t *dst = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block + w0;
+  for (uint32_t k = tid; k < (w1 - w0) / 16u; k += kDecThreads)
+    reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(win + kWinGuard)[k];
+  // accept / reject like UncompressStream (huffman_dec.cpp:361-417): by the workgroup of
+  // the row's last window, whose lanes include the one that completes the block.
+  if (tid == 0 && w1 == out_size) {
+    int bad = sh.err;
+    if (tot < out_size) bad = 1;   // ran out of payload before the block was full
+    const unsigned long long E = sh.endbit;
+    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+    if (bad) atomicMax(&df->status, fmt_err(7, 1));
+  } else if (tid == 0 && sh.err) {
+    atomicMax(&df->status, fmt_err(7, 1));
+  }
+}
+
 // k_dec_zero: the LRES symbol planes (16-byte units) and the two diagnostics arrays,
 // one launch instead of three memsets in front of every decode.
 __global__ __launch_bounds__(256) void k_dec_zero(uint4 *sym, uint32_t n16, uint32_t *a, uint32_t na, uint32_t *b,
@@ -2826,7 +2925,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     // plane.  The clear (1 GiB for a 16384 x 16384 frame) and the predictor inverse go
     // in FRONT of the join: the side stream is still walking the row headers and
     // counting (a serial 1.1 ms walk at that size), this stream has nothing else to do.
-    if (nrows > 0) {
+    static const int use_window = getenv("HIMG_ROW_WINDOW") ? atoi(getenv("HIMG_ROW_WINDOW")) : 1;
+    const bool window = use_window != 0 && (g.row_block % 16) == 0;
+    if (nrows > 0 && !window) {
       prof_begin(prof, "memset", stream);
       (void)hipMemset2DAsync(ws.fres_sym + (size_t)r0 * g.row_block, ws.fres_stride, 0,
                              (size_t)nrows * g.row_block, (size_t)batch, stream);
@@ -2841,7 +2942,18 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     if (nrows > 0) {
       // Rows without a usable fixpoint (several chunks) take the window path of
       // k_dec_huff, which skips the others.
-      HIMG_LAUNCH(k_row_write_g, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, r0);
+      if (window) {
+        const uint32_t lds = (uint32_t)sizeof(LdsTables) + 64u + kRowWindow + 2u * kWinGuard + 16u;
+        const unsigned nwin = (unsigned)(((uint32_t)g.row_block + kRowWindow - 1u) / kRowWindow);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_window),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        prof_begin(prof, "k_row_window", stream);
+        hipLaunchKernelGGL(k_row_window, dim3(nwin, nrows, batch), dim3(kDecThreads), lds, stream, g, ws, d_packed,
+                           in_stride, d_sizes, r0);
+        prof_end(prof, stream);
+      } else {
+        HIMG_LAUNCH(k_row_write_g, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, r0);
+      }
       HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, 1 + r0, 1, 2);
       HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
