@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   __shared__ short ca[2 * kNumSym], cb[2 * kNumSym], nsym[2 * kNumSym];
   __shared__ uint32_t bits[kTreeStride / 4];
   __shared__ int s_num;
+  __shared__ int s_sz[2 * kNumSym];            // subtree size in bits of the serialised tree
 
   const int strm = blockIdx.x + strm0, f = blockIdx.y, lane = threadIdx.x;
   const size_t tab = ((size_t)f * 2 + strm) * kHistStride;
@@ -1170,6 +1171,9 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
       const int c = pc[0] + pc[1];
       ca[next] = (short)pick[0]; cb[next] = (short)pick[1]; nsym[next] = -1;
       cnt[next] = c;
+      // Subtree size in bits of the serialisation (leaf: 1 + 9, branch: 1 + its children):
+      // the children exist already.
+      s_sz[next] = 1 + (pick[0] < num ? 10 : s_sz[pick[0]]) + (pick[1] < num ? 10 : s_sz[pick[1]]);
       // The new node extends the current group iff that group is the last one,
       // untouched, and of the same count.
       if (ib < ie && ie == inext && inext == next && g == c) ie = inext = next + 1;
@@ -1181,19 +1185,23 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
 
   // Codes and the serialised tree (huffman_enc.cpp:148-180) without a serial walk.
   // A node's depth, code (LSB first: taking child_b at depth d sets bit d) and bit
-  // position in the pre-order serialisation follow from its parent's; the size of a
-  // subtree (leaf: 1 + 9 bits, branch: 1 + its children) from its children's.  Both
-  // are propagated level by level, all 64 lanes working on the (at most 521) nodes:
-  // a few rounds per tree level instead of some hundred dependent LDS round trips
-  // per NODE -- this walk was most of the kernel's 0.14 ms.
+  // position in the pre-order serialisation are sums / concatenations along its path
+  // from the root: position = sum over the path of (1 + the left sibling's subtree size
+  // for a right child), code = the path's side bits.  Path sums are what POINTER JUMPING
+  // computes in log2(depth) rounds: every node keeps an ancestor, the length, the side
+  // bits and the position offset of the path segment up to it, and in a round takes over
+  // its ancestor's segment and ancestor -- nine rounds cover any tree of 261 leaves (the
+  // level-by-level propagation this replaces took two barriers per tree level, twice,
+  // and was 70 of the kernel's 112 us).  Subtree sizes (leaf: 1 + 9 bits, branch: 1 + its
+  // children) come from the merge itself, which creates parents after their children.
   __shared__ short s_par[2 * kNumSym];
   __shared__ uint8_t s_side[2 * kNumSym];
-  __shared__ short s_depth[2 * kNumSym];       // -1: not known yet
-  __shared__ int s_sz[2 * kNumSym];            // subtree size in bits, -1: not known yet
-  __shared__ int s_pos[2 * kNumSym];           // bit position of the node in the serialisation
-  __shared__ unsigned long long s_code[2 * kNumSym];
+  __shared__ short s_depth[2 * kNumSym];       // length of the node's segment; at the end: its depth
+  __shared__ int s_pos[2 * kNumSym];           // offset along the segment; at the end: bit position in the serialisation
+  __shared__ unsigned long long s_code[2 * kNumSym];   // side bits of the segment; at the end: the code
+  __shared__ short s_anc[2 * kNumSym];         // the node above the segment (the root: itself)
   __shared__ int s_changed, s_err;
-  for (int v = lane; v < next; v += 64) { s_par[v] = -1; s_depth[v] = -1; s_sz[v] = nsym[v] >= 0 ? 10 : -1; }
+  for (int v = lane; v < next; v += 64) { s_par[v] = -1; if (v < num) s_sz[v] = 10; }
   if (lane == 0) s_err = 0;
   __syncthreads();
   for (int v = num + lane; v < next; v += 64) {   // internal nodes name their children
@@ -1201,40 +1209,53 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
     s_par[cb[v]] = (short)v; s_side[cb[v]] = 1;
   }
   __syncthreads();
-  // Bottom-up: subtree sizes.
-  for (int round = 0; round < 2 * kNumSym; ++round) {
-    if (lane == 0) s_changed = 0;
-    __syncthreads();
-    for (int v = num + lane; v < next; v += 64)
-      if (s_sz[v] < 0) {
-        const int a = s_sz[ca[v]], b = s_sz[cb[v]];
-        if (a >= 0 && b >= 0) { s_sz[v] = 1 + a + b; s_changed = 1; }
-      }
-    __syncthreads();
-    if (!s_changed) break;
-  }
-  // Top-down: depth, code, position.
-  if (lane == 0 && next > 0) {
-    const int root = next - 1;
-    // A single symbol is one leaf with a 1-bit code 0 (huffman_enc.cpp:231-237).
-    s_depth[root] = (short)(num == 1 ? 1 : 0);
-    s_code[root] = 0;
-    s_pos[root] = 0;
+  const int root = next - 1;
+  for (int v = lane; v < next; v += 64) {
+    const int p = s_par[v];
+    if (p < 0) {   // the root (its record is final)
+      // A single symbol is one leaf with a 1-bit code 0 (huffman_enc.cpp:231-237).
+      s_anc[v] = (short)v; s_depth[v] = (short)(num == 1 ? 1 : 0); s_code[v] = 0; s_pos[v] = 0;
+    } else {
+      s_anc[v] = (short)p;
+      s_depth[v] = 1;
+      s_code[v] = s_side[v];
+      s_pos[v] = 1 + (s_side[v] ? s_sz[ca[p]] : 0);
+    }
   }
   __syncthreads();
-  for (int round = 0; round < 2 * kNumSym; ++round) {
-    if (lane == 0) s_changed = 0;
-    __syncthreads();
-    for (int v = lane; v < next; v += 64) {
-      const int p = s_par[v];
-      if (s_depth[v] < 0 && p >= 0 && s_depth[p] >= 0) {
-        const int d = s_depth[p];
-        s_code[v] = s_code[p] | ((s_side[v] && d < 63) ? (1ull << d) : 0ull);
-        s_pos[v] = s_pos[p] + 1 + (s_side[v] ? s_sz[ca[p]] : 0);
-        s_depth[v] = (short)min(d + 1, 255);
-        s_changed = 1;
+  constexpr int kPer = (2 * kNumSym + 63) / 64;   // nodes per lane
+  for (int round = 0; round < 12; ++round) {
+    // Every node whose segment does not start at the root yet takes over its ancestor's
+    // segment: all records are read first, then written, so a round only sees the round
+    // before.
+    short na[kPer], nd[kPer];
+    int np[kPer];
+    unsigned long long nc[kPer];
+    bool moved = false;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int v = lane + 64 * k;
+      na[k] = -1;
+      if (v < next) {
+        const int a = s_anc[v];
+        if (a != root && a != v) {
+          const int la = s_depth[a], lv = s_depth[v];
+          na[k] = s_anc[a];
+          nd[k] = (short)min(la + lv, 255);
+          nc[k] = s_code[a] | (la < 64 ? s_code[v] << la : 0ull);
+          np[k] = s_pos[a] + s_pos[v];
+          moved = true;
+        }
       }
     }
+    if (lane == 0) s_changed = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int v = lane + 64 * k;
+      if (na[k] >= 0) { s_anc[v] = na[k]; s_depth[v] = nd[k]; s_code[v] = nc[k]; s_pos[v] = np[k]; }
+    }
+    if (moved) s_changed = 1;
     __syncthreads();
     if (!s_changed) break;
   }
