@@ -1983,6 +1983,40 @@ __device__ __forceinline__ void lowres_quads(uint32_t lr0, uint32_t lr8, uint32_
   }
 }
 
+// When are 16-bit lanes exact for the two inverse passes?  The reference adds in int32
+// and narrows after each pass's >> 3 (hadamard.cpp:47-74), so all that is needed is
+// that no butterfly sum leaves int16, i.e. sum |d| <= 32767 over every ROW going into
+// the row pass and over every column of its results.  Two sufficient conditions on the
+// dequantised coefficients, checked from running maxima / minima (v_pk_max_i16 /
+// v_pk_min_i16):
+//   (A) |d| <= 3071 everywhere but in register 0 (rows 0 and 1 of column 0: the DC and
+//       its vertical neighbour), where |d| <= 11263:  rows 0, 1: 11263 + 7 x 3071 =
+//       32760; other rows 8 x 3071; after >> 3 at most 4095 / 3071, so a column sums to
+//       at most 2 x 4095 + 6 x 3071 = 26616;
+//   (B) |d| <= 4095 everywhere (8 x 4095 = 32760 in both passes).
+// (B) alone -- the round-2 test -- fails in nine of ten wavefronts of the benchmark
+// frames, whose DC terms reach 8320 (alpha: 10448): a tile whose neighbours differ needs
+// a large DC correction on top of the bilinear low-res plane, and ONE such lane sent its
+// whole wavefront through the scalar int32 path as well.  (A) holds for every tile of
+// those frames, (B) covers full-swing noise with small DC terms; a plane that satisfies
+// neither takes the scalar path, which is exact for anything.
+struct RangeAcc {
+  dpk16 mx, mn;
+  __device__ __forceinline__ void init() { mx = dpk16{-32768, -32768}; mn = dpk16{32767, 32767}; }
+  __device__ __forceinline__ void add(dpk16 d) { mx = __builtin_elementwise_max(mx, d); mn = __builtin_elementwise_min(mn, d); }
+};
+__device__ __forceinline__ bool packed_wht_exact(const RangeAcc &others, dpk16 d0) {
+  const dpk16 zero = {0, 0};
+  const dupk16 am = __builtin_bit_cast(dupk16, (dpk16)__builtin_elementwise_max(others.mx, __builtin_elementwise_sub_sat(zero, others.mn)));
+  const dupk16 a0 = __builtin_bit_cast(dupk16, (dpk16)__builtin_elementwise_max(d0, __builtin_elementwise_sub_sat(zero, d0)));
+  const dupk16 t3071 = {3071, 3071}, t4095 = {4095, 4095}, t11263 = {11263, 11263};
+  const uint32_t oa = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(am, t3071)) |
+                      __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(a0, t11263));
+  const uint32_t ob = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(am, t4095)) |
+                      __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(a0, t4095));
+  return oa == 0u || ob == 0u;
+}
+
 // slot: the tile's first symbol (scan index k is at slot[k * cols]); shift: the
 // 64 per-position shifts; shiftp: the same as 32 packed pairs in V order; lr0 /
 // lr8: (left, right) low-res samples of this and the next block row in bytes 0, 1.
@@ -1995,7 +2029,8 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
   const int cols = COLS ? COLS : cols_rt;
   // Gather + dequantise (quantize.cpp:153-165: int16 wrap == 16-bit shift left).
   dpk16 V[32];
-  uint32_t acc = 0;
+  RangeAcc rng;
+  rng.init();
   if (COLS) {
     // The companding table is the identity for small codes (mapper.cpp:54-61: up to
     // 49 in the encoder's table; the decoder derives the range from the stream's
@@ -2004,7 +2039,7 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
     // loaded as sign-extended bytes straight into the packed halves
     // (ds_read_i8_d16 / _d16_hi: no look-up, no address arithmetic, no v_perm) and
     // tested ONCE per plane and wavefront: every code in [-B, B) with B a power of
-    // two inside the identity range and B << (largest H shift) <= 4096, so the test
+    // two inside the identity range and B << (largest H shift) <= 2048, so the test
     // also stands for the 16-bit range check of these coefficients.  A wavefront
     // with a larger code in H takes the look-ups for H as well.  Group L (rows 0, 1
     // and column 0: the DC and first-order coefficients, large in most tiles)
@@ -2039,18 +2074,14 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
       const int x = e >> 2, j = e & 3;
       const dupk16 d = __builtin_bit_cast(dupk16, W[e]) << __builtin_bit_cast(dupk16, shiftp[e]);
       V[e] = __builtin_bit_cast(dpk16, d);
-      if (x == 0 || j == 0) {
-        const dupk16 bias = {0x1000, 0x1000};
-        acc |= __builtin_bit_cast(uint32_t, (dupk16)(d + bias));
-      }
+      if ((x == 0 || j == 0) && e != 0) rng.add(V[e]);   // (group H: below 2048 by its own test)
     }
     if (__builtin_expect(hslow, 0)) {
 #pragma unroll
       for (int e = 0; e < 32; ++e) {
         const int x = e >> 2, j = e & 3;
         if (x == 0 || j == 0) continue;
-        const dupk16 bias = {0x1000, 0x1000};
-        acc |= __builtin_bit_cast(uint32_t, (dupk16)(__builtin_bit_cast(dupk16, V[e]) + bias));
+        rng.add(V[e]);
       }
     }
   } else {
@@ -2074,12 +2105,11 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
     for (int e = 0; e < 32; ++e) {
       const dupk16 d = __builtin_bit_cast(dupk16, W[e]) << __builtin_bit_cast(dupk16, shiftp[e]);
       V[e] = __builtin_bit_cast(dpk16, d);
-      const dupk16 bias = {0x1000, 0x1000};
-      acc |= __builtin_bit_cast(uint32_t, (dupk16)(d + bias));
+      if (e != 0) rng.add(V[e]);
     }
   }
   dpk16 T[32];   // T[y*4 + i] = columns (2i, 2i+1) of row y after both passes
-  if (__builtin_expect((acc & 0xe000e000u) == 0, 1)) {
+  if (__builtin_expect(packed_wht_exact(rng, V[0]), 1)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       iwht8_pk(V[j], V[4 + j], V[8 + j], V[12 + j], V[16 + j], V[20 + j], V[24 + j], V[28 + j]);
@@ -2381,7 +2411,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     // tile_plane's identity test (one wavefront).  n = the largest code with
     // fmap[i] == i for all i <= n (mapper.h:33-35: a code unmaps to itself there);
     // B = the largest power of two <= n, lowered until B << (largest shift of group H:
-    // rows 2..7 of columns 1..7) <= 4096.  Words: (B, B), then the mask of the bits
+    // rows 2..7 of columns 1..7) <= 2048 (inside both range conditions of the packed
+    // transform, packed_wht_exact).  Words: (B, B), then the mask of the bits
     // that a sum code + B outside [0, 2B) sets.  No usable range: the test always fails.
     const int l = tid - 448;
     const unsigned long long ne = __ballot(df->fmap[l] != l), ne2 = __ballot(df->fmap[64 + l] != 64 + l);
@@ -2393,7 +2424,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       int B = 0;
       if (n >= 1) {
         B = 1 << (31 - __clz(n));
-        while (B && ((long long)B << smax) > 4096) B >>= 1;
+        while (B && ((long long)B << smax) > 2048) B >>= 1;
       }
       const uint32_t b16 = B ? (uint32_t)B : 0x4000u, m16 = B ? (uint32_t)(0xffffu & ~(2u * B - 1u)) : 0xffffu;
       s_shiftp[64 + 2 * l] = b16 | (b16 << 16);

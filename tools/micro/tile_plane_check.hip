@@ -57,9 +57,30 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> codes((size_t)n * 64), shift(64);
   std::vector<int16_t> unmap(256);
   std::vector<uint32_t> lr(2 * n), out((size_t)n * 16);
+  const int mode = argc > 3 ? atoi(argv[3]) : 0;
   for (int k = 0; k < 256; ++k) { int sc = (int8_t)k; unmap[k] = (int16_t)(sc * amp); }
   for (int k = 0; k < 64; ++k) shift[k] = rand() % 5;
   for (auto &c : codes) c = (rand() % 100 < zero_pct) ? 0 : (uint8_t)(rand() & 255);
+  if (mode == 1) {
+    // The edges of packed_wht_exact: every coefficient at the largest magnitude one of
+    // its two conditions allows, or one beyond it -- |d| = 3071 / 3072 / 4095 / 4096
+    // outside register 0 (positions (0,0) and (1,0)), 11263 / 11264 / 4095 / 4096 there --
+    // with all signs equal (the largest butterfly sums), alternating, or random.
+    const int16_t mags[10] = {0, 3071, 3072, 4095, 4096, 11263, 11264, 2047, 16383, 1};
+    for (int k = 0; k < 256; ++k) { const int sc = (int8_t)k; const int m = abs(sc) < 10 ? mags[abs(sc)] : 7; unmap[k] = (int16_t)(sc < 0 ? -m : m); }
+    for (int k = 0; k < 64; ++k) shift[k] = 0;
+    for (int id = 0; id < n; ++id) {
+      const int blk = id / 64, t = id % 64;
+      const int other = 1 + rand() % 4, dc = (rand() % 3 == 0) ? 1 + rand() % 4 : 5 + rand() % 2, signs = rand() % 4;
+      for (int k = 0; k < 64; ++k) {
+        const int pos = kScanD[k];
+        int code = (pos == 0 || pos == 8) ? dc : other;
+        if (rand() % 16 == 0) code = (pos == 0 || pos == 8) ? 8 : 7;   // a few smaller / larger ones
+        const bool neg = signs == 0 ? false : signs == 1 ? true : signs == 2 ? ((pos ^ (pos >> 3)) & 1) : (rand() & 1);
+        codes[((size_t)blk * 64 + k) * 64 + t] = (uint8_t)(neg ? -code : code);
+      }
+    }
+  }
   for (auto &v : lr) v = (uint32_t)(rand() & 0xffff);
   uint8_t *d_codes, *d_shift; int16_t *d_unmap; uint32_t *d_lr, *d_out;
   hipMalloc(&d_codes, codes.size()); hipMalloc(&d_shift, 64); hipMalloc(&d_unmap, 512);
