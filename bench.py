@@ -345,9 +345,10 @@ def rows_leg(args, rank, local_rank, world, dev, steps, warmup):
     enc_v, dec_v = W * H * steps / dt / 1e6, W * H * steps / dt_dec / 1e6
     return {
         "workload": "%dx%d RGBA %s q=%d: ONE frame, block rows sharded over %d rank(s); encode = RCCL all-reduce "
-                    "(261-bin histogram) + all-gather (row bits) + gather (low-res rows, packed rows) to rank 0, "
-                    "stream left in rank 0's HBM; decode = broadcast of the stream, every rank its own block rows, "
-                    "pixels stay sharded" % (W, H, kind, Q, world),
+                    "(261-bin histogram) + all-gather (row bits) + point-to-point sends of the low-res rows and the "
+                    "packed rows to rank 0 (exact sizes, received in place), stream left in rank 0's HBM; decode = "
+                    "rank 0 indexes the rows once, broadcasts the head of the stream (container, LRES, FRES tree) and "
+                    "sends every rank only its own rows' bytes, pixels stay sharded" % (W, H, kind, Q, world),
         "scaling": "strong", "n_gpus": world, "steps": steps,
         "encode_mpx_s": round(enc_v, 2), "decode_mpx_s": round(dec_v, 2),
         "encode_decode_mpx_s": round(W * H * steps / (dt + dt_dec) / 1e6, 2),

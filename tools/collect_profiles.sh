@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/refresh_profiles.sh left under gpurun_out/<dir> into profiles/ under
-# this round's names:  tools/collect_profiles.sh gpurun_out/r02c r02
+# this round's names:  tools/collect_profiles.sh gpurun_out/r03c r03
 set -eu
 SRC=$1
 TAG=$2
