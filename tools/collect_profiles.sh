@@ -8,6 +8,12 @@ grep '^{' "$SRC/bench.json" | tail -1 > "profiles/${TAG}_bench.json"
 cp "$SRC/cfg3_sweep.json" "profiles/${TAG}_cfg3_sweep.json"
 cp "$SRC/cfg4_rows.json" "profiles/${TAG}_cfg4_rows.json"
 cp "$SRC/latency.json" "profiles/${TAG}_latency.json"
+python3 - "$SRC/configs.jsonl" "profiles/${TAG}_configs.json" <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
+out = [{"workload": r["config"]["workload"], "bit_exact": r["config"]["bit_exact"], "value": r["value"], "encode_mpx_s": r["encode_mpx_s"], "decode_mpx_s": r["decode_mpx_s"], "ms_per_step": r["ms_per_step"]} for r in rows]
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+PY
 cp "$SRC"/stats_default/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_default.csv"
 cp "$SRC"/stats_streams1/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_streams1.csv"
 cp "$SRC/pmc/summary.json" "profiles/${TAG}_pmc_summary.json"

@@ -12,6 +12,15 @@ python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err"
 python3 "$ROOT/tools/occupancy_sweep.py" > "$ROOT/$OUT/cfg3_sweep.json" 2> "$ROOT/$OUT/cfg3_sweep.err"
 python3 "$ROOT/tools/rows_profile.py" > "$ROOT/$OUT/cfg4_rows.json" 2> "$ROOT/$OUT/cfg4_rows.err"
 python3 "$ROOT/tools/latency_profile.py" > "$ROOT/$OUT/latency.json" 2> "$ROOT/$OUT/latency.err"
+# Other shapes of the same workload: config 5 (quality sweep), 2048^2 / 1024^2 / 1080p batches.
+: > "$ROOT/$OUT/configs.jsonl"
+for q in 10 30 70 90; do
+  python3 "$ROOT/bench.py" --quality $q --no-rows --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 >> "$ROOT/$OUT/configs.jsonl"
+done
+for wh in "2048 2048" "1024 1024" "1920 1080"; do
+  set -- $wh
+  python3 "$ROOT/bench.py" --width $1 --height $2 --batch 256 --no-rows --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 >> "$ROOT/$OUT/configs.jsonl"
+done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_default" -- \
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
