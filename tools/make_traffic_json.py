@@ -39,6 +39,8 @@ for k, v in d.items():
         clk = 2.4e9
         if v.get("GRBM_GUI_ACTIVE"):
             clk = v["GRBM_GUI_ACTIVE"] / (v["dur_us"] * 1e-6)
+            if clk > 5e9:      # the counter is summed over the 8 XCDs
+                clk /= 8.0
         simd_cycles = v["dur_us"] * 1e-6 * clk * SIMDS
         cost = mix.get(k.split("<")[0].split("[")[0])
         valu[k] = {"wave_insts_per_symbol": round(v["SQ_INSTS_VALU"] / (SYMBOLS_PER_FRAME * frames_per_launch), 4),
