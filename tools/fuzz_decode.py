@@ -21,8 +21,8 @@ eng = himg_amd.Engine(0)
 rng = np.random.default_rng(7)
 bad_cases = 0
 for kind, w, h, q in [("randtile", 4096, 64, 50), ("randtile", 4096, 32, 90), ("gradn", 1024, 256, 70),
-                      ("rand", 512, 128, 50), ("randtile", 200, 116, 70), ("randtile", 4400, 24, 50),
-                      ("rand", 4400, 16, 90)]:
+                      ("rand", 512, 128, 50), ("randtile", 200, 116, 70), ("randtile", 4400, 40, 90),
+                      ("rand", 4400, 16, 90), ("randtile", 8192, 64, 70), ("rand", 16384, 40, 90)]:
     img = himg_amd.synth(kind, 5, w, h)
     good = ol.oracle_encode(img, q, True)
     if ol.oracle_decode(good)[0] != 0:
