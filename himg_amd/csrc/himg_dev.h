@@ -101,7 +101,7 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
 constexpr int kLresMemoWords = 6;
 struct DecWs {
   DecFrame *frames;          // [f]
-  int32_t *nodes;            // [f][2][522*3]  child_a, child_b, symbol
+  uint32_t *nodes;           // [f][2][522]  child a | child b << 10 | (symbol + 1) << 20 (1023: no child; 0: a branch)
   uint2 *grp;                // [f][2][1<<kLutBits] group table (kernels_dec.hip GrpTables)
   uint32_t *gyc;             // [f][2][1<<kLutBits] step words of the count-only groups (no four-byte limit)
   uint2 *sub;                // [f][2][kSubEntries] second-level entries for codes longer than kLutBits (.x byte / node, .y step word)

@@ -453,7 +453,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   const size_t lres = round_up((size_t)g.lres_size + 16, 256);
   const size_t fres = round_up((size_t)g.fres_size + 16, 256);
   if (!ctx->d_frames.reserve(sizeof(DecFrame) * batch) ||
-      !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 3 * 4) ||
+      !ctx->d_nodes.reserve((size_t)batch * 2 * (2 * kNumSym) * 4) ||
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_gyc.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
       !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 8) ||
@@ -464,7 +464,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
       !ctx->d_stats.reserve(((size_t)batch * (g.rows + 1) * 8 + (size_t)batch * 4 + (size_t)batch * g.rows * 8) * 4))
     return fail(ctx, HIMG_ERR_HIP, "decoder workspace allocation failed");
   w.frames = (DecFrame *)ctx->d_frames.p;
-  w.nodes = (int32_t *)ctx->d_nodes.p;
+  w.nodes = (uint32_t *)ctx->d_nodes.p;
   w.grp = (uint2 *)ctx->d_grp.p;
   w.gyc = (uint32_t *)ctx->d_gyc.p;
   w.sub = (uint2 *)ctx->d_sub.p;

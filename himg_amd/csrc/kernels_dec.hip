@@ -63,56 +63,55 @@ __device__ bool find_chunk(const uint8_t *p, uint32_t n, uint32_t *idx, uint32_t
   }
 }
 
-// Pre-order tree recovery (huffman_dec.cpp:152-213), iterative.  Node arrays:
-// nodes[3*i+0] child_a, +1 child_b, +2 symbol (-1 for branches); per node the
-// low bits of its code and its depth are kept in aux[] for the LUT fill.
+// Pre-order tree recovery (huffman_dec.cpp:152-213) by ONE lane, iterative.  The
+// nodes go to LDS in the packed form the tree walks read (child a | child b << 10 |
+// (symbol + 1) << 20, 1023 = no child); per node the low bits of its code and its
+// depth are kept in aux[] for the table fills.
 struct TreeAux { uint32_t code; int32_t depth; };
 
-// The explicit stack lives in LDS: as a per-lane array it would sit in scratch
-// (global) memory and every push/pop would be a dependent global access.
-struct TreeStack {
-  int32_t par[kMaxDepth + 4], depth[kMaxDepth + 4];
-  uint32_t code[kMaxDepth + 4];
-  uint8_t which[kMaxDepth + 4];
-};
-
-__device__ int recover_tree(const uint32_t *w /* LDS words */, uint32_t nbytes, int32_t *nodes,
+// What is carried on the loop's critical path is the bit window and three counters:
+// a branch's first child is the next node, so its attributes stay in registers; only a
+// node that follows a leaf takes its attributes (parent | depth << 10, code) from the
+// stack of pending second children, which lives in LDS (as a per-lane array it would
+// sit in scratch memory).  A second child enters itself in its parent's word with an
+// LDS atomic OR, which nothing waits for.
+__device__ int recover_tree(const uint32_t *w /* LDS words */, uint32_t nbytes, uint32_t *nd /* LDS */,
                             TreeAux *aux, int32_t *num_nodes, uint32_t *tree_bytes,
-                            TreeStack *stk /* LDS */) {
-  // Explicit stack of pending subtrees: (parent, which child, code, depth).
-  int32_t *st_par = stk->par, *st_depth = stk->depth;
-  uint32_t *st_code = stk->code;
-  uint8_t *st_which = stk->which;
-  int sp = 0, count = 0;
-  // 64-bit window over the tree bits (a node costs 1 or 10 bits).
-  unsigned long long win = ((unsigned long long)w[1] << 32) | w[0];
-  int nb = 64;
+                            uint2 *stack /* LDS, kMaxDepth + 4 entries */) {
+  unsigned long long win = ((unsigned long long)w[1] << 32) | w[0];   // a node costs 1 or 10 bits
+  int nb = 64, sp = 0, count = 0;
   uint32_t next = 2, bit = 0;
+  uint32_t ahead = w[2];
   const uint32_t bit_end = 8u * nbytes;
-  st_par[0] = -1; st_which[0] = 0; st_code[0] = 0; st_depth[0] = 0; sp = 1;
-  while (sp > 0) {
-    --sp;
-    const int par = st_par[sp], which = st_which[sp], depth = st_depth[sp];
-    const uint32_t code = st_code[sp];
+  int par = 0, depth = 0;
+  uint32_t code = 0;
+  bool second = false;     // the node is a second child (attributes from the stack)
+  bool pending = true;     // the root, or the first child of the branch just read
+  for (;;) {
+    if (!pending) {
+      if (sp == 0) break;
+      const uint2 e = stack[--sp];
+      par = (int)(e.x & 1023u); depth = (int)(e.x >> 10); code = e.y;
+      second = true;
+    }
     if (count >= kMaxNodes) return kStFormat;
     const int me = count++;
-    if (par >= 0) nodes[3 * par + which] = me;
-    nodes[3 * me + 0] = -1; nodes[3 * me + 1] = -1; nodes[3 * me + 2] = -1;
-    aux[me].code = code; aux[me].depth = depth;
-    if (nb <= 32) { win |= (unsigned long long)w[next++] << nb; nb += 32; }
+    if (nb <= 32) { win |= (unsigned long long)ahead << nb; nb += 32; ahead = w[++next]; }
     if (bit >= bit_end) return kStFormat;  // ReadBitChecked, huffman_dec.cpp:51-60
-    const int leaf = (int)(win & 1ull);
-    if (leaf) {
+    TreeAux a; a.code = code; a.depth = depth;
+    aux[me] = a;
+    if (second) atomicOr(&nd[par], (uint32_t)me << 10);
+    if (win & 1ull) {
       if (bit + 10 > bit_end) return kStFormat;  // ReadBitsChecked, huffman_dec.cpp:94-106
-      nodes[3 * me + 2] = (int)((win >> 1) & 511ull);
+      nd[me] = 0xfffffu | ((((uint32_t)(win >> 1) & 511u) + 1u) << 20);
       win >>= 10; nb -= 10; bit += 10;
+      pending = false;
     } else {
       win >>= 1; nb -= 1; bit += 1;
       if (depth + 1 > kMaxDepth) return kStUnsupported;
-      // child_b is pushed first so that child_a is parsed first (pre-order).
-      st_par[sp] = me; st_which[sp] = 1; st_depth[sp] = depth + 1;
-      st_code[sp] = depth < 32 ? (code | (1u << depth)) : code; ++sp;
-      st_par[sp] = me; st_which[sp] = 0; st_depth[sp] = depth + 1; st_code[sp] = code; ++sp;
+      nd[me] = (uint32_t)(me + 1) & 1023u;   // first child = the next node (pre-order); the second enters itself
+      stack[sp++] = make_uint2((uint32_t)me | ((uint32_t)(depth + 1) << 10), depth < 32 ? (code | (1u << depth)) : code);
+      par = me; ++depth; second = false; pending = true;
     }
   }
   *num_nodes = count;
@@ -120,18 +119,17 @@ __device__ int recover_tree(const uint32_t *w /* LDS words */, uint32_t nbytes, 
   return 0;
 }
 
-// Mapping table of the LMAP / FMAP chunk, from bytes staged in LDS (mapper.cpp:127-157).
-__device__ bool parse_map_lds(const uint8_t *in, uint32_t size, int16_t *t) {
-  if (size < 1) return false;
-  const int n1 = in[0];
-  if (n1 > 127 || (uint32_t)(1 + n1 + 2 * (127 - n1)) != size) return false;
-  const uint8_t *q = in + 1;
-  t[0] = 0;
-  for (int i = 1; i <= 127; ++i) {
-    if (i <= n1) { t[i] = (int16_t)*q++; }
-    else { t[i] = (int16_t)(uint16_t)(q[0] | (q[1] << 8)); q += 2; }
-  }
-  return true;
+// One entry of the LMAP / FMAP mapping table from bytes staged in LDS (mapper.cpp:127-157):
+// entries 1..n1 are one byte each, the others two.
+__device__ __forceinline__ bool map_ok(const uint8_t *in, uint32_t size) {
+  return size >= 1 && in[0] <= 127 && (uint32_t)(1 + in[0] + 2 * (127 - in[0])) == size;
+}
+__device__ __forceinline__ int16_t map_entry(const uint8_t *in, int i) {
+  const int n1 = in[0] <= 127 ? in[0] : 127;
+  if (i == 0) return 0;
+  if (i <= n1) return (int16_t)in[i];
+  const uint8_t *q = in + 1 + n1 + 2 * (i - n1 - 1);
+  return (int16_t)(uint16_t)(q[0] | (q[1] << 8));
 }
 
 // LUT entry: [8:0] symbol | [9] "continue at node" flag | [15:10] code bits |
@@ -166,28 +164,33 @@ __device__ __forceinline__ uint32_t sub_leaf(int sym, uint32_t rest_bits) {
 }
 
 // ---------------------------------------------------------------------------
-// k_dec_parse: one 256-thread workgroup per frame.
+// k_dec_parse: one 1024-thread workgroup per frame.
 //   1. thread 0 walks the chunk headers only (decoder.cpp:144-290): RIFF, FRMT,
 //      LMAP, LRES, QCFG, FMAP, FRES -- a chain of dependent global reads;
 //   2. the workgroup stages the small bodies (mapping tables, QCFG, the two
-//      serialised trees) in LDS;
-//   3. wave 0 recovers the LRES tree while wave 1 recovers the FRES tree (the two
-//      serial bit walks run concurrently); wave 2 parses the tables;
+//      serialised trees) in LDS, all five in one round of loads;
+//   3. one lane of wave 0 recovers the LRES tree while one of wave 1 recovers the FRES
+//      tree (the two serial bit walks run concurrently); waves 2..6 parse the tables;
 //   4. the verdict is the FIRST failure in the reference's order of checks;
-//   5. all four waves build the decode tables.
+//   5. the decode tables of BOTH streams are built side by side, 512 lanes each.
 // ---------------------------------------------------------------------------
-constexpr int kParseThreads = 256;
+constexpr int kParseThreads = 1024;
+constexpr int kParseHalf = kParseThreads / 2;   // lanes per stream in step 5
 __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, const uint8_t *packed,
                                                              size_t in_stride, const uint32_t *sizes) {
   __shared__ TreeAux aux[2][kMaxNodes + 1];
+  __shared__ uint32_t s_nd[2][kMaxNodes + 1];
   __shared__ uint32_t s_lut[2][1 << kLutBits];
   __shared__ uint32_t s_sub[2][kSubEntries];
-  __shared__ uint16_t s_heap[2 << kLutBits], s_symd[kMaxNodes + 1];
+  __shared__ __attribute__((aligned(16))) uint16_t s_heap[2][2 << kLutBits];
+  __shared__ uint16_t s_symd[2][kMaxNodes + 1];
   __shared__ uint32_t s_nslow[2], s_slow_m[2][kMaxSlow], s_slow_off[2][kMaxSlow];
   // Staged chunk bodies: 0 LMAP, 1 LRES tree, 2 QCFG, 3 FMAP, 4 FRES tree.
-  __shared__ uint32_t s_buf[5][(kTreeStride + 16) / 4];
+  constexpr int kBodyBytes = kTreeStride + 16;
+  __shared__ uint32_t s_buf[5][kBodyBytes / 4];
   __shared__ uint32_t s_off[5], s_sz[5];
-  __shared__ TreeStack s_stack[2];
+  __shared__ uint2 s_stack[2][kMaxDepth + 4];
+  __shared__ int32_t s_nn[2];
   // Verdict per check, in the reference's order (0 = passed / not reached).
   enum { cHead = 0, cLmap, cLresFind, cLresTree, cQcfg, cFmapFind, cFmap, cFresFind, cFresTree, cLeaf0, cLeaf1, cCount };
   __shared__ int s_chk[cCount];
@@ -197,11 +200,10 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
   const uint8_t *p = packed + (size_t)f * in_stride;
   const uint32_t n = sizes[f];
   DecFrame *df = ws.frames + f;
-  int32_t *nodes0 = ws.nodes + ((size_t)f * 2 + 0) * (kMaxNodes + 1) * 3;
-  int32_t *nodes1 = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
 
   if (lane < cCount) s_chk[lane] = 0;
   if (lane < 5) { s_off[lane] = 0; s_sz[lane] = 0; }
+  if (lane < 2) s_nn[lane] = 0;
   __syncthreads();
 
   if (lane == 0) {   // ---- 1: chunk headers, in file order
@@ -240,64 +242,53 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
   __syncthreads();
 
   // ---- 2: stage the bodies (a dependent global load costs ~1 us, an LDS read ~50 ns)
-  for (int b = 0; b < 5; ++b) {
-    uint8_t *dst = reinterpret_cast<uint8_t *>(s_buf[b]);
+  for (int k = lane; k < 5 * kBodyBytes; k += kParseThreads) {
+    const int b = k / kBodyBytes, j = k - b * kBodyBytes;
     const uint32_t cnt = s_sz[b] < (uint32_t)kTreeStride ? s_sz[b] : (uint32_t)kTreeStride;
-    for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16; k += kParseThreads)
-      dst[k] = k < cnt ? p[s_off[b] + k] : (uint8_t)0;
+    reinterpret_cast<uint8_t *>(s_buf[b])[j] = (uint32_t)j < cnt ? p[s_off[b] + j] : (uint8_t)0;
   }
   __syncthreads();
 
   // ---- 3: the serial walks, one per wave
-  if (lane == 0 && s_off[1]) {         // LRES tree (decoder.cpp:232, huffman_dec.cpp:152-229)
+  if ((lane == 0 && s_off[1]) || (lane == 64 && s_off[4])) {
+    // LRES tree (decoder.cpp:232) / FRES tree (decoder.cpp:290), huffman_dec.cpp:152-229
+    const int s = lane ? 1 : 0, b = s ? 4 : 1;
     uint32_t tb = 0;
-    const uint32_t sz = s_sz[1];
-    int st = recover_tree(s_buf[1], sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes0, aux[0],
-                          &df->s[0].num_nodes, &tb, &s_stack[0]);
-    if (st == kStFormat) st = fmt_err(4, 1);
+    int32_t nn = 0;
+    const uint32_t sz = s_sz[b];
+    int st = recover_tree(s_buf[b], sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, s_nd[s], aux[s],
+                          &nn, &tb, s_stack[s]);
+    if (st == kStFormat) st = fmt_err(s ? 7 : 4, 1);
     if (!st) {
-      df->s[0].root = 0;
-      df->s[0].payload_off = s_off[1] + tb;
+      df->s[s].num_nodes = nn;
+      s_nn[s] = nn;
+      df->s[s].root = 0;
+      df->s[s].payload_off = s_off[b] + tb;
       // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
-      if (df->s[0].payload_off >= df->s[0].chunk_end) st = fmt_err(4, 1);
+      if (df->s[s].payload_off >= df->s[s].chunk_end) st = fmt_err(s ? 7 : 4, 1);
     }
-    s_chk[cLresTree] = st;
+    s_chk[s ? cFresTree : cLresTree] = st;
     // A tree that is a single leaf decodes without consuming code bits in the
     // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
     // the encoder's 1-bit codes; such streams are rejected.
     // (Fixed mode: read them as the 1-bit codes the encoder writes, huffman_enc.cpp:231-237.)
-    if (!st && df->s[0].num_nodes == 1 && !g.fix_t2) s_chk[cLeaf0] = fmt_err(4, 1);
+    if (!st && nn == 1 && !g.fix_t2) s_chk[s ? cLeaf1 : cLeaf0] = fmt_err(s ? 7 : 4, 1);
   }
-  if (lane == 64 && s_off[4]) {        // FRES tree (decoder.cpp:290)
-    uint32_t tb = 0;
-    const uint32_t sz = s_sz[4];
-    int st = recover_tree(s_buf[4], sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, nodes1, aux[1],
-                          &df->s[1].num_nodes, &tb, &s_stack[1]);
-    if (st == kStFormat) st = fmt_err(7, 1);
-    if (!st) {
-      df->s[1].root = 0;
-      df->s[1].payload_off = s_off[4] + tb;
-      if (df->s[1].payload_off >= df->s[1].chunk_end) st = fmt_err(7, 1);
+  if (lane >= 128 && lane < 384) {       // mapping tables: one entry per lane
+    const int m = (lane - 128) >> 7, i = (lane - 128) & 127, b = m ? 3 : 0;
+    if (s_off[b]) {
+      const uint8_t *in = reinterpret_cast<const uint8_t *>(s_buf[b]);
+      const bool ok = s_sz[b] <= (uint32_t)kTreeStride && map_ok(in, s_sz[b]);
+      if (ok) (m ? df->fmap : df->lmap)[i] = map_entry(in, i);
+      else if (i == 0) s_chk[m ? cFmap : cLmap] = fmt_err(m ? 6 : 3, 0);
     }
-    s_chk[cFresTree] = st;
-    if (!st && df->s[1].num_nodes == 1 && !g.fix_t2) s_chk[cLeaf1] = fmt_err(7, 1);
-  }
-  if (lane == 128) {                   // mapping tables and QCFG
-    if (s_off[0]) {
-      if (s_sz[0] > (uint32_t)kTreeStride ||
-          !parse_map_lds(reinterpret_cast<const uint8_t *>(s_buf[0]), s_sz[0], df->lmap)) s_chk[cLmap] = fmt_err(3, 0);
-    }
+  } else if (lane >= 384 && lane < 416) {   // QCFG, quantize.cpp:190-213
     if (s_off[2]) {
       const uint8_t *q = reinterpret_cast<const uint8_t *>(s_buf[2]);
-      for (int i = 0; i < 32; ++i) {   // quantize.cpp:190-213
-        df->shift[0][2 * i] = q[i] >> 4; df->shift[0][2 * i + 1] = q[i] & 15;
-        const uint8_t x = df->ycbcr ? q[32 + i] : 0;
-        df->shift[1][2 * i] = x >> 4; df->shift[1][2 * i + 1] = x & 15;
-      }
-    }
-    if (s_off[3]) {
-      if (s_sz[3] > (uint32_t)kTreeStride ||
-          !parse_map_lds(reinterpret_cast<const uint8_t *>(s_buf[3]), s_sz[3], df->fmap)) s_chk[cFmap] = fmt_err(6, 0);
+      const int i = lane - 384;
+      df->shift[0][2 * i] = q[i] >> 4; df->shift[0][2 * i + 1] = q[i] & 15;
+      const uint8_t x = df->ycbcr ? q[32 + i] : 0;
+      df->shift[1][2 * i] = x >> 4; df->shift[1][2 * i + 1] = x & 15;
     }
   }
   __syncthreads();
@@ -312,105 +303,106 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
   if (s_status) return;
   const long long c_serial = clock64();
 
+  // ---- 5: both streams side by side
+  const int s = lane / kParseHalf, l = lane - s * kParseHalf;
+  const int nn = s_nn[s];
+  // The packed nodes, for the tree walks of the row kernels (codes longer than both tables).
+  {
+    uint32_t *nodes = ws.nodes + ((size_t)f * 2 + s) * (kMaxNodes + 1);
+    for (int k = l; k < nn; k += kParseHalf) nodes[k] = s_nd[s][k];
+  }
   // First-level LUTs (kLutBits wide, LSB-first codes index them directly) in LDS,
   // then the group tables derived from them.  Every node of depth <= kLutBits is
   // first entered in an implicit heap (index (1 << depth) | code); an entry then
   // finds its leaf with at most kLutBits independent reads instead of every leaf
   // replicating itself (a depth-1 leaf would write half the table on one lane).
-  for (int s = 0; s < 2; ++s) {
-    const int32_t *nodes = s ? nodes1 : nodes0;
-    const int nn = df->s[s].num_nodes;
-    for (int k = lane; k < (2 << kLutBits); k += kParseThreads) s_heap[k] = 0;
-    __syncthreads();
-    for (int k = lane; k < nn; k += kParseThreads) {
-      const int depth = aux[s][k].depth;
-      if (depth > kLutBits) continue;
-      const int sym = nodes[3 * k + 2];
-      // leaf: k + 1; branch (only looked at on the last level): 0x8000 | k
-      s_heap[(1u << depth) | aux[s][k].code] = (uint16_t)(sym >= 0 ? k + 1 : (0x8000 | k));
-      s_symd[k] = (uint16_t)(sym >= 0 ? sym : 0x8000);
-    }
-    __syncthreads();
-    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += kParseThreads) {
-      uint32_t e = 0;
-      // depth 0: a tree that is one leaf (rejected above, kept consistent anyway)
-      uint32_t h = s_heap[1];
-      if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], g.fix_t2 ? 1 : 0) | ((h - 1) << 20);
-      for (int d = 1; d <= kLutBits && !e; ++d) {
-        h = s_heap[(1u << d) | (idx & ((1u << d) - 1u))];
-        if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[h - 1], d) | ((h - 1) << 20);
-        else if (h && d == kLutBits) e = lut_node(h & 0x7fffu, d);
-      }
-      s_lut[s][idx] = e;
-    }
-    __syncthreads();
+  static_assert(sizeof(s_heap) == 16 * kParseThreads, "one 16-byte store per lane");
+  reinterpret_cast<uint4 *>(&s_heap[0][0])[lane] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int k = l; k < nn; k += kParseHalf) {
+    const int depth = aux[s][k].depth;
+    if (depth > kLutBits) continue;
+    const int sym = (int)(s_nd[s][k] >> 20) - 1;
+    // leaf: k + 1; branch (only looked at on the last level): 0x8000 | k
+    s_heap[s][(1u << depth) | aux[s][k].code] = (uint16_t)(sym >= 0 ? k + 1 : (0x8000 | k));
+    s_symd[s][k] = (uint16_t)(sym >= 0 ? sym : 0x8000);
   }
+  __syncthreads();
+  for (uint32_t idx = l; idx < (1u << kLutBits); idx += kParseHalf) {
+    uint32_t e = 0;
+    // depth 0: a tree that is one leaf (rejected above, kept consistent anyway)
+    uint32_t h = s_heap[s][1];
+    if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[s][h - 1], g.fix_t2 ? 1 : 0) | ((h - 1) << 20);
+    for (int d = 1; d <= kLutBits && !e; ++d) {
+      h = s_heap[s][(1u << d) | (idx & ((1u << d) - 1u))];
+      if (h && !(h & 0x8000u)) e = lut_leaf(s_symd[s][h - 1], d) | ((h - 1) << 20);
+      else if (h && d == kLutBits) e = lut_node(h & 0x7fffu, d);
+    }
+    s_lut[s][idx] = e;
+  }
+  if (l == 0) s_nslow[s] = 0;
+  for (int k = l; k < kSubEntries; k += kParseHalf) s_sub[s][k] = 0;
   __syncthreads();
   const long long c_lut = clock64();
   // Second-level tables for codes longer than kLutBits.  Few kLutBits-bit prefixes
   // lead to such codes; each gets a sub-table indexed by the next m bits (m = the
   // deepest leaf below it, at most kSubMaxBits; deeper leaves continue from a
   // branch node).  The flagged first-level entry keeps its slot in bits [8:0].
-  for (int s = 0; s < 2; ++s) {
-    const int32_t *nodes = s ? nodes1 : nodes0;
-    const int nn = df->s[s].num_nodes;
-    if (lane == 0) s_nslow[s] = 0;
-    for (int k = lane; k < kSubEntries; k += kParseThreads) s_sub[s][k] = 0;
-    __syncthreads();
-    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += kParseThreads) {
-      const uint32_t e = s_lut[s][idx];
-      if (e & 512u) {
-        const uint32_t slot = atomicAdd(&s_nslow[s], 1u);
-        s_lut[s][idx] = e | (slot < (uint32_t)kMaxSlow ? slot : 511u);
-        if (slot < (uint32_t)kMaxSlow) s_slow_m[s][slot] = 0;
-      }
+  for (uint32_t idx = l; idx < (1u << kLutBits); idx += kParseHalf) {
+    const uint32_t e = s_lut[s][idx];
+    if (e & 512u) {
+      const uint32_t slot = atomicAdd(&s_nslow[s], 1u);
+      s_lut[s][idx] = e | (slot < (uint32_t)kMaxSlow ? slot : 511u);
+      if (slot < (uint32_t)kMaxSlow) s_slow_m[s][slot] = 0;
     }
-    __syncthreads();
-    for (int k = lane; k < nn; k += kParseThreads) {
-      const int depth = aux[s][k].depth;
-      if (nodes[3 * k + 2] >= 0 && depth > kLutBits) {
-        const uint32_t slot = s_lut[s][aux[s][k].code & ((1u << kLutBits) - 1)] & 511u;
-        if (slot < (uint32_t)kMaxSlow) atomicMax(&s_slow_m[s][slot], (uint32_t)(depth - kLutBits));
-      }
+  }
+  __syncthreads();
+  for (int k = l; k < nn; k += kParseHalf) {
+    const int depth = aux[s][k].depth;
+    if ((s_nd[s][k] >> 20) != 0 && depth > kLutBits) {
+      const uint32_t slot = s_lut[s][aux[s][k].code & ((1u << kLutBits) - 1)] & 511u;
+      if (slot < (uint32_t)kMaxSlow) atomicMax(&s_slow_m[s][slot], (uint32_t)(depth - kLutBits));
     }
-    __syncthreads();
-    if (lane == 0) {
-      const uint32_t n = s_nslow[s] < (uint32_t)kMaxSlow ? s_nslow[s] : (uint32_t)kMaxSlow;
-      uint32_t off = 0;
-      for (uint32_t q = 0; q < n; ++q) {
-        uint32_t m = s_slow_m[s][q] < (uint32_t)kSubMaxBits ? s_slow_m[s][q] : (uint32_t)kSubMaxBits;
-        if (off + (1u << m) > (uint32_t)kSubEntries) m = 0;   // no room: plain tree walk
-        s_slow_m[s][q] = m;
-        s_slow_off[s][q] = off;
-        if (m) off += 1u << m;
-      }
+  }
+  __syncthreads();
+  if (l == 0) {
+    const uint32_t ns = s_nslow[s] < (uint32_t)kMaxSlow ? s_nslow[s] : (uint32_t)kMaxSlow;
+    uint32_t off = 0;
+    for (uint32_t q = 0; q < ns; ++q) {
+      uint32_t m = s_slow_m[s][q] < (uint32_t)kSubMaxBits ? s_slow_m[s][q] : (uint32_t)kSubMaxBits;
+      if (off + (1u << m) > (uint32_t)kSubEntries) m = 0;   // no room: plain tree walk
+      s_slow_m[s][q] = m;
+      s_slow_off[s][q] = off;
+      if (m) off += 1u << m;
     }
-    __syncthreads();
-    for (int k = lane; k < nn; k += kParseThreads) {
-      const int depth = aux[s][k].depth;
-      if (depth <= kLutBits) continue;
-      const uint32_t code = aux[s][k].code;
-      const uint32_t slot = s_lut[s][code & ((1u << kLutBits) - 1)] & 511u;
-      if (slot >= (uint32_t)kMaxSlow) continue;
-      const uint32_t m = s_slow_m[s][slot], off = s_slow_off[s][slot];
-      const uint32_t d = (uint32_t)(depth - kLutBits), rel = code >> kLutBits;
-      const int sym = nodes[3 * k + 2];
-      if (m == 0 || d > m) continue;
-      if (sym >= 0) {
-        // A valid leaf: the token resolved in the decoder's step format.  A symbol the
-        // reference rejects stays a node reference: the walk ends on it and flags it.
-        const uint32_t e = sym <= 260 ? sub_leaf(sym, d) : lut_node(k, depth);
-        for (uint32_t i = 0; i < (1u << (m - d)); ++i) s_sub[s][off + ((i << d) | rel)] = e;
-      } else if (d == m) {
-        s_sub[s][off + rel] = lut_node(k, depth);
-      }
+  }
+  __syncthreads();
+  for (int k = l; k < nn; k += kParseHalf) {
+    const int depth = aux[s][k].depth;
+    if (depth <= kLutBits) continue;
+    const uint32_t code = aux[s][k].code;
+    const uint32_t slot = s_lut[s][code & ((1u << kLutBits) - 1)] & 511u;
+    if (slot >= (uint32_t)kMaxSlow) continue;
+    const uint32_t m = s_slow_m[s][slot], off = s_slow_off[s][slot];
+    const uint32_t d = (uint32_t)(depth - kLutBits), rel = code >> kLutBits;
+    const int sym = (int)(s_nd[s][k] >> 20) - 1;
+    if (m == 0 || d > m) continue;
+    if (sym >= 0) {
+      // A valid leaf: the token resolved in the decoder's step format.  A symbol the
+      // reference rejects stays a node reference: the walk ends on it and flags it.
+      const uint32_t e = sym <= 260 ? sub_leaf(sym, d) : lut_node(k, depth);
+      for (uint32_t i = 0; i < (1u << (m - d)); ++i) s_sub[s][off + ((i << d) | rel)] = e;
+    } else if (d == m) {
+      s_sub[s][off + rel] = lut_node(k, depth);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  {
     // Out in the decoder's entry form: .x the literal byte, .y the step word of the ONE
     // token (code bits = what is left of the code after the kLutBits-bit prefix); a node
     // reference as .x = node | depth << 16, .y = 0 (also "nothing there": 0, 0).
     uint2 *sub = ws.sub + ((size_t)f * 2 + s) * kSubEntries;
-    for (int k = lane; k < kSubEntries; k += kParseThreads) {
+    for (int k = l; k < kSubEntries; k += kParseHalf) {
       const uint32_t e = s_sub[s][k];
       uint2 o;
       if (e & 31u) {
@@ -426,14 +418,14 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
     }
   }
   const long long c_sub = clock64();
-  for (int s = 0; s < 2; ++s) {
+  {
     // Group table of the lean decoder (GrpTables below).  A group is a greedy
     // sequence of tokens whose CODES lie inside the kLutBits known bits:
     // literals / single zeros / the two-zeros symbol for at most 4 output bytes,
     // optionally closed by ONE zero-run token (its zeros need no explicit bytes;
     // its extra bits are read from the stream at decode time).
     uint2 *grp = ws.grp + ((size_t)f * 2 + s) * (1u << kLutBits);
-    for (uint32_t idx = lane; idx < (1u << kLutBits); idx += kParseThreads) {
+    for (uint32_t idx = l; idx < (1u << kLutBits); idx += kParseHalf) {
       uint32_t used = 0, nout = 0, bytes = 0, g_eb = 0, s_tb = 0, s_class = 0, ntok = 0;
       const uint32_t e0 = s_lut[s][idx];
       for (;;) {
@@ -505,13 +497,17 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
 // ---------------------------------------------------------------------------
 // k_dec_rowwalk: index of the FRES block rows (huffman_dec.cpp:232-248).  Every
 // row's size header sits right behind the previous row's payload, so this is a
-// chain of dependent loads (~1.4 us per hop from HBM) that nothing can
-// parallelise; it runs on a side stream, beside k_dec_parse and the LRES kernels.
+// chain of dependent loads (0.45 us per hop for 4096-pixel rows, 0.64 us for
+// 16384-pixel ones) that nothing can parallelise; it runs on a side stream, beside
+// k_dec_parse and the LRES kernels.  (Tried and dropped, profiles/r03_experiments.md:
+// other waves of the workgroup touching the chunk a bounded distance ahead so that the
+// hops hit in L2 -- slower; the headers through the scalar cache -- 9 % faster at
+// 4096 pixels, 38 % slower at 16384.)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint8_t *packed,
                                                     size_t in_stride, const uint32_t *sizes) {
   // The walk needs where the FRES payload starts and ends -- which k_dec_parse knows
-  // only after 100 us of tree recovery.  It finds both by itself (the same chunk
+  // only after its tree recovery.  It finds both by itself (the same chunk
   // look-ups, then only the LENGTH of the serialised tree: a leaf is 1 + 9 bits, a
   // branch 1 bit, pre-order, huffman_dec.cpp:152-229) and so runs beside k_dec_parse
   // instead of behind it.  Whatever is wrong with the headers or the tree is
@@ -547,18 +543,21 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
   if (lane != 0) return;
   uint32_t bit = 0;
   {
-    const uint8_t *t8 = reinterpret_cast<const uint8_t *>(s_tree);
+    // Length of the serialised tree over a 64-bit register window.
+    unsigned long long win = ((unsigned long long)s_tree[1] << 32) | s_tree[0];
+    uint32_t next = 2, ahead = s_tree[2];
     const uint32_t bit_end = 8u * cnt;
-    int open = 1, count = 0;
+    int open = 1, count = 0, nb = 64;
     while (open > 0) {
       if (count >= kMaxNodes || bit >= bit_end) return;   // k_dec_parse rejects this tree
       ++count;
-      if ((t8[bit >> 3] >> (bit & 7u)) & 1u) {
+      if (nb <= 32) { win |= (unsigned long long)ahead << nb; nb += 32; ahead = s_tree[++next]; }
+      if (win & 1ull) {
         if (bit + 10u > bit_end) return;
-        bit += 10u;
+        win >>= 10; nb -= 10; bit += 10u;
         --open;
       } else {
-        bit += 1u;
+        win >>= 1; nb -= 1; bit += 1u;
         ++open;
       }
     }
@@ -673,9 +672,6 @@ __device__ __forceinline__ GrpTables tables_of(const LdsTables *T) {
   GrpTables t;
   t.grp = T->grp; t.gx = nullptr; t.gy = nullptr; t.nd = T->nd;
   return t;
-}
-__device__ __forceinline__ uint32_t pack_node(int a, int b, int sym) {
-  return ((uint32_t)a & 1023u) | (((uint32_t)b & 1023u) << 10) | ((uint32_t)(sym + 1) << 20);
 }
 
 // LDS byte address of a pointer into LDS, and loads through such an address (the
@@ -1423,10 +1419,9 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
 // Tree nodes and decode tables of stream `strm` of frame f -> LDS.
 __device__ __forceinline__ void load_dec_tables(const DecWs &ws, const DecFrame *df, int f, int strm,
                                                 LdsTables *T) {
-  const int32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1) * 3;
+  const uint32_t *nodes = ws.nodes + ((size_t)f * 2 + strm) * (kMaxNodes + 1);
   const int nn = min(df->s[strm].num_nodes, kMaxNodes + 1);   // (a frame that failed to parse holds anything)
-  for (int k = threadIdx.x; k < nn; k += kDecThreads)
-    T->nd[k] = pack_node(nodes[3 * k + 0], nodes[3 * k + 1], nodes[3 * k + 2]);
+  for (int k = threadIdx.x; k < nn; k += kDecThreads) T->nd[k] = nodes[k];
   const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + strm) * (1u << kLutBits));
   for (int k = threadIdx.x; k < (1 << kLutBits) / 2; k += kDecThreads)
     reinterpret_cast<uint4 *>(T->grp)[k] = gg[k];
@@ -2393,11 +2388,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   const uint4 t_grp = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits))[tid];
   uint4 t_sub = make_uint4(0, 0, 0, 0);
   if (tid < kSubEntries / 2) t_sub = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries)[tid];
-  int t_n0 = 0, t_n1 = 0, t_n2 = 0;
-  if (tid < kMaxNodes + 1) {
-    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
-    t_n0 = nodes[3 * tid]; t_n1 = nodes[3 * tid + 1]; t_n2 = nodes[3 * tid + 2];
-  }
+  uint32_t t_nd = 0;
+  if (tid < kMaxNodes + 1) t_nd = (ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1))[tid];
   if (tid < 256) {
     const int sc = (int8_t)tid;
     s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
@@ -2442,7 +2434,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   }
   reinterpret_cast<uint4 *>(T.grp)[tid] = t_grp;
   if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(T.grp + (1 << kLutBits))[tid] = t_sub;
-  if (tid < kMaxNodes + 1) T.nd[tid] = pack_node(t_n0, t_n1, t_n2);
+  if (tid < kMaxNodes + 1) T.nd[tid] = t_nd;
   __syncthreads();
   if constexpr (COLS == 512) {
     if (sh->flag) return;   // (uniform: one read, in front of the barrier above)
@@ -2611,10 +2603,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
   __syncthreads();
   const int failed = sh.flag;
   if (!failed) {   // load_dec_tables with the count-only step words next to the long-code descriptors
-    const int32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1) * 3;
+    const uint32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1);
     const int nn = df->s[1].num_nodes;
-    for (int k = tid; k < nn; k += kDecThreads)
-      nd[k] = pack_node(nodes[3 * k + 0], nodes[3 * k + 1], nodes[3 * k + 2]);
+    for (int k = tid; k < nn; k += kDecThreads) nd[k] = nodes[k];
     const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
     const uint2 *gc = reinterpret_cast<const uint2 *>(ws.gyc + ((size_t)f * 2 + 1) * (1u << kLutBits));
     for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
@@ -2852,7 +2843,10 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // LRES stream and walks all row headers, then its own FRES rows).
   const int nrows = r1 - r0;
   static const int rpc_env = [] { const char *e = getenv("HIMG_ROWS_PER_COUNT"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? v : 0; }();
-  const int rpc = rpc_env ? rpc_env : kRowsPerCount;   // rows per k_row_count workgroup (tuning knob)
+  // Rows per k_row_count workgroup (tuning knob): a workgroup loads the decode tables once
+  // for its rows; a single frame has too few rows to fill the CUs that way.
+  const long long all_rows = (long long)batch * nrows;
+  const int rpc = rpc_env ? rpc_env : all_rows <= 512 ? 1 : all_rows <= 1024 ? 2 : kRowsPerCount;
   const unsigned gx = (unsigned)((((g.cols + 31) / 32) * 64 + 255) / 256);   // k_tile_inv: two lanes per tile, 32 tiles per wave
   // Fused row kernel when the row's symbols and the decode tables fit the 160 KiB
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
