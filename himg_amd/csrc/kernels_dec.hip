@@ -63,61 +63,37 @@ __device__ bool find_chunk(const uint8_t *p, uint32_t n, uint32_t *idx, uint32_t
   }
 }
 
-// Pre-order tree recovery (huffman_dec.cpp:152-213) by ONE lane, iterative.  The
-// nodes go to LDS in the packed form the tree walks read (child a | child b << 10 |
-// (symbol + 1) << 20, 1023 = no child); per node the low bits of its code and its
-// depth are kept in aux[] for the table fills.
+// Pre-order tree recovery (huffman_dec.cpp:152-213), in parallel.  The reference reads
+// the serialised tree node by node (a branch is one 0 bit, a leaf a 1 bit and nine symbol
+// bits); as a single-lane loop that is 250 instructions of divergent control per node
+// and 120 us per frame.  Here:
+//   A  where the nodes start.  One lane per 32-bit word runs the walk over its word
+//      from each of the ten possible entry states (0..9 = bits of a leaf left over from
+//      the previous word): exit state and node count per entry state.  One lane chains
+//      the (at most 96) words; the word lanes then write their nodes' start bits.
+//   B  the tree.  open[k] = stack depth of the reference's walk after node k (a prefix
+//      sum of +1 / -1); the tree ends at the first node where it is 0.  A node that
+//      follows a branch is its first child; one that follows a leaf is the second child
+//      of the nearest earlier branch j with open[j] == open[k - 1] + 1 (the branch whose
+//      pending child sat on top of the stack).  Depth and code (LSB = first choice)
+//      follow from the parent links by pointer jumping.
+// Per node the low bits of its code and its depth are kept in aux[] for the table
+// fills; the nodes go to LDS in the packed form the tree walks read (child a |
+// child b << 10 | (symbol + 1) << 20, 1023 = no child).
 struct TreeAux { uint32_t code; int32_t depth; };
 
-// What is carried on the loop's critical path is the bit window and three counters:
-// a branch's first child is the next node, so its attributes stay in registers; only a
-// node that follows a leaf takes its attributes (parent | depth << 10, code) from the
-// stack of pending second children, which lives in LDS (as a per-lane array it would
-// sit in scratch memory).  A second child enters itself in its parent's word with an
-// LDS atomic OR, which nothing waits for.
-__device__ int recover_tree(const uint32_t *w /* LDS words */, uint32_t nbytes, uint32_t *nd /* LDS */,
-                            TreeAux *aux, int32_t *num_nodes, uint32_t *tree_bytes,
-                            uint2 *stack /* LDS, kMaxDepth + 4 entries */) {
-  unsigned long long win = ((unsigned long long)w[1] << 32) | w[0];   // a node costs 1 or 10 bits
-  int nb = 64, sp = 0, count = 0;
-  uint32_t next = 2, bit = 0;
-  uint32_t ahead = w[2];
-  const uint32_t bit_end = 8u * nbytes;
-  int par = 0, depth = 0;
-  uint32_t code = 0;
-  bool second = false;     // the node is a second child (attributes from the stack)
-  bool pending = true;     // the root, or the first child of the branch just read
-  for (;;) {
-    if (!pending) {
-      if (sp == 0) break;
-      const uint2 e = stack[--sp];
-      par = (int)(e.x & 1023u); depth = (int)(e.x >> 10); code = e.y;
-      second = true;
-    }
-    if (count >= kMaxNodes) return kStFormat;
-    const int me = count++;
-    if (nb <= 32) { win |= (unsigned long long)ahead << nb; nb += 32; ahead = w[++next]; }
-    if (bit >= bit_end) return kStFormat;  // ReadBitChecked, huffman_dec.cpp:51-60
-    TreeAux a; a.code = code; a.depth = depth;
-    aux[me] = a;
-    if (second) atomicOr(&nd[par], (uint32_t)me << 10);
-    if (win & 1ull) {
-      if (bit + 10 > bit_end) return kStFormat;  // ReadBitsChecked, huffman_dec.cpp:94-106
-      nd[me] = 0xfffffu | ((((uint32_t)(win >> 1) & 511u) + 1u) << 20);
-      win >>= 10; nb -= 10; bit += 10;
-      pending = false;
-    } else {
-      win >>= 1; nb -= 1; bit += 1;
-      if (depth + 1 > kMaxDepth) return kStUnsupported;
-      nd[me] = (uint32_t)(me + 1) & 1023u;   // first child = the next node (pre-order); the second enters itself
-      stack[sp++] = make_uint2((uint32_t)me | ((uint32_t)(depth + 1) << 10), depth < 32 ? (code | (1u << depth)) : code);
-      par = me; ++depth; second = false; pending = true;
-    }
-  }
-  *num_nodes = count;
-  *tree_bytes = (bit + 7) >> 3;  // AlignToByte, huffman_dec.cpp:229
-  return 0;
-}
+constexpr int kTreeWords = kTreeStride / 4;       // words of a staged serialised tree
+constexpr int kNodeCap = kMaxNodes + 1;           // node slots (a tree of more nodes is rejected)
+struct TreeScratch {                              // phases A / B of one tree
+  unsigned long long outs[kTreeWords], cnts[kTreeWords];   // 4 / 6 bits per entry state
+  uint32_t went[kTreeWords];                      // entry state | first node << 4
+  uint16_t pos[kNodeCap + 6];                     // start bit | leaf << 15
+  int16_t open[2][kNodeCap + 6];                  // prefix sums (two buffers)
+  __attribute__((aligned(16))) int16_t key[kNodeCap + 14];   // open[] of branches, 0 for leaves
+  uint16_t anc[kNodeCap + 6];
+  uint16_t second[kNodeCap + 6];                  // second child of a branch
+  int32_t total, first_bad, kend, kdeep;
+};
 
 // One entry of the LMAP / FMAP mapping table from bytes staged in LDS (mapper.cpp:127-157):
 // entries 1..n1 are one byte each, the others two.
@@ -169,8 +145,8 @@ __device__ __forceinline__ uint32_t sub_leaf(int sym, uint32_t rest_bits) {
 //      LMAP, LRES, QCFG, FMAP, FRES -- a chain of dependent global reads;
 //   2. the workgroup stages the small bodies (mapping tables, QCFG, the two
 //      serialised trees) in LDS, all five in one round of loads;
-//   3. one lane of wave 0 recovers the LRES tree while one of wave 1 recovers the FRES
-//      tree (the two serial bit walks run concurrently); waves 2..6 parse the tables;
+//   3. the two trees are recovered side by side (512 lanes each, see "Pre-order tree
+//      recovery" above); lanes 128..415 parse the tables;
 //   4. the verdict is the FIRST failure in the reference's order of checks;
 //   5. the decode tables of BOTH streams are built side by side, 512 lanes each.
 // ---------------------------------------------------------------------------
@@ -180,7 +156,7 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
                                                              size_t in_stride, const uint32_t *sizes) {
   __shared__ TreeAux aux[2][kMaxNodes + 1];
   __shared__ uint32_t s_nd[2][kMaxNodes + 1];
-  __shared__ uint32_t s_lut[2][1 << kLutBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut[2][1 << kLutBits];
   __shared__ uint32_t s_sub[2][kSubEntries];
   __shared__ __attribute__((aligned(16))) uint16_t s_heap[2][2 << kLutBits];
   __shared__ uint16_t s_symd[2][kMaxNodes + 1];
@@ -189,8 +165,9 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
   constexpr int kBodyBytes = kTreeStride + 16;
   __shared__ uint32_t s_buf[5][kBodyBytes / 4];
   __shared__ uint32_t s_off[5], s_sz[5];
-  __shared__ uint2 s_stack[2][kMaxDepth + 4];
   __shared__ int32_t s_nn[2];
+  static_assert(sizeof(TreeScratch) <= sizeof(s_heap) && sizeof(TreeScratch) <= sizeof(s_lut),
+                "the trees' scratch lives in the memory of the heap and the LUTs (unused until step 5)");
   // Verdict per check, in the reference's order (0 = passed / not reached).
   enum { cHead = 0, cLmap, cLresFind, cLresTree, cQcfg, cFmapFind, cFmap, cFresFind, cFresTree, cLeaf0, cLeaf1, cCount };
   __shared__ int s_chk[cCount];
@@ -249,30 +226,179 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
   }
   __syncthreads();
 
-  // ---- 3: the serial walks, one per wave
-  if ((lane == 0 && s_off[1]) || (lane == 64 && s_off[4])) {
-    // LRES tree (decoder.cpp:232) / FRES tree (decoder.cpp:290), huffman_dec.cpp:152-229
-    const int s = lane ? 1 : 0, b = s ? 4 : 1;
-    uint32_t tb = 0;
-    int32_t nn = 0;
-    const uint32_t sz = s_sz[b];
-    int st = recover_tree(s_buf[b], sz < (uint32_t)kTreeStride ? sz : (uint32_t)kTreeStride, s_nd[s], aux[s],
-                          &nn, &tb, s_stack[s]);
-    if (st == kStFormat) st = fmt_err(s ? 7 : 4, 1);
-    if (!st) {
-      df->s[s].num_nodes = nn;
-      s_nn[s] = nn;
-      df->s[s].root = 0;
-      df->s[s].payload_off = s_off[b] + tb;
-      // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
-      if (df->s[s].payload_off >= df->s[s].chunk_end) st = fmt_err(s ? 7 : 4, 1);
+  // ---- 3: the two trees side by side, 512 lanes each: LRES (decoder.cpp:232) and FRES
+  // (decoder.cpp:290), huffman_dec.cpp:152-229
+  {
+    const int s = lane / kParseHalf, l = lane - s * kParseHalf, b = s ? 4 : 1;
+    TreeScratch *ts = s ? reinterpret_cast<TreeScratch *>(&s_lut[0][0]) : reinterpret_cast<TreeScratch *>(&s_heap[0][0]);
+    const uint32_t *w = s_buf[b];
+    const bool present = s_off[b] != 0;
+    const uint32_t nbytes = !present ? 0u : s_sz[b] < (uint32_t)kTreeStride ? s_sz[b] : (uint32_t)kTreeStride;
+    const uint32_t bit_end = 8u * nbytes;
+    const int nw = (int)((bit_end + 31u) >> 5);
+    // A1: the walk over one word from every entry state
+    if (l < nw) {
+      const uint32_t x = w[l];
+      unsigned long long outs = 0, cnts = 0;
+      for (uint32_t e = 0; e < 10; ++e) {
+        uint32_t pos = e, c = 0;
+        while (pos < 32u) { ++c; pos += ((x >> pos) & 1u) ? 10u : 1u; }
+        outs |= (unsigned long long)(pos - 32u) << (4u * e);
+        cnts |= (unsigned long long)c << (6u * e);
+      }
+      ts->outs[l] = outs; ts->cnts[l] = cnts;
     }
-    s_chk[s ? cFresTree : cLresTree] = st;
-    // A tree that is a single leaf decodes without consuming code bits in the
-    // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
-    // the encoder's 1-bit codes; such streams are rejected.
-    // (Fixed mode: read them as the 1-bit codes the encoder writes, huffman_enc.cpp:231-237.)
-    if (!st && nn == 1 && !g.fix_t2) s_chk[s ? cLeaf1 : cLeaf0] = fmt_err(s ? 7 : 4, 1);
+    if (l == 0) { ts->first_bad = kNodeCap; ts->kend = kNodeCap; ts->kdeep = kNodeCap; }
+    for (int k = l; k < kNodeCap + 6; k += kParseHalf) { ts->second[k] = 0; ts->key[k] = 0; }
+    __syncthreads();
+    // A2: chain the words
+    if (l == 0) {
+      uint32_t state = 0, base = 0;
+      for (int k = 0; k < nw; ++k) {
+        ts->went[k] = state | (base << 4);
+        base += (uint32_t)(ts->cnts[k] >> (6u * state)) & 63u;
+        state = (uint32_t)(ts->outs[k] >> (4u * state)) & 15u;
+      }
+      ts->total = (int32_t)(base < (uint32_t)kNodeCap ? base : (uint32_t)kNodeCap);
+    }
+    __syncthreads();
+    // A3: the nodes' start bits
+    if (l < nw) {
+      const uint32_t x = w[l], e = ts->went[l] & 15u;
+      uint32_t k = ts->went[l] >> 4, pos = e;
+      while (pos < 32u && k < (uint32_t)kNodeCap) {
+        const uint32_t leaf = (x >> pos) & 1u;
+        ts->pos[k++] = (uint16_t)((32u * (uint32_t)l + pos) | (leaf << 15));
+        pos += leaf ? 10u : 1u;
+      }
+    }
+    __syncthreads();
+    // B1: open[] and where the tree ends
+    const int total = ts->total;
+    for (int k = l; k < kNodeCap; k += kParseHalf) {
+      int16_t d = 0;
+      if (k < total) {
+        const uint32_t pp = ts->pos[k], leaf = pp >> 15, bp = pp & 0x7fffu;
+        d = leaf ? (int16_t)-1 : (int16_t)1;
+        // ReadBitChecked / ReadBitsChecked, huffman_dec.cpp:51-60, 94-106
+        if (bp >= bit_end || (leaf && bp + 10u > bit_end)) atomicMin(&ts->first_bad, k);
+      }
+      ts->open[0][k] = d;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int d = 1; d < kNodeCap; d <<= 1) {
+      for (int k = l; k < kNodeCap; k += kParseHalf)
+        ts->open[cur ^ 1][k] = (int16_t)(ts->open[cur][k] + (k >= d ? ts->open[cur][k - d] : 0));
+      cur ^= 1;
+      __syncthreads();
+    }
+    const int16_t *open = ts->open[cur];   // (stack depth after node k) - 1
+    for (int k = l; k < total; k += kParseHalf) {
+      if (open[k] == -1) atomicMin(&ts->kend, k);
+      if (!(ts->pos[k] >> 15)) ts->key[k] = (int16_t)(open[k] + 1);   // >= 2 for a branch
+    }
+    __syncthreads();
+    // The first node the reference's walk fails on (count >= kMaxNodes, or the bits run
+    // out: huffman_dec.cpp:51-60), if any.
+    const int kend = ts->kend, first_bad = ts->first_bad;
+    const bool whole = kend < kMaxNodes && first_bad > kend;
+    const int ka = whole ? kNodeCap : min(min(first_bad, total), kMaxNodes);
+    const int nlim = whole ? kend + 1 : ka;   // nodes the walk has read
+    // B2: parents
+    for (int k = l; k < nlim; k += kParseHalf) {
+      int par = 0, which = 0;
+      if (k > 0) {
+        if (!(ts->pos[k - 1] >> 15)) {
+          par = k - 1;
+        } else {
+          which = 1;
+          const uint32_t t = (uint32_t)(uint16_t)(open[k - 1] + 2), tt = t | (t << 16);
+          const int j0 = k - 2;
+          int found = -1;
+          for (int c = j0 >> 3; c >= 0 && found < 0; --c) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&ts->key[8 * c]);
+            const uint32_t xs[4] = {q.x ^ tt, q.y ^ tt, q.z ^ tt, q.w ^ tt};
+            uint32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) any |= (xs[i] - 0x00010001u) & ~xs[i] & 0x80008000u;
+            if (!any) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int idx = 8 * c + i;
+              if (idx <= j0 && ((xs[i >> 1] >> (16 * (i & 1))) & 0xffffu) == 0u) found = idx;
+            }
+          }
+          par = found < 0 ? 0 : found;
+          ts->second[par] = (uint16_t)k;
+        }
+      }
+      ts->anc[k] = (uint16_t)par;
+      TreeAux a; a.code = (uint32_t)which; a.depth = k > 0 ? 1 : 0;
+      aux[s][k] = a;
+    }
+    __syncthreads();
+    // B3: depth and code by pointer jumping (a depth beyond 63 stays at >= 32: rejected below)
+    for (int r = 0; r < 6; ++r) {
+      static_assert(kNodeCap <= 2 * kParseHalf, "two nodes per lane");
+      const int k0 = l, k1 = l + kParseHalf;
+      TreeAux n0, n1;
+      uint16_t a0 = 0, a1 = 0;
+      n0.code = n1.code = 0; n0.depth = n1.depth = 0;
+      if (k0 < nlim) {
+        const int a = ts->anc[k0];
+        const TreeAux me = aux[s][k0], up = aux[s][a];
+        n0.code = up.code | (up.depth < 32 ? me.code << up.depth : 0u);
+        n0.depth = min(me.depth + up.depth, 255);
+        a0 = ts->anc[a];
+      }
+      if (k1 < nlim) {
+        const int a = ts->anc[k1];
+        const TreeAux me = aux[s][k1], up = aux[s][a];
+        n1.code = up.code | (up.depth < 32 ? me.code << up.depth : 0u);
+        n1.depth = min(me.depth + up.depth, 255);
+        a1 = ts->anc[a];
+      }
+      __syncthreads();
+      if (k0 < nlim) { aux[s][k0] = n0; ts->anc[k0] = a0; }
+      if (k1 < nlim) { aux[s][k1] = n1; ts->anc[k1] = a1; }
+      __syncthreads();
+    }
+    // B4: a branch deeper than the decoder walks; the packed nodes
+    for (int k = l; k < nlim; k += kParseHalf) {
+      const uint32_t pp = ts->pos[k], leaf = pp >> 15;
+      if (!leaf) {
+        if (aux[s][k].depth + 1 > kMaxDepth) atomicMin(&ts->kdeep, k);
+        s_nd[s][k] = ((uint32_t)(k + 1) & 1023u) | ((uint32_t)ts->second[k] << 10);
+      } else {
+        const uint32_t bp = (pp & 0x7fffu) + 1u, wi = bp >> 5;
+        const uint32_t sym = (uint32_t)((((unsigned long long)w[wi + 1] << 32) | w[wi]) >> (bp & 31u)) & 511u;
+        s_nd[s][k] = 0xfffffu | ((sym + 1u) << 20);
+      }
+    }
+    __syncthreads();
+    if (l == 0 && present) {
+      // The first failure in the order of the reference's walk.
+      int st = 0;
+      if (ts->kdeep < ka) st = kStUnsupported;
+      else if (!whole) st = fmt_err(s ? 7 : 4, 1);
+      if (!st) {
+        const int nn = kend + 1;
+        const uint32_t tb = ((ts->pos[kend] & 0x7fffu) + 10u + 7u) >> 3;   // AlignToByte, huffman_dec.cpp:229
+        df->s[s].num_nodes = nn;
+        s_nn[s] = nn;
+        df->s[s].root = 0;
+        df->s[s].payload_off = s_off[b] + tb;
+        // UncompressStream's first test (huffman_dec.cpp:277-278): nothing left after the tree.
+        if (df->s[s].payload_off >= df->s[s].chunk_end) st = fmt_err(s ? 7 : 4, 1);
+        // A tree that is a single leaf decodes without consuming code bits in the
+        // reference (huffman_dec.cpp:173-185 with bits == 0) and cannot round-trip
+        // the encoder's 1-bit codes; such streams are rejected.
+        // (Fixed mode: read them as the 1-bit codes the encoder writes, huffman_enc.cpp:231-237.)
+        if (!st && nn == 1 && !g.fix_t2) s_chk[s ? cLeaf1 : cLeaf0] = fmt_err(s ? 7 : 4, 1);
+      }
+      s_chk[s ? cFresTree : cLresTree] = st;
+    }
   }
   if (lane >= 128 && lane < 384) {       // mapping tables: one entry per lane
     const int m = (lane - 128) >> 7, i = (lane - 128) & 127, b = m ? 3 : 0;

@@ -317,6 +317,35 @@ def test_bit_flips_in_the_payload_decode_like_the_reference(engine, unfused_engi
     assert accepted > 10 and rejected > 10   # the mutations exercise both outcomes
 
 
+def test_damaged_trees_decode_like_the_reference(engine):
+    """The serialised Huffman trees of the LRES and FRES chunks (k_dec_parse recovers
+    them in parallel: node starts per 32-bit word, then the tree from prefix sums and
+    pointer jumping) with one to three flipped bits: a leaf turned into a branch shifts
+    every later node, trees end early or run into the payload, symbols change.  The
+    reference either rejects such a stream or decodes other pixels (huffman_dec.cpp:152-229);
+    the GPU decoder must agree, bit for bit."""
+    img = himg_amd.synth("rand", 11, 512, 128)
+    good = ol.oracle_encode(img, 50, True)
+    assert ol.oracle_decode(good)[0] == 0
+    ch = _chunks(good)
+    rng = np.random.default_rng(5)
+    accepted = rejected = 0
+    for t in range(400):
+        bad = good.copy()
+        off, sz = ch["FRES" if t % 2 else "LRES"]
+        for _ in range(1 + t % 3):
+            bad[off + int(rng.integers(0, min(sz, 340)))] ^= 1 << int(rng.integers(0, 8))
+        rc, pix = ol.oracle_decode(bad)
+        if rc == 0:
+            _eq(engine.decode(bad).ravel(), pix.ravel(), "pixels of mutation %d" % t)
+        else:
+            with pytest.raises(himg_amd.HimgError):
+                engine.decode(bad)
+        accepted += rc == 0
+        rejected += rc != 0
+    assert accepted > 10 and rejected > 10
+
+
 def test_fixed_mode_decodes_what_the_reference_cannot(engine):
     """HIMG_OPT_FIX_T2 (opt-in): streams of the reference's own encoder that its
     decoder rejects -- compressible frames (trap T2), frames of one block row,
