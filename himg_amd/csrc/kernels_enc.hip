@@ -1079,20 +1079,25 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
 }
 
 // ---------------------------------------------------------------------------
-// k_tree: one wavefront per (stream, frame).  Builds the Huffman tree with the
+// k_tree: one workgroup (nine wavefronts) per (stream, frame).  Builds the Huffman tree with the
 // reference's tie-breaking (trap T5): repeatedly join the two lightest nodes
 // under the total order (count ascending, node index DESCENDING); the lighter
 // becomes child_a (bit 0).  Then a pre-order walk serialises the tree and
 // assigns LSB-first codes (huffman_enc.cpp:148-180).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
+constexpr int kTreeThreads = 576;   // nine waves: one lane per node of the largest tree (2 * 261 - 1)
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }   // a wave-uniform value, in an SGPR
+
+__global__ __launch_bounds__(kTreeThreads) void k_tree(EncWs ws, int strm0) {
   __shared__ int cnt[2 * kNumSym];
-  __shared__ int s_cnt[kNumSym];          // leaves sorted by (count, -index)
-  __shared__ short s_idx[kNumSym];
+  __shared__ int s_cnt[kNumSym + 2];      // leaves sorted by (count, -index)
+  __shared__ short s_idx[kNumSym + 2];
   __shared__ short ca[2 * kNumSym], cb[2 * kNumSym], nsym[2 * kNumSym];
+  __shared__ short s_end[2 * kNumSym];    // for the first node of a run of equal counts: the node after the run
   __shared__ uint32_t bits[kTreeStride / 4];
   __shared__ int s_num;
   __shared__ int s_sz[2 * kNumSym];            // subtree size in bits of the serialised tree
+  static_assert(kTreeThreads >= 2 * kNumSym, "one lane per node");
 
   const int strm = blockIdx.x + strm0, f = blockIdx.y, lane = threadIdx.x;
   const size_t tab = ((size_t)f * 2 + strm) * kHistStride;
@@ -1100,26 +1105,30 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   uint64_t *codes = ws.codes + tab;
   uint32_t *lens = ws.lens + tab;
 
-  for (int k = lane; k < kTreeStride / 4; k += 64) bits[k] = 0;
-  for (int k = lane; k < kHistStride; k += 64) { codes[k] = 0; lens[k] = 0; }
-  // Leaves in ascending symbol order (huffman_enc.cpp:186-196).
-  int num = 0;
-  for (int base = 0; base < kNumSym; base += 64) {
-    const int k = base + lane;
-    const uint32_t c = k < kNumSym ? hist[k] : 0;
-    const unsigned long long mask = __ballot(c > 0);
-    if (c > 0) {
-      const int idx = num + __popcll(mask & ((1ull << lane) - 1ull));
-      cnt[idx] = (int)c; ca[idx] = -1; cb[idx] = -1; nsym[idx] = (short)k;
+  for (int k = lane; k < kTreeStride / 4; k += kTreeThreads) bits[k] = 0;
+  for (int k = lane; k < kHistStride; k += kTreeThreads) { codes[k] = 0; lens[k] = 0; }
+  // Leaves in ascending symbol order (huffman_enc.cpp:186-196): wave 0 compacts them.
+  if (lane < 64) {
+    int n = 0;
+    for (int base = 0; base < kNumSym; base += 64) {
+      const int k = base + lane;
+      const uint32_t c = k < kNumSym ? hist[k] : 0;
+      const unsigned long long mask = __ballot(c > 0);
+      if (c > 0) {
+        const int idx = n + __popcll(mask & ((1ull << lane) - 1ull));
+        cnt[idx] = (int)c; ca[idx] = -1; cb[idx] = -1; nsym[idx] = (short)k; s_sz[idx] = 10;
+      }
+      n += __popcll(mask);
     }
-    num += __popcll(mask);
+    if (lane == 0) s_num = n;
   }
   __syncthreads();
+  const int num = s_num;
 
   // Join the two lightest nodes until one is left (huffman_enc.cpp:199-227).  The
   // reference's scan picks them under the total order (count ascending, node index
   // DESCENDING).  Instead of searching all nodes every time (O(n^2)):
-  //   * the leaves are sorted once by that order (rank sort, all 64 lanes);
+  //   * the leaves are sorted once by that order (rank sort, one lane per leaf);
   //   * internal nodes are created with non-decreasing counts, so among them the
   //     lightest is the LAST node of the leading group of equal counts.  A group is
   //     final once consumption from it starts (any later node weighs at least
@@ -1128,36 +1137,46 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
   //     starts at inext" describes the queue, consumed from ie - 1 downwards;
   //   * ties between a leaf and an internal node go to the internal node (its
   //     index is larger).
-  // One lane then merges in O(n).
-  for (int j = lane; j < num; j += 64) {
-    const int cj = cnt[j];
+  if (lane < num) {
+    const int cj = cnt[lane];
     int rank = 0;
     for (int i = 0; i < num; ++i) {
       const int ci = cnt[i];
-      rank += (ci < cj || (ci == cj && i > j)) ? 1 : 0;
+      rank += (ci < cj || (ci == cj && i > lane)) ? 1 : 0;
     }
     s_cnt[rank] = cj;
-    s_idx[rank] = (short)j;
+    s_idx[rank] = (short)lane;
   }
   __syncthreads();
-  int next = num;
-  if (lane == 0 && num > 1) {
+  if (lane < 64 && num > 1) {
+    const int un = uni(num);             // (the merge's copy of num and next, in SGPRs)
+    int next = un;
+    // The merge is serial, O(n), and wave 0 runs it with WAVE-UNIFORM control: every
+    // value that steers the loop sits in an SGPR (uni()), so the loop is scalar
+    // branches and scalar arithmetic instead of one lane's divergent code under exec
+    // masks, and no LDS read is waited for on the way round: the head of the sorted
+    // leaves is fetched one leaf ahead, and what the queue of internal nodes needs --
+    // the count of the group that opens next and where it ends -- is known in
+    // registers when the run of equal counts it belongs to is closed, or fetched when
+    // the group before it opens.  Subtree sizes flow through VGPRs to their store.
     int lh = 0;                          // head of the sorted leaves
-    int ib = num, ie = num, inext = num; // current internal group [ib, ie), next group from inext
+    int lc = uni(s_cnt[0]), li = uni(s_idx[0]);    // the head leaf
+    int lc_nv = s_cnt[1], li_nv = s_idx[1];         // the one behind it (num > 1), still in flight (VGPRs)
+    int ib = un, ie = un, inext = un;    // current internal group [ib, ie), next group from inext
     int g = 0;                           // count of the current group
-    int lc = s_cnt[0], li = s_idx[0];    // the head leaf
-    for (int left = num; left > 1; --left) {
+    int run0 = un, run_c = -1;           // the run of equal counts at the end of the nodes: [run0, next)
+    int pg_v = 0, pe_v = 0;              // count / end of the group at inext when that run is closed (VGPRs)
+    for (int left = un; left > 1; --left) {
       int pick[2], pc[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (ib == ie && inext < next) {  // open the next group of equal counts
           ib = inext;
-          g = cnt[ib];
-          int e = ib + 1;
-          while (e < next && cnt[e] == g) ++e;
-          ie = inext = e;
+          if (ib >= run0) { g = run_c; ie = inext = next; }   // the last run (it may still grow, below)
+          else { g = uni(pg_v); ie = inext = uni(pe_v); }
+          if (inext < run0) { pg_v = cnt[inext]; pe_v = s_end[inext]; }   // the group after it, for later
         }
-        const bool have_int = ib < ie, have_leaf = lh < num;
+        const bool have_int = ib < ie, have_leaf = lh < un;
         if (have_int && (!have_leaf || g <= lc)) {
           pick[t] = --ie;
           pc[t] = g;
@@ -1165,52 +1184,66 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
           pick[t] = li;
           pc[t] = lc;
           ++lh;
-          if (lh < num) { lc = s_cnt[lh]; li = s_idx[lh]; }
+          lc = uni(lc_nv); li = uni(li_nv);
+          const int nx = min(lh + 1, un);        // (the arrays hold two entries of padding)
+          lc_nv = s_cnt[nx]; li_nv = s_idx[nx];
         }
       }
       const int c = pc[0] + pc[1];
-      ca[next] = (short)pick[0]; cb[next] = (short)pick[1]; nsym[next] = -1;
-      cnt[next] = c;
       // Subtree size in bits of the serialisation (leaf: 1 + 9, branch: 1 + its children):
       // the children exist already.
-      s_sz[next] = 1 + (pick[0] < num ? 10 : s_sz[pick[0]]) + (pick[1] < num ? 10 : s_sz[pick[1]]);
+      const int sz = 1 + s_sz[pick[0]] + s_sz[pick[1]];
+      const bool grows = c == run_c;     // the new node joins the last run (untouched, or it would weigh more)
+      if (lane == 0) {
+        ca[next] = (short)pick[0]; cb[next] = (short)pick[1]; nsym[next] = -1;
+        cnt[next] = c;
+        s_sz[next] = sz;
+        if (!grows) s_end[run0] = (short)next;
+      }
+      if (!grows) {
+        if (run0 == inext) { pg_v = run_c; pe_v = next; }   // the run that closes is the group that opens next
+        run0 = next; run_c = c;
+      }
       // The new node extends the current group iff that group is the last one,
       // untouched, and of the same count.
       if (ib < ie && ie == inext && inext == next && g == c) ie = inext = next + 1;
       ++next;
+      // (what steers the loop stays in SGPRs)
+      lh = uni(lh); ib = uni(ib); ie = uni(ie); inext = uni(inext); g = uni(g); run0 = uni(run0); run_c = uni(run_c);
+      next = uni(next);
     }
   }
   __syncthreads();
-  next = num > 1 ? 2 * num - 1 : num;
+  const int next = num > 1 ? 2 * num - 1 : num;
 
   // Codes and the serialised tree (huffman_enc.cpp:148-180) without a serial walk.
   // A node's depth, code (LSB first: taking child_b at depth d sets bit d) and bit
   // position in the pre-order serialisation are sums / concatenations along its path
   // from the root: position = sum over the path of (1 + the left sibling's subtree size
   // for a right child), code = the path's side bits.  Path sums are what POINTER JUMPING
-  // computes in log2(depth) rounds: every node keeps an ancestor, the length, the side
-  // bits and the position offset of the path segment up to it, and in a round takes over
-  // its ancestor's segment and ancestor -- nine rounds cover any tree of 261 leaves (the
-  // level-by-level propagation this replaces took two barriers per tree level, twice,
-  // and was 70 of the kernel's 112 us).  Subtree sizes (leaf: 1 + 9 bits, branch: 1 + its
-  // children) come from the merge itself, which creates parents after their children.
+  // computes in log2(depth) rounds: every node (one lane each) keeps an ancestor, the
+  // length, the side bits and the position offset of the path segment up to it, and in a
+  // round takes over its ancestor's segment and ancestor -- nine rounds cover any tree
+  // of 261 leaves.  Subtree sizes (leaf: 1 + 9 bits, branch: 1 + its children) come from
+  // the merge itself, which creates parents after their children.
   __shared__ short s_par[2 * kNumSym];
   __shared__ uint8_t s_side[2 * kNumSym];
   __shared__ short s_depth[2 * kNumSym];       // length of the node's segment; at the end: its depth
   __shared__ int s_pos[2 * kNumSym];           // offset along the segment; at the end: bit position in the serialisation
   __shared__ unsigned long long s_code[2 * kNumSym];   // side bits of the segment; at the end: the code
   __shared__ short s_anc[2 * kNumSym];         // the node above the segment (the root: itself)
-  __shared__ int s_changed, s_err;
-  for (int v = lane; v < next; v += 64) { s_par[v] = -1; if (v < num) s_sz[v] = 10; }
-  if (lane == 0) s_err = 0;
+  __shared__ int s_changed[2], s_err;
+  const int v = lane;
+  if (v < next) s_par[v] = -1;
+  if (lane == 0) { s_err = 0; s_changed[0] = 0; s_changed[1] = 0; }
   __syncthreads();
-  for (int v = num + lane; v < next; v += 64) {   // internal nodes name their children
+  if (v >= num && v < next) {   // internal nodes name their children
     s_par[ca[v]] = (short)v; s_side[ca[v]] = 0;
     s_par[cb[v]] = (short)v; s_side[cb[v]] = 1;
   }
   __syncthreads();
   const int root = next - 1;
-  for (int v = lane; v < next; v += 64) {
+  if (v < next) {
     const int p = s_par[v];
     if (p < 0) {   // the root (its record is final)
       // A single symbol is one leaf with a 1-bit code 0 (huffman_enc.cpp:231-237).
@@ -1223,44 +1256,34 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
     }
   }
   __syncthreads();
-  constexpr int kPer = (2 * kNumSym + 63) / 64;   // nodes per lane
   for (int round = 0; round < 12; ++round) {
     // Every node whose segment does not start at the root yet takes over its ancestor's
     // segment: all records are read first, then written, so a round only sees the round
     // before.
-    short na[kPer], nd[kPer];
-    int np[kPer];
-    unsigned long long nc[kPer];
-    bool moved = false;
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int v = lane + 64 * k;
-      na[k] = -1;
-      if (v < next) {
-        const int a = s_anc[v];
-        if (a != root && a != v) {
-          const int la = s_depth[a], lv = s_depth[v];
-          na[k] = s_anc[a];
-          nd[k] = (short)min(la + lv, 255);
-          nc[k] = s_code[a] | (la < 64 ? s_code[v] << la : 0ull);
-          np[k] = s_pos[a] + s_pos[v];
-          moved = true;
-        }
+    short na = -1, nd = 0;
+    int np = 0;
+    unsigned long long nc = 0;
+    if (v < next) {
+      const int a = s_anc[v];
+      if (a != root && a != v) {
+        const int la = s_depth[a], lv = s_depth[v];
+        na = s_anc[a];
+        nd = (short)min(la + lv, 255);
+        nc = s_code[a] | (la < 64 ? s_code[v] << la : 0ull);
+        np = s_pos[a] + s_pos[v];
       }
     }
-    if (lane == 0) s_changed = 0;
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int v = lane + 64 * k;
-      if (na[k] >= 0) { s_anc[v] = na[k]; s_depth[v] = nd[k]; s_code[v] = nc[k]; s_pos[v] = np[k]; }
+    if (na >= 0) {
+      s_anc[v] = na; s_depth[v] = nd; s_code[v] = nc; s_pos[v] = np;
+      s_changed[round & 1] = 1;
     }
-    if (moved) s_changed = 1;
+    if (lane == 0) s_changed[(round & 1) ^ 1] = 0;   // (read two barriers ago)
     __syncthreads();
-    if (!s_changed) break;
+    if (!s_changed[round & 1]) break;
   }
   // Leaves: code table entries and their 10 bits of the serialisation (branches are 0 bits).
-  for (int v = lane; v < num; v += 64) {
+  if (v < num) {
     const int sym = nsym[v], d = s_depth[v];
     codes[sym] = s_code[v];
     lens[sym] = (uint32_t)d;
@@ -1271,15 +1294,14 @@ __global__ __launch_bounds__(64) void k_tree(EncWs ws, int strm0) {
     if (val >> 32) atomicOr(&bits[(pos >> 5) + 1], (uint32_t)(val >> 32));
   }
   __syncthreads();
+  const uint32_t nb = next > 0 ? (uint32_t)s_sz[next - 1] : 0u;
+  const int nbytes = (int)((nb + 7) >> 3);
   if (lane == 0) {
-    const uint32_t nb = next > 0 ? (uint32_t)s_sz[next - 1] : 0u;
-    s_num = (int)((nb + 7) >> 3);
     ws.tree_nbytes[(size_t)f * 2 + strm] = (nb + 7) >> 3;
     if (s_err) atomicMax(&ws.status[f], 3);  // code longer than 32 bits: outside the built scope
   }
-  __syncthreads();
   uint8_t *tree = ws.tree + ((size_t)f * 2 + strm) * kTreeStride;
-  for (int k = lane; k < s_num; k += 64) tree[k] = (uint8_t)(bits[k >> 2] >> ((k & 3) * 8));
+  for (int k = lane; k < nbytes; k += kTreeThreads) tree[k] = (uint8_t)(bits[k >> 2] >> ((k & 3) * 8));
 }
 
 __device__ __forceinline__ int extra_bits_of(int sym) {
@@ -1891,7 +1913,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   }
   HIMG_LAUNCH_PAD(k_tok_hist, dim3(g.rows, batch), b256, g, ws, g.lres_spans);   // FRES rows
   if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-  HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(64), ws, 0);
+  HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(kTreeThreads), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
   HIMG_LAUNCH_PAD(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes, 0);
@@ -1932,7 +1954,7 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
 
 void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
                            hipStream_t stream, Profiler *prof) {
-  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(64), ws, 1);
+  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 1);
   if (r1 > r0)
     HIMG_LAUNCH(k_row_bits, dim3((r1 - r0 + 255) / 256), dim3(256), g, ws, r0, r1 - r0, d_bits_out);
 }
@@ -1962,7 +1984,7 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
               ws.lres_sym, ws.lres_stride, lt);
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, 1), b256, g, ws);
   HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, 1), b256, g, ws, 0);
-  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(64), ws, 0);
+  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0);
   HIMG_LAUNCH(k_emit, dim3(g.lres_spans, 1), b256, g, ws, d_out, out_cap, d_size, 0);
   HIMG_LAUNCH(k_place_fres, dim3(1024), b256, g, ws, d_rel, rel_bytes, d_out, d_size);
