@@ -91,6 +91,7 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
   int32_t parse_status;      // k_dec_parse's own verdict (status collects the later kernels' as well)
   int32_t walk_status;       // k_dec_rowwalk's verdict: it runs beside k_dec_parse, k_row_count merges it
   uint32_t rows_first;       // k_dec_rowwalk: byte offset of the first FRES row header (0: not found)
+  uint32_t walk_q, walk_r, walk_end;   // k_dec_rowwalk in several launches: where the next one resumes (walk_q 0: finished)
   int32_t ycbcr;
   DecStream s[2];
   int16_t lmap[128];         // decoder-side companding tables (positive halves)
@@ -141,10 +142,20 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
                    const uint8_t *d_fmap_lut, hipStream_t stream, Profiler *prof,
                    hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
 
+// The decoder's helper streams and events (owned by the context).
+constexpr int kWalkSegs = 4;   // single large frames: at most this many row ranges whose walk / count / row kernels overlap
+struct DecStreams {
+  hipStream_t side = nullptr;    // the serial row-header walk; k_row_count behind it (batches)
+  hipStream_t side2 = nullptr;   // single frames: k_row_count of a row range while `side` walks the next one
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_walk[kWalkSegs] = {}, ev_cnt[kWalkSegs] = {};
+  int walk_segs = 0;             // HIMG_WALK_SEGS at context creation (0: by frame size)
+};
+
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
-                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1,
+                   const DecStreams *ds, int r0, int r1,
                    const uint32_t *d_row_index = nullptr, bool index_only = false);
 
 // Row-sharded encode of one frame (multi-GPU): phases between the collectives.

@@ -100,8 +100,7 @@ struct himg_hip_ctx {
   bool allow_fused = true;
   bool use_side = true;  // HIMG_SIDE_STREAM=0 keeps the row-header walk on the caller's stream
   // Side stream + events: the decoder forks its serial row-header walk onto it.
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  DecStreams dstr;
   // The encoder's side stream carries its LRES branch, which is on the critical path
   // (k_tree waits for it): default priority, its own events -- not the decoder's
   // lowest-priority stream, behind whose wide k_row_count launches of other contexts it
@@ -230,6 +229,7 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   himg_hip_ctx *ctx = new himg_hip_ctx();
   ctx->device = device;
   if (const char *e = std::getenv("HIMG_FORCE_UNFUSED")) ctx->allow_fused = !(e[0] == '1');
+  if (const char *e = std::getenv("HIMG_WALK_SEGS")) ctx->dstr.walk_segs = atoi(e);
   if (const char *e = std::getenv("HIMG_SIDE_STREAM")) ctx->use_side = !(e[0] == '0');
   if (const char *e = std::getenv("HIMG_FIX_T2")) ctx->fix_t2 = e[0] == '1';
   if (const char *e = std::getenv("HIMG_FORCE_LRES_SERIAL")) ctx->lres_serial = e[0] == '1';
@@ -257,9 +257,13 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   // frees up (they sit on the critical path of the frame, the counts do not).
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  if (hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+  bool ev_ok = true;
+  for (int k = 0; k < kWalkSegs; ++k)
+    ev_ok = ev_ok && hipEventCreateWithFlags(&ctx->dstr.ev_walk[k], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->dstr.ev_cnt[k], hipEventDisableTiming) == hipSuccess;
+  if (!ev_ok || hipStreamCreateWithPriority(&ctx->dstr.side, hipStreamNonBlocking, prio_least) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->dstr.side2, hipStreamNonBlocking, prio_least) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->dstr.ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->side_enc, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork_e, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join_e, hipEventDisableTiming) != hipSuccess) {
@@ -274,9 +278,13 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipDeviceSynchronize();
-  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-  if (ctx->side) hipStreamDestroy(ctx->side);
+  if (ctx->dstr.ev_fork) hipEventDestroy(ctx->dstr.ev_fork);
+  for (int k = 0; k < kWalkSegs; ++k) {
+    if (ctx->dstr.ev_walk[k]) hipEventDestroy(ctx->dstr.ev_walk[k]);
+    if (ctx->dstr.ev_cnt[k]) hipEventDestroy(ctx->dstr.ev_cnt[k]);
+  }
+  if (ctx->dstr.side) hipStreamDestroy(ctx->dstr.side);
+  if (ctx->dstr.side2) hipStreamDestroy(ctx->dstr.side2);
   if (ctx->ev_fork_e) hipEventDestroy(ctx->ev_fork_e);
   if (ctx->ev_join_e) hipEventDestroy(ctx->ev_join_e);
   if (ctx->side_enc) hipStreamDestroy(ctx->side_enc);
@@ -606,7 +614,7 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   if (rc) return rc;
   launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
                 (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof,
-                ctx->allow_fused, ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, 0,
+                ctx->allow_fused, ctx->use_side ? &ctx->dstr : nullptr, 0,
                 g.rows);
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
@@ -640,7 +648,7 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
   uint8_t *base = (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C;
   launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
                 (const uint32_t *)ctx->d_sizes.p, base, d_status, s, &ctx->prof, ctx->allow_fused,
-                ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, row0, row1);
+                ctx->use_side ? &ctx->dstr : nullptr, row0, row1);
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }
@@ -669,7 +677,7 @@ extern "C" int himg_hip_decode_index_device(himg_hip_ctx *ctx, const void *d_pac
   if (rc) return rc;
   launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
                 (const uint32_t *)ctx->d_sizes.p, nullptr, d_status, s, &ctx->prof, ctx->allow_fused,
-                nullptr, ctx->ev_fork, ctx->ev_join, 0, g.rows, nullptr, true);
+                nullptr, 0, g.rows, nullptr, true);
   HIP_TRY(ctx, hipMemcpyAsync(d_row_index, ctx->dec_ws.row_off, (size_t)g.rows * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(ctx, hipMemcpyAsync(d_row_index + g.rows, ctx->dec_ws.row_len, (size_t)g.rows * 4,
                               hipMemcpyDeviceToDevice, s));
@@ -708,7 +716,7 @@ extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void
   uint8_t *base = (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C;
   launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
                 (const uint32_t *)ctx->d_sizes.p, base, d_status, s, &ctx->prof, ctx->allow_fused,
-                ctx->use_side ? ctx->side : nullptr, ctx->ev_fork, ctx->ev_join, row0, row1, d_row_index);
+                ctx->use_side ? &ctx->dstr : nullptr, row0, row1, d_row_index);
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }

@@ -630,8 +630,13 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
 // hops hit in L2 -- slower; the headers through the scalar cache -- 9 % faster at
 // 4096 pixels, 38 % slower at 16384.)
 // ---------------------------------------------------------------------------
+// A single frame's walk is cut into row ranges, one launch each (row_end: walk the rows in
+// front of it; the last launch walks to the end of the chunk; resume: continue where the
+// launch before stopped, DecFrame::walk_q / walk_r): the counts and the row kernels of a
+// range run while the next range is walked (launch_decode).
 __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint8_t *packed,
-                                                    size_t in_stride, const uint32_t *sizes) {
+                                                    size_t in_stride, const uint32_t *sizes,
+                                                    int row_end, int resume) {
   // The walk needs where the FRES payload starts and ends -- which k_dec_parse knows
   // only after its tree recovery.  It finds both by itself (the same chunk
   // look-ups, then only the LENGTH of the serialised tree: a leaf is 1 + 9 bits, a
@@ -644,63 +649,71 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
   const int f = blockIdx.x, lane = threadIdx.x;
   DecFrame *df = ws.frames + f;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  const uint32_t n = sizes[f];
-  if (lane == 0) {
-    uint32_t idx = 12, sz = 0;
-    bool ok = n >= 12;
-    const uint32_t tags[6] = {0x544d5246u /*FRMT*/, 0x50414d4cu /*LMAP*/, 0x5345524cu /*LRES*/,
-                              0x47464351u /*QCFG*/, 0x50414d46u /*FMAP*/, 0x53455246u /*FRES*/};
-    for (int t = 0; ok && t < 6; ++t) {   // the order of k_dec_parse (decoder.cpp:144-290)
-      ok = find_chunk(p, n, &idx, tags[t], &sz);
-      if (ok && t < 5) idx += sz;
+  uint32_t q = 0, end = 0;
+  int r = 0;
+  if (resume) {
+    if (lane != 0) return;
+    q = df->walk_q; r = (int)df->walk_r; end = df->walk_end;
+    if (q == 0) return;   // finished (or never started): the verdict is in
+  } else {
+    const uint32_t n = sizes[f];
+    if (lane == 0) {
+      uint32_t idx = 12, sz = 0;
+      bool ok = n >= 12;
+      const uint32_t tags[6] = {0x544d5246u /*FRMT*/, 0x50414d4cu /*LMAP*/, 0x5345524cu /*LRES*/,
+                                0x47464351u /*QCFG*/, 0x50414d46u /*FMAP*/, 0x53455246u /*FRES*/};
+      for (int t = 0; ok && t < 6; ++t) {   // the order of k_dec_parse (decoder.cpp:144-290)
+        ok = find_chunk(p, n, &idx, tags[t], &sz);
+        if (ok && t < 5) idx += sz;
+      }
+      s_hdr[0] = ok ? idx : 0u;
+      s_hdr[1] = ok ? sz : 0u;
+      df->walk_status = 0;
+      df->rows_first = 0;
+      df->walk_q = 0;
     }
-    s_hdr[0] = ok ? idx : 0u;
-    s_hdr[1] = ok ? sz : 0u;
-    df->walk_status = 0;
-    df->rows_first = 0;
-  }
-  __syncthreads();
-  const uint32_t coff = s_hdr[0], csz = s_hdr[1];
-  if (coff == 0) return;
-  const uint32_t cnt = csz < (uint32_t)kTreeStride ? csz : (uint32_t)kTreeStride;
-  for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16u; k += 64u)
-    reinterpret_cast<uint8_t *>(s_tree)[k] = k < cnt ? p[coff + k] : (uint8_t)0;
-  __syncthreads();
-  if (lane != 0) return;
-  uint32_t bit = 0;
-  {
-    // Length of the serialised tree over a 64-bit register window.
-    unsigned long long win = ((unsigned long long)s_tree[1] << 32) | s_tree[0];
-    uint32_t next = 2, ahead = s_tree[2];
-    const uint32_t bit_end = 8u * cnt;
-    int open = 1, count = 0, nb = 64;
-    while (open > 0) {
-      if (count >= kMaxNodes || bit >= bit_end) return;   // k_dec_parse rejects this tree
-      ++count;
-      if (nb <= 32) { win |= (unsigned long long)ahead << nb; nb += 32; ahead = s_tree[++next]; }
-      if (win & 1ull) {
-        if (bit + 10u > bit_end) return;
-        win >>= 10; nb -= 10; bit += 10u;
-        --open;
-      } else {
-        win >>= 1; nb -= 1; bit += 1u;
-        ++open;
+    __syncthreads();
+    const uint32_t coff = s_hdr[0], csz = s_hdr[1];
+    if (coff == 0) return;
+    const uint32_t cnt = csz < (uint32_t)kTreeStride ? csz : (uint32_t)kTreeStride;
+    for (uint32_t k = lane; k < (uint32_t)kTreeStride + 16u; k += 64u)
+      reinterpret_cast<uint8_t *>(s_tree)[k] = k < cnt ? p[coff + k] : (uint8_t)0;
+    __syncthreads();
+    if (lane != 0) return;
+    uint32_t bit = 0;
+    {
+      // Length of the serialised tree over a 64-bit register window.
+      unsigned long long win = ((unsigned long long)s_tree[1] << 32) | s_tree[0];
+      uint32_t next = 2, ahead = s_tree[2];
+      const uint32_t bit_end = 8u * cnt;
+      int open = 1, count = 0, nb = 64;
+      while (open > 0) {
+        if (count >= kMaxNodes || bit >= bit_end) return;   // k_dec_parse rejects this tree
+        ++count;
+        if (nb <= 32) { win |= (unsigned long long)ahead << nb; nb += 32; ahead = s_tree[++next]; }
+        if (win & 1ull) {
+          if (bit + 10u > bit_end) return;
+          win >>= 10; nb -= 10; bit += 10u;
+          --open;
+        } else {
+          win >>= 1; nb -= 1; bit += 1u;
+          ++open;
+        }
       }
     }
+    q = coff + ((bit + 7u) >> 3);   // AlignToByte, huffman_dec.cpp:229
+    end = coff + csz;
+    if (q >= end) return;                    // nothing behind the tree: k_dec_parse's verdict
+    df->rows_first = q;
+    if (g.fix_t2 && g.rows == 1) {   // the encoder writes one block row without a size header
+      ws.row_off[(size_t)f * g.rows] = q;
+      ws.row_len[(size_t)f * g.rows] = end - q;
+      return;
+    }
   }
-  int st = 0;
-  uint32_t q = coff + ((bit + 7u) >> 3);   // AlignToByte, huffman_dec.cpp:229
-  const uint32_t end = coff + csz;
-  if (q >= end) return;                    // nothing behind the tree: k_dec_parse's verdict
   uint32_t *ro = ws.row_off + (size_t)f * g.rows, *rl = ws.row_len + (size_t)f * g.rows;
-  df->rows_first = q;
-  if (g.fix_t2 && g.rows == 1) {   // the encoder writes one block row without a size header
-    ro[0] = q;
-    rl[0] = end - q;
-    return;
-  }
-  int r = 0;
-  while (q != end) {
+  int st = 0;
+  while (q != end && r < row_end) {
     if (q + 2 > end) { st = fmt_err(7, 1); break; }
     uint32_t len = p[q] | (p[q + 1] << 8);
     q += 2;
@@ -714,8 +727,13 @@ __global__ __launch_bounds__(64) void k_dec_rowwalk(Geom g, DecWs ws, const uint
     ++r;
     q += len;
   }
-  if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
-  df->walk_status = st;
+  if (st || q == end) {
+    if (!st && r < g.rows) st = fmt_err(7, 1);  // fewer blocks than block rows
+    df->walk_status = st;
+    df->walk_q = 0;
+  } else {   // the next launch goes on from here
+    df->walk_q = q; df->walk_r = (uint32_t)r; df->walk_end = end;
+  }
 }
 
 // k_dec_set_index: the row index comes from the caller (row-sharded decode: the rank
@@ -2953,15 +2971,16 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
-                   hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, int r0, int r1,
+                   const DecStreams *ds, int r0, int r1,
                    const uint32_t *d_row_index, bool index_only) {
   // d_row_index: the FRES row index is given (k_dec_set_index instead of the serial
   // header walk; one frame).  index_only: container parse and row-header walk only --
   // the caller reads ws.row_off / ws.row_len / DecFrame::rows_first (rank 0 of a
   // row-sharded decode).
+  constexpr int kWalkAll = 0x7fffffff;
   if (index_only) {
     HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
-    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
+    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes, kWalkAll, 0);
     HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
     return;
   }
@@ -2978,6 +2997,19 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // LDS (width <= 4352 for RGBA); the payload is read in place from L2.
   constexpr uint32_t kLdsMax = 160u * 1024u;
   const int wps = (allow_fused && fused_layout(g.row_block).total <= kLdsMax) ? 1 : 0;
+  // A single large frame (nothing else to fill the GPU with while one lane walks its row
+  // headers, 1.3 ms for 16384 x 16384): the rows in two ranges -- the walk of a range on
+  // `side`, its counts on `side2`, its row kernels on the caller's stream, each behind the
+  // stage before it and beside the next range's walk.  16384^2: 4.15 -> 3.32 ms, which is
+  // the sum of the row kernels' own times (two ranges or four); a dependency across
+  // streams costs tens of microseconds, so frames of fewer than 1024 block rows (4096^2:
+  // 0.40 ms either way, 1024^2: 0.23 -> 0.30 ms) stay in one piece.
+  const int seg_env = ds ? ds->walk_segs : 0;
+  const int seg_want = seg_env ? (seg_env < 1 ? 1 : seg_env > kWalkSegs ? kWalkSegs : seg_env) : (nrows >= 1024 ? 2 : 1);
+  const int nseg = (ds && batch == 1 && !d_row_index && r0 == 0 && r1 == g.rows && nrows >= 16 * kWalkSegs) ? seg_want : 1;
+  hipStream_t side = ds ? ds->side : nullptr;
+  hipStream_t cnt_stream = !ds ? stream : nseg > 1 ? ds->side2 : ds->side;
+  auto seg_lo = [&](int k) { return r0 + (int)((long long)nrows * k / nseg); };
   // Diagnostics and the LRES symbols (k_lres_write stores the non-zero ones only) are
   // cleared up front: k_row_count may start as soon as the parse and the walk are done.
   {
@@ -2989,41 +3021,52 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     prof_end(prof, stream);
   }
   // Fork: the serial FRES row-header walk runs on the side stream beside k_dec_parse.
-  if (side) {
-    (void)hipEventRecord(ev_fork, stream);
-    (void)hipStreamWaitEvent(side, ev_fork, 0);
+  if (ds) {
+    (void)hipEventRecord(ds->ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ds->ev_fork, 0);
     if (d_row_index) {
       prof_begin(prof, "k_dec_set_index", side);
       hipLaunchKernelGGL(k_dec_set_index, dim3(1), dim3(256), 0, side, g, ws, d_row_index, d_sizes, r0, r1);
+      prof_end(prof, side);
+      (void)hipEventRecord(ds->ev_walk[0], side);
     } else {
-      prof_begin(prof, "k_dec_rowwalk", side);
-      hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride, d_sizes);
+      for (int k = 0; k < nseg; ++k) {
+        prof_begin(prof, "k_dec_rowwalk", side);
+        hipLaunchKernelGGL(k_dec_rowwalk, dim3(batch), dim3(64), 0, side, g, ws, d_packed, in_stride, d_sizes,
+                           k + 1 < nseg ? seg_lo(k + 1) : kWalkAll, k > 0 ? 1 : 0);
+        prof_end(prof, side);
+        (void)hipEventRecord(ds->ev_walk[k], side);
+      }
     }
-    prof_end(prof, side);
   }
   HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
-  // The FRES fixpoint rounds need the decode tables (parse) and the row index (walk);
-  // they join this stream again before the first FRES row kernel.
-  // (side == nullptr: everything in line.)
-  if (side) {
-    (void)hipEventRecord(ev_fork, stream);
-    (void)hipStreamWaitEvent(side, ev_fork, 0);
+  // The FRES counts need the decode tables (parse) and the row index (walk); their
+  // stream joins this one again before the FRES row kernels.
+  // (ds == nullptr: everything in line.)
+  auto row_count = [&](hipStream_t s, int a, int b) {
+    if (b <= a) return;
+    prof_begin(prof, "k_row_count", s);
+    if (wps)
+      hipLaunchKernelGGL(k_row_count<true>, dim3((b - a + rpc - 1) / rpc, batch), dim3(kDecThreads), 0, s, g, ws,
+                         d_packed, in_stride, d_sizes, a, b, rpc);
+    else
+      hipLaunchKernelGGL(k_row_count<false>, dim3((b - a + rpc - 1) / rpc, batch), dim3(kDecThreads), 0, s, g, ws,
+                         d_packed, in_stride, d_sizes, a, b, rpc);
+    prof_end(prof, s);
+  };
+  if (ds) {
+    (void)hipEventRecord(ds->ev_fork, stream);
+    (void)hipStreamWaitEvent(cnt_stream, ds->ev_fork, 0);
     // They fill the CUs the latency-bound LRES kernels leave idle.
-    if (nrows > 0) {
-      prof_begin(prof, "k_row_count", side);
-      if (wps)
-        hipLaunchKernelGGL(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), 0,
-                           side, g, ws, d_packed, in_stride, d_sizes, r0, r1, rpc);
-      else
-        hipLaunchKernelGGL(k_row_count<false>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), 0,
-                           side, g, ws, d_packed, in_stride, d_sizes, r0, r1, rpc);
-      prof_end(prof, side);
+    for (int k = 0; k < nseg; ++k) {
+      if (cnt_stream != side) (void)hipStreamWaitEvent(cnt_stream, ds->ev_walk[k], 0);
+      row_count(cnt_stream, seg_lo(k), seg_lo(k + 1));
+      (void)hipEventRecord(ds->ev_cnt[k], cnt_stream);
     }
-    (void)hipEventRecord(ev_join, side);
   } else if (d_row_index) {
     HIMG_LAUNCH(k_dec_set_index, dim3(1), dim3(256), g, ws, d_row_index, d_sizes, r0, r1);
   } else {
-    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes);
+    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes, kWalkAll, 0);
   }
   // LRES: every chunk in parallel, chain verified, serial fallback if not.
   static const int lres_stage = getenv("HIMG_LRES_STAGE") ? atoi(getenv("HIMG_LRES_STAGE")) : 3;
@@ -3043,10 +3086,6 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   if (wps) {
     HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
                 dim3(64 * kUnpredWaves), g, ws);
-    if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-    if (!side && nrows > 0)
-      HIMG_LAUNCH(k_row_count<true>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
-                  d_packed, in_stride, d_sizes, r0, r1, rpc);
     // Rows per workgroup: as many as the transform has lanes for and the LDS holds
     // (4096-pixel rows: one).
     const int per_row = ((g.cols + 31) / 32) * 64;
@@ -3056,21 +3095,25 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     if (rpw_env > 0 && rpw_env < rpw) rpw = rpw_env;
     if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) rpw = 1;
     const uint32_t lds = fused_layout(g.row_block, rpw).total;
-    prof_begin(prof, "k_dec_row_fused", stream);
-#define HIMG_FUSED_LAUNCH(COLS)                                                                 \
+#define HIMG_FUSED_LAUNCH(COLS, A, B)                                                           \
   do {                                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<COLS>),           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3((nrows + rpw - 1) / rpw, batch),           \
+    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3(((B) - (A) + rpw - 1) / rpw, batch),       \
                        dim3(kDecThreads), lds, stream, g, ws, d_packed, in_stride, d_sizes,     \
-                       d_out, r0, r1, rpw);                                                     \
+                       d_out, (A), (B), rpw);                                                   \
   } while (0)
-    if (nrows > 0) {
-      if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) HIMG_FUSED_LAUNCH(512);   // whole tiles only (FULL4)
-      else HIMG_FUSED_LAUNCH(0);
+    for (int k = 0; k < nseg; ++k) {
+      const int a = seg_lo(k), b = seg_lo(k + 1);
+      if (ds) (void)hipStreamWaitEvent(stream, ds->ev_cnt[k], 0);
+      else row_count(stream, a, b);
+      if (b <= a) continue;
+      prof_begin(prof, "k_dec_row_fused", stream);
+      if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) HIMG_FUSED_LAUNCH(512, a, b);   // whole tiles only (FULL4)
+      else HIMG_FUSED_LAUNCH(0, a, b);
+      prof_end(prof, stream);
     }
 #undef HIMG_FUSED_LAUNCH
-    prof_end(prof, stream);
   } else {
     // Symbols through HBM: the write pass stores the non-zero literals into the zeroed
     // plane.  The clear (1 GiB for a 16384 x 16384 frame) and the predictor inverse go
@@ -3086,11 +3129,11 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     }
     HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
                 dim3(64 * kUnpredWaves), g, ws);
-    if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
-    if (!side && nrows > 0)
-      HIMG_LAUNCH(k_row_count<false>, dim3((nrows + rpc - 1) / rpc, batch), dim3(kDecThreads), g, ws,
-                  d_packed, in_stride, d_sizes, r0, r1, rpc);
-    if (nrows > 0) {
+    for (int k = 0; k < nseg; ++k) {
+      const int a = seg_lo(k), b = seg_lo(k + 1);
+      if (ds) (void)hipStreamWaitEvent(stream, ds->ev_cnt[k], 0);
+      else row_count(stream, a, b);
+      if (b <= a) continue;
       // Rows without a usable fixpoint (several chunks) take the window path of
       // k_dec_huff, which skips the others.
       if (window) {
@@ -3099,15 +3142,15 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_window),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         prof_begin(prof, "k_row_window", stream);
-        hipLaunchKernelGGL(k_row_window, dim3(nwin, nrows, batch), dim3(kDecThreads), lds, stream, g, ws, d_packed,
-                           in_stride, d_sizes, r0);
+        hipLaunchKernelGGL(k_row_window, dim3(nwin, b - a, batch), dim3(kDecThreads), lds, stream, g, ws, d_packed,
+                           in_stride, d_sizes, a);
         prof_end(prof, stream);
       } else {
-        HIMG_LAUNCH(k_row_write_g, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, r0);
+        HIMG_LAUNCH(k_row_write_g, dim3(b - a, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, a);
       }
-      HIMG_LAUNCH(k_dec_huff, dim3(nrows, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, 1 + r0, 1, 2);
-      HIMG_LAUNCH(k_tile_inv, dim3(gx, nrows, batch), dim3(256), g, ws, d_out, r0);
+      HIMG_LAUNCH(k_dec_huff, dim3(b - a, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
+                  d_sizes, 1 + a, 1, 2);
+      HIMG_LAUNCH(k_tile_inv, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
     }
   }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);

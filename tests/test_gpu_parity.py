@@ -346,6 +346,60 @@ def test_damaged_trees_decode_like_the_reference(engine):
     assert accepted > 10 and rejected > 10
 
 
+def test_row_ranges_decode_like_one_piece():
+    """HIMG_WALK_SEGS (by default only frames of 1024 block rows or more: BASELINE config 4):
+    the row-header walk in up to four launches, the counts and the row kernels of a range
+    beside the walk of the next.  Good streams, streams whose damage sits in a later range
+    (rows of the earlier ranges are decoded before the walk finds it) and truncated ones
+    must come out exactly as from the one-piece decode -- fused and generic row kernels."""
+    import os
+    engs = []
+    try:
+        for segs, unfused in ((4, False), (3, True)):
+            os.environ["HIMG_WALK_SEGS"] = str(segs)
+            if unfused:
+                os.environ["HIMG_FORCE_UNFUSED"] = "1"
+            try:
+                engs.append(himg_amd.Engine(0))
+            finally:
+                del os.environ["HIMG_WALK_SEGS"]
+                os.environ.pop("HIMG_FORCE_UNFUSED", None)
+        rng = np.random.default_rng(9)
+        for kind, w, h, q in (("rand", 512, 1024, 50), ("randtile", 1024, 640, 80), ("gradn", 200, 900, 60)):
+            img = himg_amd.synth(kind, 2, w, h)
+            good = ol.oracle_encode(img, q, True)
+            rc, pix = ol.oracle_decode(good)
+            assert rc == 0
+            ch = _chunks(good)
+            off, sz = ch["FRES"]
+            offs = himg_amd.index_host(good)[3]
+            for eng in engs:
+                _eq(eng.decode(good).ravel(), pix.ravel(), "%s %dx%d" % (kind, w, h))
+            accepted = rejected = 0
+            for t in range(40):
+                bad = good.copy()
+                lo = off + sz // 4 * (t % 4)          # the damage in each quarter of the chunk in turn
+                bad[int(rng.integers(lo, lo + sz // 4))] ^= 1 << int(rng.integers(0, 8))
+                if t % 8 == 7:
+                    bad[off + sz - 3] ^= 0x55          # and near its end
+                if t % 5 == 4:                         # a damaged size header of a row in that quarter
+                    r = min(len(offs) - 1, len(offs) // 4 * (t % 4) + int(rng.integers(0, len(offs) // 4)))
+                    bad[int(offs[r]) - 2] ^= 1 << int(rng.integers(0, 8))
+                rc, pix_bad = ol.oracle_decode(bad)
+                for eng in engs:
+                    if rc == 0:
+                        _eq(eng.decode(bad).ravel(), pix_bad.ravel(), "mutation %d" % t)
+                    else:
+                        with pytest.raises(himg_amd.HimgError):
+                            eng.decode(bad)
+                accepted += rc == 0
+                rejected += rc != 0
+            assert accepted > 0 and rejected > 3, (accepted, rejected)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_fixed_mode_decodes_what_the_reference_cannot(engine):
     """HIMG_OPT_FIX_T2 (opt-in): streams of the reference's own encoder that its
     decoder rejects -- compressible frames (trap T2), frames of one block row,
