@@ -8,6 +8,10 @@ OUT=${1:-gpurun_out/refresh}
 SHA=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
+# The PMC passes first: bench.py quotes profiles/traffic.json (HBM bytes per launch, issue
+# fractions) next to its live timings, so the file it reads must be this commit's.
+(cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 8 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
+ python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 8 "$OUT/traffic.json" "$SHA" && cp "$OUT/traffic.json" profiles/traffic.json)
 python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err"
 python3 "$ROOT/tools/occupancy_sweep.py" > "$ROOT/$OUT/cfg3_sweep.json" 2> "$ROOT/$OUT/cfg3_sweep.err"
 python3 "$ROOT/tools/rows_profile.py" > "$ROOT/$OUT/cfg4_rows.json" 2> "$ROOT/$OUT/cfg4_rows.err"
@@ -26,6 +30,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_defaul
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_streams1" -- \
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 8 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_streams1.log" 2>&1
-cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 8 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
-python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 8 "$OUT/traffic.json" "$SHA"
+cd "$ROOT"
 ls "$ROOT/$OUT"
