@@ -78,6 +78,7 @@ constexpr int kLutBits = 11;  // width of the Huffman decode group table
 constexpr int kDecThreads = 1024;
 constexpr int kSubEntries = 1024;  // second-level decode table (codes longer than kLutBits)
 constexpr int kSubMaxBits = 6;     // widest second-level sub-table
+constexpr int kLresSubBits = 256;  // parallel LRES decode: payload bits per lane of a chunk (kDecThreads lanes)
 
 struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
   uint32_t payload_off;      // byte offset (in the packed stream) after the aligned tree

@@ -489,7 +489,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   {
     // LRES payload <= lres_size + tree bytes (huffman_enc.cpp:242-244).
     const size_t max_bits = 8ull * ((size_t)g.lres_size + kTreeStride);
-    const size_t cb = (size_t)kDecThreads * 8 * 32;
+    const size_t cb = (size_t)kDecThreads * kLresSubBits;   // bits per chunk (kLresChunkBits of kernels_dec.hip)
     int nch = (int)((max_bits + cb - 1) / cb);
     if (nch > 1024) nch = 1024;  // beyond this the serial path takes over (k_lres_fix)
     w.lres_chunks = nch;

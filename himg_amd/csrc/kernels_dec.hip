@@ -1643,7 +1643,6 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
 // If an end did change (a mis-speculation ran through a whole 32 KiB chunk) the
 // frame falls back to the serial workgroup-per-stream path (k_dec_huff).
 // ---------------------------------------------------------------------------
-constexpr int kLresSubBits = 256;   // bits per lane
 constexpr int kLresChunkBits = kDecThreads * kLresSubBits;
 
 // One chunk of the LRES stream, tables already in LDS.  FIX false: the speculative
