@@ -2158,18 +2158,20 @@ __device__ __forceinline__ bool packed_wht_exact(const RangeAcc &others, dpk16 d
 // slot: the tile's first symbol (scan index k is at slot[k * cols]); shift: the
 // 64 per-position shifts; shiftp: the same as 32 packed pairs in V order; lr0 /
 // lr8: (left, right) low-res samples of this and the next block row in bytes 0, 1.
-// hfast (COLS only): {bias pair, mask pair} of the identity test below.
+// hfast (COLS != 0): {bias pair, mask pair} of the identity test below.
+// COLS > 0: the tile count per block row at compile time (slot offsets are immediates);
+// COLS < 0: the same fast gather with the run-time count (64 address adds per plane).
 template <int COLS>
 __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, const int16_t *s_unmap,
                                            const uint8_t *shift, const uint32_t *shiftp,
                                            uint32_t lr0, uint32_t lr8, uint32_t O[16],
                                            const uint32_t *hfast = nullptr) {
-  const int cols = COLS ? COLS : cols_rt;
+  const int cols = COLS > 0 ? COLS : cols_rt;
   // Gather + dequantise (quantize.cpp:153-165: int16 wrap == 16-bit shift left).
   dpk16 V[32];
   RangeAcc rng;
   rng.init();
-  if (COLS) {
+  if (COLS != 0) {
     // The companding table is the identity for small codes (mapper.cpp:54-61: up to
     // 49 in the encoder's table; the decoder derives the range from the stream's
     // FMAP), and everything but the lowest frequencies of a tile IS small.  The 21
@@ -2332,7 +2334,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
                                                      const uint8_t *s_shift, const uint32_t *s_shiftp,
                                                      int ycbcr, int u, int s, int v, uint8_t *img,
                                                      const uint32_t *pre_lr = nullptr) {
-  const int cols = COLS ? COLS : cols_rt;
+  const int cols = COLS > 0 ? COLS : cols_rt;
   const int C = FULL4 ? 4 : g.C;
   const int v2 = min(v + 1, g.rows - 1);
     const int u2 = min(u + 1, cols - 1);
@@ -2352,7 +2354,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
           lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
         }
         tile_plane<COLS>(sym + (size_t)c * 64 * cols + u, cols, s_unmap, s_shift + chroma * 64,
-                         s_shiftp + chroma * 32, lr0, lr8, O, COLS ? s_shiftp + 64 + 2 * chroma : nullptr);
+                         s_shiftp + chroma * 32, lr0, lr8, O, COLS != 0 ? s_shiftp + 64 + 2 * chroma : nullptr);
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[i] = 0;
@@ -2432,13 +2434,39 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
     }
 }
 
+// tile_plane's identity test, by one wavefront (l = 0..63).  n = the largest code with
+// fmap[i] == i for all i <= n (mapper.h:33-35: a code unmaps to itself there);
+// B = the largest power of two <= n, lowered until B << (largest shift of group H:
+// rows 2..7 of columns 1..7) <= 2048 (inside both range conditions of the packed
+// transform, packed_wht_exact).  dst[2 * chroma + {0, 1}]: (B, B), then the mask of the
+// bits that a sum code + B outside [0, 2B) sets.  No usable range: the test always fails.
+__device__ __forceinline__ void identity_test_words(const DecFrame *df, int l, uint32_t *dst) {
+  const unsigned long long ne = __ballot(df->fmap[l] != l), ne2 = __ballot(df->fmap[64 + l] != 64 + l);
+  const int n = ne ? __ffsll((long long)ne) - 2 : (ne2 ? 62 + __ffsll((long long)ne2) : 127);
+  if (l < 2) {
+    int smax = 0;
+    for (int y = 2; y < 8; ++y)
+      for (int x = 1; x < 8; ++x) smax = max(smax, (int)df->shift[l][y * 8 + x]);
+    int B = 0;
+    if (n >= 1) {
+      B = 1 << (31 - __clz(n));
+      while (B && ((long long)B << smax) > 2048) B >>= 1;
+    }
+    const uint32_t b16 = B ? (uint32_t)B : 0x4000u, m16 = B ? (uint32_t)(0xffffu & ~(2u * B - 1u)) : 0xffffu;
+    dst[2 * l] = b16 | (b16 << 16);
+    dst[2 * l + 1] = m16 | (m16 << 16);
+  }
+}
+
 // k_tile_inv: the transform of the unfused path (rows too wide for LDS): the
 // symbols come from HBM (ws.fres_sym, written by k_dec_huff); two lanes per tile,
 // 128 tiles per workgroup.
+// FAST: four channels, whole tiles (tile_plane's identity-range gather, no ragged edges).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out_frames, int v0) {
   __shared__ int16_t s_unmap[256];   // indexed by the code byte
   __shared__ uint8_t s_shift[2][64];
-  __shared__ uint32_t s_shiftp[2][32];
+  __shared__ uint32_t s_shiftp[2 * 32 + 4];   // [chroma][register pair], then the identity-test words
   const int v = blockIdx.y + v0, f = blockIdx.z;
   const DecFrame *df = ws.frames + f;
   __shared__ int s_status;
@@ -2452,20 +2480,21 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
     if (k < 128) s_shift[k >> 6][k & 63] = df->shift[k >> 6][k & 63];
     if (k < 64) {
       const int ch = k >> 5, e = k & 31, x = e >> 2, j = e & 3;
-      s_shiftp[ch][e] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
+      s_shiftp[ch * 32 + e] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
     }
+    if (FAST && k >= 192) identity_test_words(df, k - 192, s_shiftp + 64);
   }
   __syncthreads();
   const int it = blockIdx.x * 256 + threadIdx.x;   // (tile, half): both lanes of a pair are in or out
   if (pair_tile(it) >= g.cols) return;
-  transform_store_pair<0>(g, g.cols, ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)v * g.row_block,
-                          ws.low + (size_t)f * ws.plane_stride, s_unmap, &s_shift[0][0], &s_shiftp[0][0],
+  transform_store_pair<(FAST ? -1 : 0), FAST>(g, g.cols, ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)v * g.row_block,
+                          ws.low + (size_t)f * ws.plane_stride, s_unmap, &s_shift[0][0], s_shiftp,
                           df->ycbcr, pair_tile(it), pair_half(it), v,
                           out_frames + (size_t)f * ((size_t)g.W * g.H * g.C));
 }
 
-// COLS != 0 fixes the tile count per block row at compile time (512 = 4096-pixel
-// rows): the 64 symbol slots of a tile are then at immediate LDS offsets instead
+// COLS > 0 fixes the tile count per block row at compile time (512 = 4096-pixel
+// rows; COLS < 0: any width of four-channel whole tiles, run-time count, the same transform paths): the 64 symbol slots of a tile are then at immediate LDS offsets instead
 // of 64 live address registers, which is what keeps the transform phase from
 // spilling.
 // A workgroup takes `rpw` consecutive block rows: narrow rows leave most of the 1024
@@ -2543,28 +2572,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
     s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
   } else if (tid < 512) {
-    // tile_plane's identity test (one wavefront).  n = the largest code with
-    // fmap[i] == i for all i <= n (mapper.h:33-35: a code unmaps to itself there);
-    // B = the largest power of two <= n, lowered until B << (largest shift of group H:
-    // rows 2..7 of columns 1..7) <= 2048 (inside both range conditions of the packed
-    // transform, packed_wht_exact).  Words: (B, B), then the mask of the bits
-    // that a sum code + B outside [0, 2B) sets.  No usable range: the test always fails.
-    const int l = tid - 448;
-    const unsigned long long ne = __ballot(df->fmap[l] != l), ne2 = __ballot(df->fmap[64 + l] != 64 + l);
-    const int n = ne ? __ffsll((long long)ne) - 2 : (ne2 ? 62 + __ffsll((long long)ne2) : 127);
-    if (l < 2) {
-      int smax = 0;
-      for (int y = 2; y < 8; ++y)
-        for (int x = 1; x < 8; ++x) smax = max(smax, (int)df->shift[l][y * 8 + x]);
-      int B = 0;
-      if (n >= 1) {
-        B = 1 << (31 - __clz(n));
-        while (B && ((long long)B << smax) > 2048) B >>= 1;
-      }
-      const uint32_t b16 = B ? (uint32_t)B : 0x4000u, m16 = B ? (uint32_t)(0xffffu & ~(2u * B - 1u)) : 0xffffu;
-      s_shiftp[64 + 2 * l] = b16 | (b16 << 16);
-      s_shiftp[64 + 2 * l + 1] = m16 | (m16 << 16);
-    }
+    identity_test_words(df, tid - 448, s_shiftp + 64);
   }
   const GrpTables tb = tables_of(&T);
   const int rb = r0 + (int)blockIdx.x * rpw;
@@ -2615,7 +2623,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 
   const long long c_p2 = clock64();
   const int ycbcr = df->ycbcr;
-  const int cols = COLS ? COLS : g.cols;
+  const int cols = COLS > 0 ? COLS : g.cols;
   // ---- phase 2: inverse transform, colour inverse and stores ----
   // Two adjacent lanes share a tile (transform_store_pair).  The decoded symbols
   // stay read-only in LDS: no barrier, no second pass over them.
@@ -2625,7 +2633,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   for (int it = tid; it < per_row * nr; it += kDecThreads) {
     const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
     if (pair_tile(il) < cols)
-      transform_store_pair<COLS, COLS == 512>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
+      transform_store_pair<COLS, COLS != 0>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
                                               pair_tile(il), pair_half(il), rb + i, img,
                                               COLS == 512 ? pre_lr : nullptr);
   }
@@ -3108,7 +3116,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       else row_count(stream, a, b);
       if (b <= a) continue;
       prof_begin(prof, "k_dec_row_fused", stream);
-      if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) HIMG_FUSED_LAUNCH(512, a, b);   // whole tiles only (FULL4)
+      const bool whole4 = g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0;   // FULL4
+      if (g.W == 4096 && whole4) HIMG_FUSED_LAUNCH(512, a, b);
+      else if (whole4) HIMG_FUSED_LAUNCH(-1, a, b);
       else HIMG_FUSED_LAUNCH(0, a, b);
       prof_end(prof, stream);
     }
@@ -3149,7 +3159,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       }
       HIMG_LAUNCH(k_dec_huff, dim3(b - a, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
                   d_sizes, 1 + a, 1, 2);
-      HIMG_LAUNCH(k_tile_inv, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
+      if (g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0) HIMG_LAUNCH(k_tile_inv<true>, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
+      else HIMG_LAUNCH(k_tile_inv<false>, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
     }
   }
   HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);

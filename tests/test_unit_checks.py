@@ -17,13 +17,19 @@ def tile_plane_check():
 # mode 1: every coefficient at or one beyond the largest magnitude the packed path's
 # range conditions allow (packed_wht_exact), with the sign patterns that maximise the
 # butterfly sums.
+# variant: 0 the generic gather, -1 the identity-range gather (codes of rows 2..7 x columns
+# 1..7 taken as they are when a wavefront's all lie in the identity range of the companding
+# table: amplitude 1 makes the table the identity, so planes of small codes take it and
+# planes with larger ones fall back) with the run-time tile count, 64 the same with the
+# count at compile time.
 @pytest.mark.gpu
-@pytest.mark.parametrize("amp,zeros,mode", [(1, 60, 0), (2, 90, 0), (4, 60, 0), (16, 30, 0), (300, 60, 0), (1, 0, 1)])
-def test_tile_plane_matches_the_scalar_model(tile_plane_check, amp, zeros, mode):
+@pytest.mark.parametrize("variant", [0, -1, 64])
+@pytest.mark.parametrize("amp,zeros,mode", [(1, 60, 0), (1, 60, 2), (1, 95, 2), (2, 90, 0), (4, 60, 0), (16, 30, 0), (300, 60, 0), (1, 0, 1)])
+def test_tile_plane_matches_the_scalar_model(tile_plane_check, amp, zeros, mode, variant):
     """tile_plane (kernels_dec.hip) == the int32 arithmetic of hadamard.cpp:47-74,
     quantize.cpp:153-165, downsampled.cpp:116-169 and decoder.cpp:401-413 on
     16384 random planes."""
-    r = subprocess.run([tile_plane_check, str(amp), str(zeros), str(mode)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([tile_plane_check, str(amp), str(zeros), str(mode), str(variant)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatching pixels 0" in r.stdout
     assert "lowres_quads mismatches 0" in r.stdout

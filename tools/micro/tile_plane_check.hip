@@ -10,11 +10,15 @@ void prof_begin(Profiler *, const char *, hipStream_t) {}
 void prof_end(Profiler *, hipStream_t) {}
 }
 
+// VARIANT 0: the generic gather (run-time tile count); -1: the identity-range gather with
+// the run-time count; 64: the same with the count at compile time.
+template <int VARIANT>
 __global__ void k_check(const uint8_t *codes, const int16_t *unmap, const uint8_t *shift, const uint32_t *lr,
-                        uint32_t *out, int n) {
+                        uint32_t *out, int n, uint32_t hf0, uint32_t hf1) {
   __shared__ int16_t s_unmap[256];
   __shared__ uint8_t s_shift[64];
   __shared__ uint32_t s_shiftp[32];
+  __shared__ uint32_t s_hfast[2];
   __shared__ uint8_t s_sym[64 * 64];
   const int t = threadIdx.x;
   for (int k = t; k < 256; k += 64) s_unmap[k] = unmap[k];
@@ -27,7 +31,9 @@ __global__ void k_check(const uint8_t *codes, const int16_t *unmap, const uint8_
   __syncthreads();
   uint32_t O[16];
   const int id = blockIdx.x * 64 + t;
-  tile_plane<0>(s_sym + t, 64, s_unmap, s_shift, s_shiftp, lr[2 * id], lr[2 * id + 1], O);
+  if (t == 0) { s_hfast[0] = hf0; s_hfast[1] = hf1; }
+  __syncthreads();
+  tile_plane<VARIANT>(s_sym + t, 64, s_unmap, s_shift, s_shiftp, lr[2 * id], lr[2 * id + 1], O, VARIANT ? s_hfast : nullptr);
   for (int i = 0; i < 16; ++i) out[(size_t)id * 16 + i] = O[i];
 }
 
@@ -61,6 +67,8 @@ int main(int argc, char **argv) {
   for (int k = 0; k < 256; ++k) { int sc = (int8_t)k; unmap[k] = (int16_t)(sc * amp); }
   for (int k = 0; k < 64; ++k) shift[k] = rand() % 5;
   for (auto &c : codes) c = (rand() % 100 < zero_pct) ? 0 : (uint8_t)(rand() & 255);
+  if (mode == 2)   // small codes only (inside the identity range of an identity table): the fast gather is taken
+    for (auto &c : codes) c = (rand() % 100 < zero_pct) ? 0 : (uint8_t)(int8_t)(rand() % 81 - 40);
   if (mode == 1) {
     // The edges of packed_wht_exact: every coefficient at the largest magnitude one of
     // its two conditions allows, or one beyond it -- |d| = 3071 / 3072 / 4095 / 4096
@@ -89,7 +97,23 @@ int main(int argc, char **argv) {
   hipMemcpy(d_shift, shift.data(), 64, hipMemcpyHostToDevice);
   hipMemcpy(d_unmap, unmap.data(), 512, hipMemcpyHostToDevice);
   hipMemcpy(d_lr, lr.data(), lr.size() * 4, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k_check, dim3(blocks), dim3(64), 0, 0, d_codes, d_unmap, d_shift, d_lr, d_out, n);
+  // The identity-test words, by the rule of identity_test_words (kernels_dec.hip).
+  const int variant = argc > 4 ? atoi(argv[4]) : 0;
+  uint32_t hf0, hf1;
+  {
+    int nid = 127;
+    for (int i = 0; i < 128; ++i) if (unmap[i] != i) { nid = i - 1; break; }
+    int smax = 0;
+    for (int y = 2; y < 8; ++y) for (int x = 1; x < 8; ++x) smax = shift[y * 8 + x] > smax ? shift[y * 8 + x] : smax;
+    int B = 0;
+    if (nid >= 1) { B = 1; while (2 * B <= nid) B *= 2; while (B && ((long long)B << smax) > 2048) B >>= 1; }
+    const uint32_t b16 = B ? (uint32_t)B : 0x4000u, m16 = B ? (uint32_t)(0xffffu & ~(2u * B - 1u)) : 0xffffu;
+    hf0 = b16 | (b16 << 16); hf1 = m16 | (m16 << 16);
+    printf("variant %d, identity range %d, B %d\n", variant, nid, B);
+  }
+  if (variant == 0) hipLaunchKernelGGL(k_check<0>, dim3(blocks), dim3(64), 0, 0, d_codes, d_unmap, d_shift, d_lr, d_out, n, hf0, hf1);
+  else if (variant < 0) hipLaunchKernelGGL(k_check<-1>, dim3(blocks), dim3(64), 0, 0, d_codes, d_unmap, d_shift, d_lr, d_out, n, hf0, hf1);
+  else hipLaunchKernelGGL(k_check<64>, dim3(blocks), dim3(64), 0, 0, d_codes, d_unmap, d_shift, d_lr, d_out, n, hf0, hf1);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
   hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost);
   {
