@@ -133,12 +133,24 @@ def main_decode(mode, kind, seed, W, H, q, outfile):
     """Row-sharded decode: rank 0 owns the stream; the assembled pixels (or the
     word REJECTED) go to outfile, what left rank 0 to outfile.stats."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nccl = mode == "dgpu_nccl"   # one GPU per rank, RCCL: collectives and point-to-point on device tensors
+    if nccl:
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     full = ol.oracle_encode(himg_amd.synth(kind, seed, W, H), q, True)
     packed = full if rank == 0 else None
     if mode == "dstub":
         eng = StubDecodeEngine(full)
         ok, pix = sharded.decode_sharded(eng, packed, W, H, 4, device="cpu", comm_device="cpu")
+    elif nccl:
+        eng = himg_amd.Engine(rank)
+        d_packed = torch.from_numpy(full).to(dev) if rank == 0 else None
+        ok, pix = sharded.decode_sharded(eng, d_packed, W, H, 4, device=dev)
+        if ok and rank == 0 and torch.is_tensor(pix):
+            pix = pix.cpu().numpy()
     else:
         eng = himg_amd.Engine(0)
         ok, pix = sharded.decode_sharded(eng, packed, W, H, 4, device="cuda:0", comm_device="cpu")
@@ -156,25 +168,33 @@ def main_decode(mode, kind, seed, W, H, q, outfile):
 def main():
     mode, kind, seed, W, H, q, outfile = sys.argv[1:8]
     seed, W, H, q = int(seed), int(W), int(H), int(q)
-    if mode in ("dstub", "dgpu"):
+    if mode in ("dstub", "dgpu", "dgpu_nccl"):
         return main_decode(mode, kind, seed, W, H, q, outfile)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nccl = mode == "gpu_nccl"   # one GPU per rank, RCCL
+    if nccl:
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     img = himg_amd.synth(kind, seed, W, H)
     rows, cols = (H + 7) // 8, (W + 7) // 8
     if mode == "stub":
         backend = StubBackend(img, q)
     else:
-        eng = himg_amd.Engine(0)
+        eng = himg_amd.Engine(rank if nccl else 0)
         r0, r1 = sharded.shard_rows(rows, world)[rank]
         # This rank only uploads its shard plus the halo (11 pixel rows above, 5 below).
         y0, y1 = max(0, 8 * r0 - 11), min(H, 8 * r1 + 5)
         if r1 <= r0:
             y0, y1 = 0, 1
-        d_shard = torch.from_numpy(np.ascontiguousarray(img[y0:y1])).to("cuda:0")
-        backend = sharded.EngineBackend(eng, d_shard, y0, W, H, q, True, comm_device="cpu")
+        d_shard = torch.from_numpy(np.ascontiguousarray(img[y0:y1])).to("cuda:%d" % (rank if nccl else 0))
+        backend = sharded.EngineBackend(eng, d_shard, y0, W, H, q, True, comm_device=None if nccl else "cpu")
     out = sharded.encode_sharded(backend, rows, cols, 4, rows > 1)
     if rank == 0:
+        if torch.is_tensor(out):
+            out = out.cpu().numpy()
         np.asarray(out, np.uint8).tofile(outfile)
     dist.barrier()
     dist.destroy_process_group()

@@ -268,3 +268,28 @@ def test_sharded_decode_two_processes(tmp_path):
     assert rc == 0 and np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
     _run_ranks(2, ["dgpu", "grad", 0, 512, 512, 50, out])
     assert open(out).read() == "REJECTED"
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()   # (does not initialise the GPU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_rccl_one_gpu_per_rank(tmp_path, world):
+    """The row-sharded encode and decode over RCCL (backend "nccl"), one GPU per rank,
+    device tensors in every collective and point-to-point transfer -- the path
+    `bench.py --gpus N` takes on a multi-GPU node.  Skipped where fewer GPUs are visible
+    (the single-GPU test box: the gloo tests above run the same orchestration there)."""
+    if _gpus() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, _gpus()))
+    out = tmp_path / "out.himg"
+    img = himg_amd.synth("randtile", 3, 1024, 2048)
+    want = ol.oracle_encode(img, 50, True)
+    _run_ranks(world, ["gpu_nccl", "randtile", 3, 1024, 2048, 50, out])
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+    rc, pix = ol.oracle_decode(want)
+    assert rc == 0
+    _run_ranks(world, ["dgpu_nccl", "randtile", 3, 1024, 2048, 50, out])
+    assert np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
