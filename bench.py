@@ -51,7 +51,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="frames per GPU per step (resident in HBM: 128 x 64 MiB of pixels, as much again of symbols "
+                         "and of decoded pixels -- a tenth of the 288 GB; 64 frames: 3 percent slower, 256: 1 percent faster)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (one engine context each) the batch is split over.  Default 1: every "
                          "kernel then has the GPU to itself, so its live duration is its own (the roofline "
@@ -435,8 +437,16 @@ def main():
     # Synthetic frames: rank r gets seeds r*B .. r*B+B-1 modulo 256, the extent of the
     # golden table (seed 0 is SURVEY.md's golden input).
     seeds = [(rank * B + i) % 256 for i in range(B)]
-    frames = np.stack([himg_amd.synth(args.kind, sd, W, H) for sd in seeds])
-    d_frames = torch.from_numpy(frames).to(dev)
+    # (Generated and uploaded frame by frame: the host never holds the batch -- eight ranks
+    # of 128 frames would be 64 GiB of host memory otherwise.  Frame 0 stays for the
+    # oracle check and the CPU baseline.)
+    d_frames = torch.empty((B, H, W, 4), dtype=torch.uint8, device=dev)
+    frames = [None]
+    for i, sd in enumerate(seeds):
+        fr = himg_amd.synth(args.kind, sd, W, H)
+        d_frames[i].copy_(torch.from_numpy(fr))
+        if i == 0:
+            frames[0] = fr
     cap = himg_amd.max_packed_size(W, H, 4)
     d_out = torch.empty((B, cap), dtype=torch.uint8, device=dev)
     d_sizes = torch.zeros(B, dtype=torch.int32, device=dev)

@@ -5,6 +5,7 @@ set -eu
 SRC=$1
 TAG=$2
 grep '^{' "$SRC/bench.json" | tail -1 > "profiles/${TAG}_bench.json"
+grep '^{' "$SRC/bench_b64.json" | tail -1 > "profiles/${TAG}_bench_b64.json"
 cp "$SRC/cfg3_sweep.json" "profiles/${TAG}_cfg3_sweep.json"
 cp "$SRC/cfg4_rows.json" "profiles/${TAG}_cfg4_rows.json"
 cp "$SRC/latency.json" "profiles/${TAG}_latency.json"

@@ -13,13 +13,15 @@ mkdir -p "$ROOT/$OUT"
 (cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 8 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
  python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 8 "$OUT/traffic.json" "$SHA" && cp "$OUT/traffic.json" profiles/traffic.json)
 python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err"
+# The same with 64 frames per launch: the batch DESIGN.md's per-kernel discussion is written for.
+python3 "$ROOT/bench.py" --batch 64 --no-rows --no-extras --no-cpu-baseline > "$ROOT/$OUT/bench_b64.json" 2> "$ROOT/$OUT/bench_b64.err"
 python3 "$ROOT/tools/occupancy_sweep.py" > "$ROOT/$OUT/cfg3_sweep.json" 2> "$ROOT/$OUT/cfg3_sweep.err"
 python3 "$ROOT/tools/rows_profile.py" > "$ROOT/$OUT/cfg4_rows.json" 2> "$ROOT/$OUT/cfg4_rows.err"
 python3 "$ROOT/tools/latency_profile.py" > "$ROOT/$OUT/latency.json" 2> "$ROOT/$OUT/latency.err"
 # Other shapes of the same workload: config 5 (quality sweep), 2048^2 / 1024^2 / 1080p batches.
 : > "$ROOT/$OUT/configs.jsonl"
 for q in 10 30 70 90; do
-  python3 "$ROOT/bench.py" --quality $q --no-rows --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 >> "$ROOT/$OUT/configs.jsonl"
+  python3 "$ROOT/bench.py" --quality $q --batch 64 --no-rows --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 >> "$ROOT/$OUT/configs.jsonl"
 done
 for wh in "2048 2048" "1024 1024" "1920 1080"; do
   set -- $wh
@@ -27,7 +29,7 @@ for wh in "2048 2048" "1024 1024" "1920 1080"; do
 done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_default" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --batch 64 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_streams1" -- \
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 8 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_streams1.log" 2>&1
 cd "$ROOT"
