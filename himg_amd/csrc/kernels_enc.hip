@@ -1452,35 +1452,64 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) { return wave_scan
 // buffered by iteration parity; every thread flushes AND re-zeroes its own words
 // of the circular buffer, and the next ORs only come after the next iteration's
 // barriers, so the flush needs no barrier of its own.
-__global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
-                                              const uint32_t *sizes, int sp0) {
-  __shared__ uint32_t stage[kStageWords];
+//
+// ROWS > 1 (batches): the workgroup's ROWS wavefronts take one span EACH (ROWS
+// consecutive spans), 1024 symbols per iteration, sharing only the tables: what is a
+// barrier above is program order inside one wavefront, nobody waits for a slower
+// wavefront's busiest lane, and a workgroup of eight waves shares one set of tables
+// (46 KiB for eight spans against 8 x 24.5).
+template <int ROWS>
+__global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : 256) void k_emit_t(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
+                                                                       const uint32_t *sizes, int sp0, int sp1) {
+  constexpr int NT = ROWS > 1 ? 64 : 256;          // lanes that work on one span
+  constexpr int NG = ROWS > 1 ? ROWS : 1;          // spans per workgroup
+  constexpr int NWAVE = NT / 64;                   // wavefronts per span
+  // (staging words per span, a power of two: 256 per wavefront send too many iterations to the
+  // window-by-window path -- 3.26 ms per 64 frames against 2.92 --, 1024 cost a workgroup per CU)
+  constexpr int kStage = ROWS > 1 ? 512 : kStageWords;
+  constexpr uint32_t kWindow = (uint32_t)(kStage - 4) * 32u;                // + carry word + 46-bit spill
+  constexpr int kIter = NT * 16;                                            // symbols per iteration
+  __shared__ uint32_t stage_all[NG * kStage];
   __shared__ unsigned long long s_cl[kHistStride];  // code | length << 32
   // Merged token pairs: a zero run of r <= 6 zeros followed by the literal `sym`
   // (the common case by far) costs ONE lookup and ONE put: bits | length << 24,
   // 0 where the pair is longer than 24 bits (then the tokens go one by one).
   __shared__ uint32_t s_pair[kPairRuns + 1][256];   // row kPairRuns: zeros ("not merged")
   __shared__ uint32_t s_run[kRunTab + 1];   // run token of r zeros: bits | length << 24 (0: not representable; [kRunTab] = 0)
-  __shared__ uint32_t s_priv[(kPrivWords + 1) * 256];   // [word][lane]: the bits a lane assembled this iteration (+ one row that absorbs an overflowing lane's stores)
+  __shared__ uint32_t s_priv_all[NG * (kPrivWords + 1) * NT];   // [word][lane]: the bits a lane assembled this iteration (+ one row that absorbs an overflowing lane's stores)
   __shared__ ZR sm_zr[2][4];
   __shared__ uint32_t sm_u[2][4];
 
-  const int sp = blockIdx.x + sp0, f = blockIdx.y, tid = threadIdx.x;
-  const int lane = lane_id(), wave = wave_id();
+  const int f = blockIdx.y;
+  const int grp = ROWS > 1 ? (int)threadIdx.x / NT : 0;
+  const int tid = ROWS > 1 ? (int)threadIdx.x % NT : (int)threadIdx.x;   // lane index inside the span's group
+  const int sp = (int)blockIdx.x * NG + grp + sp0;
+  const int lane = lane_id(), wave = ROWS > 1 ? 0 : wave_id();
+  uint32_t *stage = stage_all + grp * kStage;
+  uint32_t *s_priv = s_priv_all + grp * (kPrivWords + 1) * NT;
+  // One group's barrier: the workgroup's for a span of four wavefronts, program order
+  // (LDS operations of one wavefront execute in order) for a span of one.
+  auto gsync = [&]() {
+    if (ROWS > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    else __syncthreads();
+  };
   if (sizes[f] == 0) return;  // frame failed (status says why)
-  const Span s = get_span(g, ws, sp, f);
+  const bool live = sp < sp1;
+  const Span s = get_span(g, ws, live ? sp : sp0, f);
   const int nsp = g.lres_spans + g.rows;
-  const unsigned long long B0 = ws.span_bit0[(size_t)f * nsp + sp];
-  const unsigned long long B1 = B0 + ws.span_bits[(size_t)f * nsp + sp];
+  const unsigned long long B0 = ws.span_bit0[(size_t)f * nsp + (live ? sp : sp0)];
+  const unsigned long long B1 = B0 + ws.span_bits[(size_t)f * nsp + (live ? sp : sp0)];
   uint8_t *o8 = out + (size_t)f * out_stride;
   uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
 
+  // The tables (every span of a workgroup belongs to the same stream of the same frame).
+  const int nthreads = NT * NG, t_all = (int)threadIdx.x;
   const size_t tab = ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
-  for (int k = tid; k < kHistStride; k += 256)
+  for (int k = t_all; k < kHistStride; k += nthreads)
     s_cl[k] = (unsigned long long)(uint32_t)ws.codes[tab + k] | ((unsigned long long)ws.lens[tab + k] << 32);
-  for (int k = tid; k < kStageWords; k += 256) stage[k] = 0;
+  for (int k = t_all; k < NG * kStage; k += nthreads) stage_all[k] = 0;
   __syncthreads();
-  for (int k = tid; k < kPairRuns * 256; k += 256) {
+  for (int k = t_all; k < kPairRuns * 256; k += nthreads) {
     const int r = k >> 8, sym = k & 255;
     // run token of r zeros (huffman_enc.cpp:111-141): none, literal 0, 256, or 257 + (r - 3)
     const int rs = r == 1 ? 0 : r == 2 ? 256 : 257;
@@ -1491,9 +1520,9 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     const int n = lr + eb + ls;
     s_pair[r][sym] = (sym != 0 && ls > 0 && (r == 0 || lr > 0) && n <= 24) ? ((uint32_t)bits | ((uint32_t)n << 24)) : 0u;
   }
-  s_pair[kPairRuns][tid] = 0;
-  if (tid == 0) s_run[kRunTab] = 0;
-  for (int r = tid; r < kRunTab; r += 256) {
+  for (int k = t_all; k < 256; k += nthreads) s_pair[kPairRuns][k] = 0;
+  if (t_all == 0) s_run[kRunTab] = 0;
+  for (int r = t_all; r < kRunTab; r += nthreads) {
     const int rs = r == 1 ? 0 : r == 2 ? 256 : r <= 6 ? 257 : r <= 22 ? 258 : 259;
     const int eb = r <= 2 ? 0 : r <= 6 ? 2 : r <= 22 ? 4 : 8;
     const int ev = r <= 2 ? 0 : r <= 6 ? r - 3 : r <= 22 ? r - 7 : r - 23;
@@ -1502,13 +1531,14 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     s_run[r] = (r > 0 && len > 0 && len + eb <= 24)
                    ? ((uint32_t)cl | ((uint32_t)ev << len) | ((uint32_t)(len + eb) << 24)) : 0u;
   }
-  int run_carry = span_carry_in(g, ws, sp, f);  // zeros pending in front of this iteration
+  int run_carry = live ? span_carry_in(g, ws, sp, f) : 0;  // zeros pending in front of this iteration
   // Positions are bits relative to the dword that holds the span's first bit;
-  // word k of the span is global dword gw0 + k and staging slot k % kStageWords.
+  // word k of the span is global dword gw0 + k and staging slot k % kStage.
   const unsigned long long gw0 = B0 >> 5;
   uint32_t sbit = (uint32_t)(B0 & 31);  // position of the next token
   uint32_t fw = 0;                      // words already flushed
   __syncthreads();
+  if (!live) return;   // (ROWS > 1: a wavefront beyond the last span; nothing below is a workgroup barrier then)
 
   auto store_word = [&](unsigned long long gw, uint32_t val) {
     const unsigned long long wb0 = gw * 32ull;
@@ -1528,25 +1558,29 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
   uint32_t w[4], wn[4];
   load16(s.sym + tid * 16, s.len - tid * 16, w);
   int par = 0;
-  for (int base = 0; base < s.len; base += kIterSyms, par ^= 1) {
+  for (int base = 0; base < s.len; base += kIter, par ^= 1) {
     const int off = base + tid * 16;
     const int nvalid = max(0, min(16, s.len - off));
     // Prefetch the next iteration's symbols.
-    if (base + kIterSyms < s.len) load16(s.sym + off + kIterSyms, s.len - off - kIterSyms, wn);
+    if (base + kIter < s.len) load16(s.sym + off + kIter, s.len - off - kIter, wn);
     const uint32_t mask = nonzero_mask16(w, nvalid);
 
     // (A) zero-run state in front of every lane.
     const ZR incl = wave_scan_zr(summarize16(mask, nvalid));
-    if (lane == 63) sm_zr[par][wave] = incl;
     const ZR ex = zr_unpack(wave_prev(kZrIdentity, zr_pack(incl)));
-    __syncthreads();
     ZR pre, tot;
     pre.tz = run_carry; pre.az = 0;
-    tot = pre;
+    if (NWAVE > 1) {
+      if (lane == 63) sm_zr[par][wave] = incl;
+      __syncthreads();
+      tot = pre;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < wave) pre = zr_combine(pre, sm_zr[par][k]);
-      tot = zr_combine(tot, sm_zr[par][k]);
+      for (int k = 0; k < 4; ++k) {
+        if (k < wave) pre = zr_combine(pre, sm_zr[par][k]);
+        tot = zr_combine(tot, sm_zr[par][k]);
+      }
+    } else {
+      tot = zr_combine(pre, zr_unpack((uint32_t)__builtin_amdgcn_readlane((int)zr_pack(incl), 63)));
     }
     const int run_in = zr_combine(pre, ex).tz;
     run_carry = tot.tz;
@@ -1568,7 +1602,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
       auto lput = [&](uint32_t v, int n) {  // n <= 32
         a |= (unsigned long long)v << ab;
         ab += n;
-        s_priv[min(nw, (uint32_t)kPrivWords) * 256 + tid] = (uint32_t)a;
+        s_priv[min(nw, (uint32_t)kPrivWords) * NT + tid] = (uint32_t)a;
         const uint32_t st = ab >> 5;   // 0 or 1
         nw += st;
         a >>= (st << 5);
@@ -1582,45 +1616,52 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
                   });
       mybits = nw * 32u + ab;
       nwords = nw + (ab ? 1u : 0u);
-      s_priv[min(nw, (uint32_t)kPrivWords) * 256 + tid] = (uint32_t)a;   // the bits left of a word that completed
+      s_priv[min(nw, (uint32_t)kPrivWords) * NT + tid] = (uint32_t)a;   // the bits left of a word that completed
       ovf = nwords > (uint32_t)kPrivWords;
     }
     const uint32_t bincl = wave_scan_u32(mybits);
-    if (lane == 63) sm_u[par][wave] = bincl;
-    const int any_ovf = __syncthreads_or(ovf ? 1 : 0);
     uint32_t bpre = 0, iter_bits = 0;
+    int any_ovf;
+    if (NWAVE > 1) {
+      if (lane == 63) sm_u[par][wave] = bincl;
+      any_ovf = __syncthreads_or(ovf ? 1 : 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < wave) bpre += sm_u[par][k];
-      iter_bits += sm_u[par][k];
+      for (int k = 0; k < 4; ++k) {
+        if (k < wave) bpre += sm_u[par][k];
+        iter_bits += sm_u[par][k];
+      }
+    } else {
+      any_ovf = __any(ovf ? 1 : 0);
+      iter_bits = (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
     }
     const uint32_t my_pos = sbit + bpre + bincl - mybits;  // where this lane's first token starts
     const uint32_t iter_end = sbit + iter_bits;
 
-    if (!any_ovf && iter_bits <= kWindowBits) {
+    if (!any_ovf && iter_bits <= kWindow) {
       // Fast path: shift the lane's words to its bit offset and OR them in.
       // One OR per staging word: the part of word j that spills over is OR-ed in
       // together with word j + 1.
       const uint32_t sh = my_pos & 31;
-      uint32_t widx = (my_pos >> 5) & (kStageWords - 1), carry = 0;
+      uint32_t widx = (my_pos >> 5) & (kStage - 1), carry = 0;
       // (Not unrolled: fully unrolled to kPrivWords it is 103 instructions every iteration,
       // whatever the lanes hold -- and a third of the iterations, in the sparse
       // high-frequency rows, have one word per lane at most.)
 #pragma unroll 1
       for (uint32_t j = 0; j < nwords; ++j) {
-        const unsigned long long v = (unsigned long long)s_priv[j * 256 + tid] << sh;
+        const unsigned long long v = (unsigned long long)s_priv[j * NT + tid] << sh;
         atomicOr(&stage[widx], (uint32_t)v | carry);
         carry = (uint32_t)(v >> 32);
-        widx = (widx + 1) & (kStageWords - 1);
+        widx = (widx + 1) & (kStage - 1);
       }
       if (carry) atomicOr(&stage[widx], carry);
-      __syncthreads();   // (C)
+      gsync();   // (C)
       const uint32_t nw = iter_end >> 5;
-      for (uint32_t k = fw + tid; k < nw; k += 256) {
-        const uint32_t slot = k & (kStageWords - 1);
+      for (uint32_t k = fw + tid; k < nw; k += NT) {
+        const uint32_t slot = k & (kStage - 1);
         store_word(gw0 + k, stage[slot]);
         stage[slot] = 0;
       }
+      if (ROWS > 1) gsync();   // (one wavefront: the next iteration's ORs are not behind a barrier of their own)
       fw = nw;
       sbit = iter_end;
       w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
@@ -1631,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
     // window by window.
     uint32_t wlo = sbit;
     for (;;) {
-      const uint32_t whi = iter_end - wlo <= kWindowBits ? iter_end : wlo + kWindowBits;
+      const uint32_t whi = iter_end - wlo <= kWindow ? iter_end : wlo + kWindow;
       const bool whole = wlo == sbit && whi == iter_end;
       uint32_t widx = 0, accb = 0;
       unsigned long long acc = 0;
@@ -1640,13 +1681,13 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
         accb += n;
         if (accb >= 32) {
           atomicOr(&stage[widx], (uint32_t)acc);
-          widx = (widx + 1) & (kStageWords - 1);
+          widx = (widx + 1) & (kStage - 1);
           acc >>= 32;
           accb -= 32;
         }
       };
       if (whole) {
-        widx = (my_pos >> 5) & (kStageWords - 1);
+        widx = (my_pos >> 5) & (kStage - 1);
         accb = my_pos & 31;
         walk16_pairs(w, mask, nvalid, run_in, flush, &s_pair[0][0], s_run,
                      [&](uint32_t pair) { put(pair & 0xffffffu, (int)(pair >> 24)); },
@@ -1663,7 +1704,7 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
           const unsigned long long cl = s_cl[sym];
           const int len = (int)(cl >> 32);
           if (q >= wlo && q < whi) {
-            if (!started) { widx = (q >> 5) & (kStageWords - 1); accb = q & 31; started = true; }
+            if (!started) { widx = (q >> 5) & (kStage - 1); accb = q & 31; started = true; }
             put((uint32_t)cl, len);
             if (eb) put((uint32_t)ev, eb);
           }
@@ -1671,26 +1712,26 @@ __global__ __launch_bounds__(256) void k_emit(Geom g, EncWs ws, uint8_t *out, si
         });
       }
       if (accb && acc) atomicOr(&stage[widx], (uint32_t)acc);
-      __syncthreads();   // (C)
+      gsync();   // (C)
 
       // Flush the words that are complete below whi; each thread re-zeroes what it
       // flushed.  (Bits of a token that spills past whi stay staged.)
       const uint32_t nw = whi >> 5;
-      for (uint32_t k = fw + tid; k < nw; k += 256) {
-        const uint32_t slot = k & (kStageWords - 1);
+      for (uint32_t k = fw + tid; k < nw; k += NT) {
+        const uint32_t slot = k & (kStage - 1);
         store_word(gw0 + k, stage[slot]);
         stage[slot] = 0;
       }
       fw = nw;
       wlo = whi;
-      if (wlo >= iter_end) break;
-      __syncthreads();   // the next window's ORs must not meet this flush
+      if (wlo >= iter_end) { if (ROWS > 1) gsync(); break; }
+      gsync();   // the next window's ORs must not meet this flush
     }
     sbit = iter_end;
     w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
   }
-  __syncthreads();
-  if (tid == 0 && (sbit & 31)) store_word(gw0 + (sbit >> 5), stage[(sbit >> 5) & (kStageWords - 1)]);
+  gsync();
+  if (tid == 0 && (sbit & 31)) store_word(gw0 + (sbit >> 5), stage[(sbit >> 5) & (kStage - 1)]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1855,6 +1896,35 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
 #undef HIMG_PIX
 }
 
+// k_emit over the spans [sp0, sp1) of every frame: LRES spans (they meet at bit positions:
+// one workgroup each), then the FRES rows -- a wavefront each, eight to a workgroup, when
+// there are enough of them to fill the GPU that way (batches); a single frame keeps one
+// workgroup per row (HIMG_EMIT_ROWS=0 / 1 forces either).
+constexpr int kEmitRows = 8;   // (2 / 4 / 6 rows per workgroup: 3.35 / 2.99 / 3.49 ms per 64 frames, 8: 2.92)
+static void launch_emit(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_stride, const uint32_t *d_sizes,
+                        int sp0, int sp1, int batch, hipStream_t stream, Profiler *prof) {
+  static const int rows_env = getenv("HIMG_EMIT_ROWS") ? atoi(getenv("HIMG_EMIT_ROWS")) : -1;
+  const int l1 = sp0 < g.lres_spans ? (sp1 < g.lres_spans ? sp1 : g.lres_spans) : sp0;   // [sp0, l1): LRES spans
+  if (l1 > sp0) {
+    prof_begin(prof, "k_emit", stream);
+    hipLaunchKernelGGL(k_emit_t<1>, dim3(l1 - sp0, batch), dim3(256), lds_pad(), stream, g, ws, d_out, out_stride,
+                       d_sizes, sp0, l1);
+    prof_end(prof, stream);
+  }
+  if (sp1 > l1) {
+    const long long rows = (long long)(sp1 - l1) * batch;
+    const bool by_wave = rows_env >= 0 ? rows_env != 0 : rows >= 8192;
+    prof_begin(prof, "k_emit", stream);
+    if (by_wave)
+      hipLaunchKernelGGL(k_emit_t<kEmitRows>, dim3((sp1 - l1 + kEmitRows - 1) / kEmitRows, batch), dim3(64 * kEmitRows),
+                         lds_pad(), stream, g, ws, d_out, out_stride, d_sizes, l1, sp1);
+    else
+      hipLaunchKernelGGL(k_emit_t<1>, dim3(sp1 - l1, batch), dim3(256), lds_pad(), stream, g, ws, d_out, out_stride,
+                         d_sizes, l1, sp1);
+    prof_end(prof, stream);
+  }
+}
+
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
                    uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,
                    const StaticChunks &sc, const ShiftTables &st, const LresTables &lt,
@@ -1916,7 +1986,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(kTreeThreads), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0);
-  HIMG_LAUNCH_PAD(k_emit, dim3(nsp, batch), b256, g, ws, d_out, out_stride, d_sizes, 0);
+  launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
 }
@@ -1964,8 +2034,7 @@ void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
                        uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof) {
   HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1);
   if (r1 > r0)
-    HIMG_LAUNCH(k_emit, dim3(r1 - r0, 1), dim3(256), g, ws, d_rel, rel_cap, d_rel_size,
-                g.lres_spans + r0);
+    launch_emit(g, ws, d_rel, rel_cap, d_rel_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
 }
 
 void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &sc,
@@ -1986,7 +2055,7 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
   HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, 1), b256, g, ws, 0);
   HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0);
-  HIMG_LAUNCH(k_emit, dim3(g.lres_spans, 1), b256, g, ws, d_out, out_cap, d_size, 0);
+  launch_emit(g, ws, d_out, out_cap, d_size, 0, g.lres_spans, 1, stream, prof);
   HIMG_LAUNCH(k_place_fres, dim3(1024), b256, g, ws, d_rel, rel_bytes, d_out, d_size);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, 1), b256, g, ws, d_out, out_cap, d_size);
 }
