@@ -2810,6 +2810,155 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
 }
 
 // ---------------------------------------------------------------------------
+// k_row_count_w: the same records (every one of the 1024 lanes of a row kernel: its first
+// owned token and the exclusive prefix of the symbol counts), computed by ONE WAVEFRONT
+// per row -- for batches, where there are rows enough to fill the GPU that way.  The
+// wavefront takes the row kernel's lanes 64 at a time (phase j: lanes 64 j .. 64 j + 63,
+// a contiguous 2 KiB of the payload, read in place): speculative lead-in, count, then
+// the chain is made exact among the 64 (a lane starts where its left neighbour ended:
+// one DPP move per round instead of an LDS exchange and two workgroup barriers; a lane
+// whose guess was wrong walks to its re-join point again, 64 bits), and the
+// prefix of the counts is a wave scan on top of the phases before.  Lane 0 of a phase
+// starts where lane 63 of the phase before ended: exact, like the first lane of a chunk.
+// No staging of the payload (staging a phase's 2.3 KiB in LDS per wavefront was measured:
+// no faster -- the kernel is bound by the decode steps themselves), no 1024-lane scans,
+// sixteen rows share one load of the decode tables.
+// ---------------------------------------------------------------------------
+constexpr int kCountRowsW = kDecThreads / 64;   // rows per workgroup (one per wavefront)
+__global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws, const uint8_t *packed,
+                                                               size_t in_stride, const uint32_t *sizes,
+                                                               int r0, int r1) {
+  __shared__ __attribute__((aligned(16))) uint32_t gyx[2 * kTabEntries];
+  __shared__ uint32_t nd[kMaxNodes + 1];
+  __shared__ int s_flag;
+  uint32_t *gy = gyx, *gx = gyx + kTabEntries;
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  DecFrame *df = ws.frames + f;
+  if (tid == 0) {
+    // The row walk ran beside k_dec_parse: its verdict counts if the parse passed.
+    const int w = df->parse_status == 0 ? df->walk_status : 0;
+    if (w && blockIdx.x == 0) atomicMax(&df->status, w);
+    s_flag = df->status | w;
+  }
+  __syncthreads();
+  const int failed = s_flag;
+  if (!failed) {   // load_dec_tables with the count-only step words next to the long-code descriptors
+    const uint32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1);
+    const int nn = df->s[1].num_nodes;
+    for (int k = tid; k < nn; k += kDecThreads) nd[k] = nodes[k];
+    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    const uint2 *gc = reinterpret_cast<const uint2 *>(ws.gyc + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
+      const uint4 q = gg[k];
+      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);   // long-code descriptors
+      reinterpret_cast<uint2 *>(gy)[k] = gc[k];                  // count-only step words
+    }
+    const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
+    for (int k = tid; k < kSubEntries / 2; k += kDecThreads) {
+      const uint4 q = gs[k];
+      reinterpret_cast<uint2 *>(gx + (1 << kLutBits))[k] = make_uint2(q.x, q.z);
+      reinterpret_cast<uint2 *>(gy + (1 << kLutBits))[k] = make_uint2(q.y, q.w);
+    }
+  }
+  __syncthreads();
+  GrpTables tb;
+  tb.grp = nullptr; tb.gx = gx; tb.gy = gy; tb.nd = nd;
+  const int r = r0 + (int)blockIdx.x * kCountRowsW + (tid >> 6);
+  if (r >= r1) return;
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+  if (lane == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
+  const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
+  const unsigned long long rem64 = 8ull * pay_len;
+  uint32_t sb = (uint32_t)((rem64 + kDecThreads - 1) / kDecThreads);
+  sb = (sb + 31u) & ~31u;
+  sb = sb < kMinSubBits ? kMinSubBits : sb;
+  // More than one chunk, or nothing to do: the row kernels do it all (k_row_count's rule).
+  if (failed || sb > (uint32_t)g.max_sub || rem64 == 0 || g.row_block >= (1 << 22)) return;
+  const uint32_t rem = (uint32_t)rem64;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
+  const uint32_t rel_end = rel0 + rem;
+  const uint32_t lead = (uint32_t)g.lead_bits;
+  uint32_t first = rel0;   // where the phase's first lane starts: exact
+  uint32_t base = 0;       // symbols in front of the phase
+  uint32_t rounds = 0;
+  auto phase = [&](auto &rdr, uint32_t shift, int j) {
+    // (positions inside this lambda are relative to `shift` bits in front of rel0's dword)
+    const int v = 64 * j + lane;
+    const SubGrid q = sub_grid(rel0, rem, sb, v);
+    const bool active = q.active;
+    const uint32_t b0 = q.b0 - shift, lim = q.lim - shift, lo0 = rel0 - shift, fst = first - shift;
+    uint32_t start = active ? b0 : rel_end - shift;
+    if (lane == 0 && active) start = fst;
+    // Lead-in (see lean_fixpoint): the first token boundary at or past the nominal
+    // start, found from lead_bits in front of it.
+    bool at_start = false;   // the reader stands at `start`
+    if (lane > 0 && active && lead) {
+      const uint32_t from = start - lo0 > lead ? start - lead : lo0;
+      uint32_t guess, none;
+      lean_count<true>(rdr, tb, from, start, &guess, &none);
+      start = guess;
+      at_start = true;
+    }
+    uint32_t endpos = start, cnt = 0;
+    bool dirty = active;
+    // Re-join (see lean_fixpoint): the walk is cut at T = nominal start + kJoinBits; a lane
+    // whose start moves in a later round walks up to T again, and if it arrives at the
+    // same token boundary everything behind is what it already has.  A round after the
+    // first then costs the wavefront kJoinBits instead of a whole sub-sequence.
+    uint32_t T = (active ? b0 : rel_end - shift) + kJoinBits;
+    if (T > lim || T < b0) T = lim;
+    uint32_t posT = ~0u, cT = 0;
+    for (;;) {
+      if (dirty) {
+        uint32_t p1, c1;
+        lean_count<true>(rdr, tb, start, T, &p1, &c1, at_start);
+        if (p1 == posT) {
+          cnt = c1 + (cnt - cT);
+        } else {
+          uint32_t c2;
+          lean_count<true>(rdr, tb, p1, lim, &endpos, &c2, start < T || at_start);
+          cnt = c1 + c2;
+        }
+        posT = p1;
+        cT = c1;
+        at_start = false;
+      }
+      // The chain: a lane starts where its left neighbour ended.
+      const uint32_t left = __shfl_up(endpos, 1);
+      const uint32_t ns = lane == 0 ? fst : left;
+      dirty = active && ns != start;
+      if (active) start = ns;
+      ++rounds;
+      if (!__any(dirty ? 1 : 0)) break;
+    }
+    // Exclusive prefix of the counts (k_row_count's clamp: see row_count_one).
+    const uint32_t c = min(cnt, 0x3fffffu);
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    l_start[v] = start + shift - rel0;
+    l_off[v] = base + incl - c;
+    if (v == q.last_active) l_off[kDecThreads + 1] = endpos + shift - rel0;
+    base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    // The next phase starts where this one's last lane ended (a phase of inactive lanes: nowhere).
+    first = (uint32_t)__builtin_amdgcn_readlane((int)(active ? endpos + shift : rel_end), 63);
+  };
+#pragma unroll 1
+  for (int j = 0; j < kDecThreads / 64; ++j) phase(rd, 0u, j);
+  if (lane == 0) {
+    l_off[kDecThreads] = base;
+    l_off[kDecThreads + 3] = rounds;
+    l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_row_write_g: write pass of the generic path (rows whose symbols do not fit the
 // LDS: wider than 4224 pixels) straight to the PRE-ZEROED symbol plane in HBM, from
 // k_row_count's lane starts and offsets.  No LDS window, no barrier in the pass: a
@@ -3050,10 +3199,17 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // The FRES counts need the decode tables (parse) and the row index (walk); their
   // stream joins this one again before the FRES row kernels.
   // (ds == nullptr: everything in line.)
+  // Batches: one wavefront per row (k_row_count_w) -- from 8192 rows per call, below that
+  // the 1024-lane kernel keeps the GPU busier (HIMG_COUNT_WAVE=0 / 1 forces either).
+  static const int cw_env = getenv("HIMG_COUNT_WAVE") ? atoi(getenv("HIMG_COUNT_WAVE")) : -1;
+  const bool count_wave = cw_env >= 0 ? cw_env != 0 : all_rows >= 8192;
   auto row_count = [&](hipStream_t s, int a, int b) {
     if (b <= a) return;
     prof_begin(prof, "k_row_count", s);
-    if (wps)
+    if (count_wave)
+      hipLaunchKernelGGL(k_row_count_w, dim3((b - a + kCountRowsW - 1) / kCountRowsW, batch), dim3(kDecThreads), 0, s,
+                         g, ws, d_packed, in_stride, d_sizes, a, b);
+    else if (wps)
       hipLaunchKernelGGL(k_row_count<true>, dim3((b - a + rpc - 1) / rpc, batch), dim3(kDecThreads), 0, s, g, ws,
                          d_packed, in_stride, d_sizes, a, b, rpc);
     else
