@@ -10,8 +10,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 # The PMC passes first: bench.py quotes profiles/traffic.json (HBM bytes per launch, issue
 # fractions) next to its live timings, so the file it reads must be this commit's.
-(cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 8 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
- python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 8 "$OUT/traffic.json" "$SHA" && cp "$OUT/traffic.json" profiles/traffic.json)
+(cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 16 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
+ python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 16 "$OUT/traffic.json" "$SHA" && cp "$OUT/traffic.json" profiles/traffic.json)
 python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err"
 # The same with 64 frames per launch: the batch DESIGN.md's per-kernel discussion is written for.
 python3 "$ROOT/bench.py" --batch 64 --no-rows --no-extras --no-cpu-baseline > "$ROOT/$OUT/bench_b64.json" 2> "$ROOT/$OUT/bench_b64.err"
@@ -31,6 +31,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_default" -- \
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --batch 64 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_streams1" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 8 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_streams1.log" 2>&1
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 16 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_streams1.log" 2>&1
 cd "$ROOT"
 ls "$ROOT/$OUT"
