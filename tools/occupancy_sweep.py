@@ -67,7 +67,8 @@ def main():
     out = {"workload": "256 x 1920x1080 RGBA randtile seeds 0..255 q=50, encode, one MI355X, frames resident in HBM; "
                        "streams of seeds 0, 1, 127, 255 checked against the golden table at every point",
            "lds_pad_note": "HIMG_LDS_PAD bytes of unused dynamic LDS per workgroup of k_pix_fwd (8 KiB static), k_tok_hist "
-                           "(12 KiB) and k_emit (22 KiB): workgroups per CU = min(waves limit, floor(160 KiB / (static + pad)))",
+                           "(18 KiB) and k_emit (46 KiB per 512-thread workgroup of eight rows in a batch like this one; 24.5 KiB per "
+                           "256-thread workgroup otherwise): workgroups per CU = min(waves limit, floor(160 KiB / (static + pad)))",
            "points": []}
     for pad in (0, 8192, 16384, 32768, 49152, 65536, 98304):
         env = dict(os.environ, HIMG_SWEEP_CHILD="1", HIMG_LDS_PAD=str(pad))
