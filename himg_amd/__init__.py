@@ -270,6 +270,8 @@ class Engine:
         """himg_hip_set_option; option names: "fix_t2" (see include/himg_hip.h)."""
         opt = {"fix_t2": 1}[option] if isinstance(option, str) else int(option)
         self._check(lib().himg_hip_set_option(self._ctx, opt, int(value)), "set_option")
+        if opt == 1:
+            self.fix_t2 = bool(value)   # (the row-sharded decoder's host index follows it, sharded.py)
 
     # device-resident API -------------------------------------------------------
     def encode_device(self, d_frames, batch, width, height, pixel_stride, channels, quality,
@@ -414,8 +416,7 @@ class MultiEngine:
         w, h, c = C.c_int(), C.c_int(), C.c_int()
         rc = lib().himg_hip_multi_decode(self._m, packed.ctypes.data, packed.nbytes, C.byref(out), C.byref(w),
                                          C.byref(h), C.byref(c))
-        if rc:
-            raise HimgError(rc, "multi_decode")
+        self._check(rc, "multi_decode")
         n = w.value * h.value * c.value
         a = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), (n,)).copy().reshape(h.value, w.value, c.value)
         lib().himg_hip_free(out)

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -63,15 +64,30 @@ struct Slot {
 struct himg_hip_multi {
   std::vector<Slot> slots;
   Buf low_full, rel_full, out;   // slot 0's device
-  std::string err;
-  bool staged = false;           // HIMG_MULTI_STAGED=1: never write through peer access
+  std::string err;               // the FIRST failure of the current call (guarded by err_mu: the
+  std::mutex err_mu;             // slot threads of one phase usually fail together)
+  bool err_set = false;
+  int fix_t2 = 0;                // HIMG_OPT_FIX_T2 as set on the slots (the host row index needs it too)
+  // Packed rows of a row-sharded encode: packed locally and moved by hipMemcpyPeerAsync
+  // (staged, the default), or stored by every slot's k_emit straight into slot 0's
+  // buffer through peer access (HIMG_MULTI_STAGED=0).  The direct form has not run on
+  // two physical GPUs yet -- the test box has one -- so it is opt-in until
+  // tests/test_multi_device.py::test_two_devices_both_exchange_forms has passed on one
+  // that has.
+  bool staged = true;
 };
 
 namespace {
 
+// Record a failure: the first one of a call wins (every entry point clears the slate).
 int mfail(himg_hip_multi *m, int code, const std::string &msg) {
-  m->err = msg;
+  std::lock_guard<std::mutex> lock(m->err_mu);
+  if (!m->err_set) { m->err = msg; m->err_set = true; }
   return code;
+}
+void mclear(himg_hip_multi *m) {
+  std::lock_guard<std::mutex> lock(m->err_mu);
+  m->err_set = false;
 }
 
 // Run f(slot index) on one host thread per slot; returns the first non-zero result.
@@ -115,7 +131,7 @@ void shard_rows(int rows, int n, std::vector<int> *r0, std::vector<int> *r1) {
 extern "C" int himg_hip_create_multi(const int *devices, int n, himg_hip_multi **out) {
   if (!devices || n < 1 || n > 64 || !out) return HIMG_ERR_ARG;
   himg_hip_multi *m = new himg_hip_multi();
-  if (const char *e = std::getenv("HIMG_MULTI_STAGED")) m->staged = e[0] == '1';
+  if (const char *e = std::getenv("HIMG_MULTI_STAGED")) m->staged = e[0] != '0';
   m->slots.resize(n);
   for (int d = 0; d < n; ++d) {
     Slot &s = m->slots[d];
@@ -175,6 +191,7 @@ extern "C" int himg_hip_multi_set_option(himg_hip_multi *m, int option, int valu
     const int rc = himg_hip_set_option(s.ctx, option, value);
     if (rc) return rc;
   }
+  if (option == HIMG_OPT_FIX_T2) m->fix_t2 = value ? 1 : 0;
   return HIMG_OK;
 }
 
@@ -185,6 +202,7 @@ extern "C" int himg_hip_multi_encode_batch(himg_hip_multi *m, const uint8_t *con
                                            int quality, int use_ycbcr, uint8_t *const *dst,
                                            const size_t *dst_cap, size_t *out_sizes) {
   if (!m || !frames || n < 0 || !dst || !dst_cap || !out_sizes) return HIMG_ERR_ARG;
+  mclear(m);
   const int ns = (int)m->slots.size();
   return for_slots(m, [&](int d) {
     const int f0 = (int)((long long)n * d / ns), f1 = (int)((long long)n * (d + 1) / ns);
@@ -192,7 +210,7 @@ extern "C" int himg_hip_multi_encode_batch(himg_hip_multi *m, const uint8_t *con
     const int rc = himg_hip_encode_batch(m->slots[d].ctx, frames + f0, f1 - f0, width, height, pixel_stride,
                                          num_channels, quality, use_ycbcr, dst + f0, dst_cap + f0,
                                          out_sizes + f0);
-    if (rc) m->err = himg_hip_last_error(m->slots[d].ctx);
+    if (rc) (void)mfail(m, rc, himg_hip_last_error(m->slots[d].ctx));
     return rc;
   });
 }
@@ -203,13 +221,14 @@ extern "C" int himg_hip_multi_decode_batch(himg_hip_multi *m, const uint8_t *con
                                            int *channels) {
   if (!m || !packed || !packed_sizes || n < 0 || !dst || !dst_cap || !widths || !heights || !channels)
     return HIMG_ERR_ARG;
+  mclear(m);
   const int ns = (int)m->slots.size();
   return for_slots(m, [&](int d) {
     const int f0 = (int)((long long)n * d / ns), f1 = (int)((long long)n * (d + 1) / ns);
     if (f1 <= f0) return 0;
     const int rc = himg_hip_decode_batch(m->slots[d].ctx, packed + f0, packed_sizes + f0, f1 - f0, dst + f0,
                                          dst_cap + f0, widths + f0, heights + f0, channels + f0);
-    if (rc) m->err = himg_hip_last_error(m->slots[d].ctx);
+    if (rc) (void)mfail(m, rc, himg_hip_last_error(m->slots[d].ctx));
     return rc;
   });
 }
@@ -220,6 +239,7 @@ extern "C" int himg_hip_multi_encode(himg_hip_multi *m, const uint8_t *data, int
                                      int pixel_stride, int num_channels, int quality, int use_ycbcr,
                                      uint8_t **out, size_t *out_size) {
   if (!m || !data || !out || !out_size || width < 1 || height < 1) return HIMG_ERR_ARG;
+  mclear(m);
   *out = nullptr;
   *out_size = 0;
   const int ns = (int)m->slots.size();
@@ -227,7 +247,7 @@ extern "C" int himg_hip_multi_encode(himg_hip_multi *m, const uint8_t *data, int
   if (ns == 1 || rows < 32) {   // nothing to shard: the single-device path
     const int e = himg_hip_encode(m->slots[0].ctx, data, width, height, pixel_stride, num_channels, quality,
                                   use_ycbcr, out, out_size);
-    if (e) m->err = himg_hip_last_error(m->slots[0].ctx);
+    if (e) (void)mfail(m, e, himg_hip_last_error(m->slots[0].ctx));
     return e;
   }
   std::vector<int> r0, r1;
@@ -339,12 +359,13 @@ extern "C" int himg_hip_multi_encode(himg_hip_multi *m, const uint8_t *data, int
 extern "C" int himg_hip_multi_decode(himg_hip_multi *m, const uint8_t *packed, size_t packed_size,
                                      uint8_t **out, int *width, int *height, int *num_channels) {
   if (!m || !packed || !out || !width || !height || !num_channels) return HIMG_ERR_ARG;
+  mclear(m);
   *out = nullptr;
   // The single-device decoder: small frames, one slot, and every stream that is (or may
   // be) rejected -- it words the verdict like the reference (decoder.cpp:96-135).
   auto single = [&]() {
     const int e = himg_hip_decode(m->slots[0].ctx, packed, packed_size, out, width, height, num_channels);
-    if (e) m->err = himg_hip_last_error(m->slots[0].ctx);
+    if (e) { mclear(m); (void)mfail(m, e, himg_hip_last_error(m->slots[0].ctx)); }
     return e;
   };
   const int ns = (int)m->slots.size();
@@ -355,7 +376,7 @@ extern "C" int himg_hip_multi_decode(himg_hip_multi *m, const uint8_t *packed, s
   // The row index, once, on the host (the stream is in host memory).
   std::vector<uint32_t> index(2 * (size_t)rows);
   uint32_t first = 0;
-  rc = himg_hip_index_host(packed, packed_size, 0, &w, &h, &c, index.data(), rows, &first);
+  rc = himg_hip_index_host(packed, packed_size, m->fix_t2, &w, &h, &c, index.data(), rows, &first);
   if (rc != HIMG_OK) return single();
   std::vector<int> r0, r1;
   shard_rows(rows, ns, &r0, &r1);
@@ -377,6 +398,10 @@ extern "C" int himg_hip_multi_decode(himg_hip_multi *m, const uint8_t *packed, s
     size_t lo = std::max<size_t>((size_t)index[r0[d]] > 16 ? index[r0[d]] - 16 : 0, first) / 16 * 16;
     size_t hi = std::min(((size_t)index[r1[d] - 1] + index[rows + r1[d] - 1] + 16 + 15) / 16 * 16, cap);
     hi = std::min(hi, packed_size);   // the host buffer ends with the stream
+    // The row kernels read whole dwords and a few dwords ahead: what lies behind the
+    // stream (and behind this slot's slice) must not be a previous frame's bytes.
+    MHIP(m, hipMemsetAsync((uint8_t *)s.packed.p + packed_size / 16 * 16, 0, cap + 64 - packed_size / 16 * 16, s.stream));
+    if (hi < packed_size / 16 * 16) MHIP(m, hipMemsetAsync((uint8_t *)s.packed.p + hi, 0, 64, s.stream));
     MHIP(m, hipMemcpyAsync(s.packed.p, packed, std::min(head, packed_size), hipMemcpyHostToDevice, s.stream));
     if (hi > lo)
       MHIP(m, hipMemcpyAsync((uint8_t *)s.packed.p + lo, packed + lo, hi - lo, hipMemcpyHostToDevice, s.stream));

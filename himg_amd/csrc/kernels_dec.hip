@@ -1030,7 +1030,12 @@ __device__ __forceinline__ void lean_step(RD &rd, const GrpTables &t, bool singl
 // token of a group is sure to start before lim (pos + kLutBits <= lim), single
 // tokens for the last few bits -- so that the hot loop carries no `single` test.
 // cont: the reader already stands at pos (a previous call ended there).
-template <bool SOA = false, class RD = GReader>
+// GRP: the lane owns the GROUPS that start in [pos, lim) -- one loop, no single-token
+// tail; the walk ends at the first group boundary at or past lim (up to kLutBits + 14
+// bits behind it).  Any token boundary divides two lanes' ranges correctly as long as
+// the consumer walks from its own start to its right neighbour's start (the row kernels
+// do), so the count kernels need not agree on a canonical one.
+template <bool SOA = false, class RD = GReader, bool GRP = false>
 __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t pos,
                                            uint32_t lim, uint32_t *endpos, uint32_t *count,
                                            bool cont = false) {
@@ -1075,13 +1080,18 @@ __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t 
       pos += adv + n;
       c += ((y >> 10) & 511u) + extra;
     };
-    while ((int)pos <= limk) step();
-    if (tm != TM) step();   // the loop ended between the two steps of a long code
-    while (pos < lim) {
-      uint32_t nbits, cnt, by;
-      lean_step<false, SOA>(rd, t, true, &nbits, &cnt, &by, &bad);
-      pos += nbits;
-      c += cnt;
+    if constexpr (GRP) {
+      while (pos < lim) step();
+      if (tm != TM) step();
+    } else {
+      while ((int)pos <= limk) step();
+      if (tm != TM) step();   // the loop ended between the two steps of a long code
+      while (pos < lim) {
+        uint32_t nbits, cnt, by;
+        lean_step<false, SOA>(rd, t, true, &nbits, &cnt, &by, &bad);
+        pos += nbits;
+        c += cnt;
+      }
     }
   }
   *endpos = pos;
@@ -1438,6 +1448,7 @@ __device__ __forceinline__ SubGrid sub_grid(uint32_t rel0, uint32_t bits, uint32
 // in registers.
 struct PreLane {
   uint32_t start, off, nxt, tot, endrel, valid, rounds;
+  uint32_t nstart;   // the right neighbour's start (~0u: none, the lane walks to the end of the chunk)
 };
 
 // Decode one whole stream with one workgroup, chunk after chunk (each chunk's
@@ -1487,7 +1498,16 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
 
     uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0;
     unsigned long long tot, off;
+    // Where the lane's walk ends.  With k_row_count's records: at its right neighbour's
+    // start -- the count kernels divide the chunk at token boundaries of their own choice
+    // (k_row_count_w: the first GROUP boundary at or past the nominal one), and a lane
+    // owns exactly the tokens in front of its neighbour's first.
+    uint32_t wlim = lim;
     const bool pre = cur == 0 && (pl ? pl->valid != 0 : (pre_off && pre_off[kDecThreads + 2] != 0));
+    if (pre) {
+      const uint32_t ns = pl ? pl->nstart : (tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u);
+      wlim = ns < rel_end - rel0 ? rel0 + ns : rel_end;
+    }
     if (pre && pl) {
       // The same record, loaded by the caller before its first barrier.
       start = rel0 + pl->start;
@@ -1519,18 +1539,18 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     if (FUSED) {
       uint32_t end_bp = ~0u;
       if (inside) {
-        if (!lean_write(rd, tb, start, lim, (uint32_t)opl, lds_out)) sh->err = 1;
+        if (!lean_write(rd, tb, start, wlim, (uint32_t)opl, lds_out)) sh->err = 1;
       } else if (exact) {
-        if (!exact_write(rd, tb, start, lim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
+        if (!exact_write(rd, tb, start, wlim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
       }
       if (end_bp != ~0u) sh->endbit = cur + (end_bp - rel0);
       __syncthreads();
     } else if (GLOBAL) {
-      lean_write_global(rd, tb, sh, start, lim, opl, exact, out_size, cur, rel0, gout, exact ? opl : opl + cnt);
+      lean_write_global(rd, tb, sh, start, wlim, opl, exact, out_size, cur, rel0, gout, exact ? opl : opl + cnt);
       __syncthreads();
     } else {
       const unsigned long long O1 = (O0 + tot < out_size) ? O0 + tot : out_size;
-      lean_write_windows(rd, tb, sh, start, lim, opl, exact, O0, O1, out_size, cur, rel0, win, gout);
+      lean_write_windows(rd, tb, sh, start, wlim, opl, exact, O0, O1, out_size, cur, rel0, win, gout);
     }
     { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
 
@@ -1614,7 +1634,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     if (use_row_count) {
       pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
       pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
-      // use_row_count == 2: rows with a usable fixpoint were written by k_row_write_g.
+      // use_row_count == 2: rows with a usable fixpoint were written by k_row_window.
       if (use_row_count == 2 && pre_off[kDecThreads + 2] != 0) return;
     }
   }
@@ -2534,6 +2554,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     const size_t ri = (size_t)f * g.rows + (size_t)(r0 + (int)blockIdx.x);
     const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + 4);
     pl.start = ps[tid]; pl.off = po[tid]; pl.nxt = po[tid + 1];
+    pl.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
     pl.tot = po[kDecThreads]; pl.endrel = po[kDecThreads + 1]; pl.valid = po[kDecThreads + 2]; pl.rounds = po[kDecThreads + 3];
     pre_off0 = ws.row_off[ri]; pre_len0 = ws.row_len[ri];
     const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + (int)blockIdx.x;
@@ -2825,11 +2846,95 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
 // sixteen rows share one load of the decode tables.
 // ---------------------------------------------------------------------------
 constexpr int kCountRowsW = kDecThreads / 64;   // rows per workgroup (one per wavefront)
+
+// A piece of the payload staged in LDS, read ON DEMAND: a step fetches the 32 stream bits
+// at its position with one ds_read2_b32 and one v_alignbit instead of keeping a 64-bit
+// register window alive (the refill of ReaderT -- ten instructions with a 64-bit shift
+// and a global load -- is executed by the whole wavefront whenever one of its 64 lanes
+// runs low, i.e. on almost every step).  A step consumes at most kLutBits + 14 = 25 bits.
+// Layout: the lanes of a wavefront read at a stride of one sub-sequence (8 dwords for
+// 256 bits) and advance at about the same pace, which in a plain copy is an 8-way bank
+// conflict on every read.  The piece is therefore stored in blocks of 33 dwords -- 32 of
+// the payload, then a COPY of the next block's first dword -- so that dword w sits at
+// w + w / 32 (the lane stride becomes co-prime with the 32 banks) and the pair
+// (w, w + 1) is adjacent for every w.
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));   // two dwords at a dword-aligned address: ds_read2_b32
+struct LdsBits {
+  uint32_t base;   // LDS byte address of the dword that holds bit 0
+  __device__ __forceinline__ uint32_t window(uint32_t pos) const {
+    const uint32_t w = pos >> 5;
+    const uint32_t a = base + ((w + (w >> 5)) << 2);
+    const u32x2 x = *(const __attribute__((address_space(3))) u32x2_a4 *)(uintptr_t)a;
+    return __builtin_amdgcn_alignbit(x.y, x.x, pos);   // (the hardware takes pos[4:0])
+  }
+};
+constexpr uint32_t kStageSubBits = 320;                                    // longest sub-sequence the staged form takes
+constexpr uint32_t kStageWords = 64u * kStageSubBits / 32u + 32u;          // payload dwords of one phase: 64 sub-sequences + slack
+constexpr uint32_t kStageAlloc = (kStageWords + kStageWords / 32u + 3u) & ~3u;  // the same in blocks of 33
+static_assert(kStageWords % 32 == 0, "whole blocks");
+
+// 64 stream bits in a register pair, for walk_token (no refill: one token at most).
+struct BitWin64 {
+  unsigned long long win;
+  __device__ __forceinline__ void consume(int n) { win >>= n; }
+  __device__ __forceinline__ void refill() {}
+};
+
+// The GROUPS that start in [pos, lim), from the staged payload (lean_count<.., GRP = true>
+// over an LdsBits): where the last one ends, how many symbols they produce.
+__device__ __forceinline__ void grp_count_lds(const LdsBits &bits, const GrpTables &t, uint32_t pos, uint32_t lim,
+                                              uint32_t *endpos, uint32_t *count) {
+  uint32_t c = 0;
+  if (pos < lim) {
+    bool bad = false;
+    const uint32_t TM = ((1u << kLutBits) - 1u) << 2;
+    const uint32_t TB = lds_addr(t.gy);
+    const uint32_t XOFF = (uint32_t)kTabEntries * 4u;   // from a step word to its .x
+    uint32_t tm = TM, tb = TB;   // which table the next step indexes (lean_count: long codes take two steps)
+    auto step = [&]() {
+      uint32_t win = bits.window(pos);
+      const uint32_t a = ((win << 2) & tm) + tb;
+      uint32_t y = lds_ld32(a);
+      uint32_t ntm = TM, ntb = TB;
+      if (__builtin_expect(y == 0, 0)) {
+        const uint32_t x = lds_ld32(a + XOFF);
+        if ((x >> 31) && tm == TM) {
+          ntm = ((1u << (x & 255u)) - 1u) << 2;
+          ntb = TB + (((1u << kLutBits) + ((x >> 8) & 0xffffu)) << 2);
+          y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
+        } else {
+          // Neither table resolves it: the tree walk, over a register window at pos.
+          BitWin64 rd;   // 64 bits: the deepest code the walk follows is 32
+          rd.win = (unsigned long long)win | ((unsigned long long)bits.window(pos + 32u) << 32);
+          const int base = tm == TM ? 0 : kLutBits;
+          uint32_t len, by;
+          y = walk_token(rd, t, x, base, &len, &by, &bad);
+          pos += len - (uint32_t)base;
+          win = bits.window(pos);
+        }
+      }
+      tm = ntm; tb = ntb;
+      const uint32_t extra = __builtin_amdgcn_ubfe(win, y, y >> 5);
+      pos += y >> 27;
+      c += ((y >> 10) & 511u) + extra;
+    };
+    while (pos < lim) step();
+    if (tm != TM) step();   // the loop ended between the two steps of a long code
+  }
+  *endpos = pos;
+  *count = c;
+}
+
+// Rows whose sub-sequences are at most kStageSubBits bits long (4096-pixel rows up to
+// ~2.4 bits per symbol): every phase's piece of the payload goes to LDS first -- coalesced
+// 16-byte loads -- and the walks read it on demand (grp_count_lds); longer rows are read in
+// place through register windows (wave-uniform choice per row).
 __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws, const uint8_t *packed,
                                                                size_t in_stride, const uint32_t *sizes,
                                                                int r0, int r1) {
   __shared__ __attribute__((aligned(16))) uint32_t gyx[2 * kTabEntries];
   __shared__ uint32_t nd[kMaxNodes + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kCountRowsW * kStageAlloc];
   __shared__ int s_flag;
   uint32_t *gy = gyx, *gx = gyx + kTabEntries;
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -2884,21 +2989,61 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   uint32_t first = rel0;   // where the phase's first lane starts: exact
   uint32_t base = 0;       // symbols in front of the phase
   uint32_t rounds = 0;
-  auto phase = [&](auto &rdr, uint32_t shift, int j) {
-    // (positions inside this lambda are relative to `shift` bits in front of rel0's dword)
+  uint32_t *stage = s_stage + (tid >> 6) * kStageAlloc;
+  LdsBits bits;
+  bits.base = lds_addr(stage);
+  auto phases = [&](auto staged_c) {
+  constexpr bool STAGED = decltype(staged_c)::value;
+#pragma unroll 1
+  for (int j = 0; j < kDecThreads / 64; ++j) {
     const int v = 64 * j + lane;
     const SubGrid q = sub_grid(rel0, rem, sb, v);
     const bool active = q.active;
+    const uint32_t pb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.b0);   // the phase's first lane: its nominal start
+    if (pb0 >= rel_end) {   // a phase beyond the payload: its lanes own nothing
+      l_start[v] = rem;
+      l_off[v] = base;
+      continue;
+    }
+    // STAGED: positions below are relative to the dword `w0` of the reader's window, the
+    // first one staged: the one that holds the first bit of the phase's first lane.
+    uint32_t shift = 0;
+    if constexpr (STAGED) {
+      const uint32_t w0 = pb0 >> 5;
+      shift = 32u * w0;
+      wave_lds_sync();   // the walks of the phase before are done with the buffer
+      for (uint32_t k = (uint32_t)lane; 4u * k < kStageWords; k += 64u) {
+        const uint32_t w = w0 + 4u * k;
+        uint4 x;
+        if (w + 3u <= rd.jmax) {
+          const PackedU4 u = *reinterpret_cast<const PackedU4 *>(rd.w + w);
+          x.x = u.x; x.y = u.y; x.z = u.z; x.w = u.w;
+        } else {
+          x.x = rd.ld(w); x.y = rd.ld(w + 1u); x.z = rd.ld(w + 2u); x.w = rd.ld(w + 3u);
+        }
+        // Blocks of 33 (see LdsBits): four dwords of one block, and the block's first dword
+        // once more behind the block before it.
+        uint32_t *d = stage + 4u * k + (k >> 3);
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        if ((k & 7u) == 0u && k) d[-1] = x.x;
+      }
+      wave_lds_sync();
+    }
+    auto walk = [&](uint32_t from, uint32_t to, uint32_t *e, uint32_t *c, bool cont) {
+      if constexpr (STAGED) { (void)cont; grp_count_lds(bits, tb, from, to, e, c); }
+      else lean_count<true, GReader, true>(rd, tb, from, to, e, c, cont);
+    };
     const uint32_t b0 = q.b0 - shift, lim = q.lim - shift, lo0 = rel0 - shift, fst = first - shift;
     uint32_t start = active ? b0 : rel_end - shift;
     if (lane == 0 && active) start = fst;
-    // Lead-in (see lean_fixpoint): the first token boundary at or past the nominal
+    // Lead-in (see lean_fixpoint): a boundary of the token chain at or past the nominal
     // start, found from lead_bits in front of it.
     bool at_start = false;   // the reader stands at `start`
     if (lane > 0 && active && lead) {
-      const uint32_t from = start - lo0 > lead ? start - lead : lo0;
+      uint32_t from = start - lo0 > lead ? start - lead : lo0;
+      if (from < pb0 - shift) from = pb0 - shift;   // (a lead-in longer than a sub-sequence: not in front of the phase)
       uint32_t guess, none;
-      lean_count<true>(rdr, tb, from, start, &guess, &none);
+      walk(from, start, &guess, &none, false);
       start = guess;
       at_start = true;
     }
@@ -2906,20 +3051,20 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     bool dirty = active;
     // Re-join (see lean_fixpoint): the walk is cut at T = nominal start + kJoinBits; a lane
     // whose start moves in a later round walks up to T again, and if it arrives at the
-    // same token boundary everything behind is what it already has.  A round after the
-    // first then costs the wavefront kJoinBits instead of a whole sub-sequence.
+    // same boundary everything behind is what it already has.  A round after the first
+    // then costs the wavefront kJoinBits instead of a whole sub-sequence.
     uint32_t T = (active ? b0 : rel_end - shift) + kJoinBits;
     if (T > lim || T < b0) T = lim;
     uint32_t posT = ~0u, cT = 0;
     for (;;) {
       if (dirty) {
         uint32_t p1, c1;
-        lean_count<true>(rdr, tb, start, T, &p1, &c1, at_start);
+        walk(start, T, &p1, &c1, at_start);
         if (p1 == posT) {
           cnt = c1 + (cnt - cT);
         } else {
           uint32_t c2;
-          lean_count<true>(rdr, tb, p1, lim, &endpos, &c2, start < T || at_start);
+          walk(p1, lim, &endpos, &c2, start < T || at_start);
           cnt = c1 + c2;
         }
         posT = p1;
@@ -2948,62 +3093,14 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     // The next phase starts where this one's last lane ended (a phase of inactive lanes: nowhere).
     first = (uint32_t)__builtin_amdgcn_readlane((int)(active ? endpos + shift : rel_end), 63);
+  }
   };
-#pragma unroll 1
-  for (int j = 0; j < kDecThreads / 64; ++j) phase(rd, 0u, j);
+  if (sb <= kStageSubBits) phases(std::true_type{});
+  else phases(std::false_type{});
   if (lane == 0) {
     l_off[kDecThreads] = base;
     l_off[kDecThreads + 3] = rounds;
     l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_row_write_g: write pass of the generic path (rows whose symbols do not fit the
-// LDS: wider than 4224 pixels) straight to the PRE-ZEROED symbol plane in HBM, from
-// k_row_count's lane starts and offsets.  No LDS window, no barrier in the pass: a
-// lane stores the non-zero literal bytes of its groups, zeros are the fill.  (The
-// window path, k_dec_huff, took 4x as long per row: sixteen 32 KiB windows with
-// three barriers each for a 16384-pixel row.)  Rows k_row_count left alone (several
-// chunks) are skipped here and taken by k_dec_huff.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, const uint8_t *packed,
-                                                             size_t in_stride, const uint32_t *sizes, int r0) {
-  __shared__ LdsTables T;
-  __shared__ StreamShared sh;
-  const int r = r0 + (int)blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-  DecFrame *df = ws.frames + f;
-  const uint32_t *pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-  const uint32_t *pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
-  if (tid == 0) { sh.flag = (df->status || pre_off[kDecThreads + 2] == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
-  __syncthreads();
-  if (sh.flag) return;   // frame failed, or the row is k_dec_huff's
-  load_dec_tables(ws, df, f, 1, &T);
-  const GrpTables tb = tables_of(&T);
-  const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
-  const uint32_t out_size = (uint32_t)g.row_block;
-  const unsigned long long P1 = 8ull * pay_len;
-  uint32_t sb = (uint32_t)((P1 + kDecThreads - 1) / kDecThreads);
-  sb = (sb + 31u) & ~31u;
-  sb = sb < kMinSubBits ? kMinSubBits : sb;
-  GReader rd;
-  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off);
-  const uint32_t lim = sub_grid(rel0, (uint32_t)P1, sb, tid).lim;
-  const uint32_t start = rel0 + pre_start[tid];
-  const uint32_t off = pre_off[tid], cnt = pre_off[tid + 1] - off;   // [kDecThreads] holds the total
-  const uint32_t tot = pre_off[kDecThreads];
-  const bool exact = !(off + cnt < out_size) && off < out_size;
-  __syncthreads();
-  lean_write_global(rd, tb, &sh, start, lim, off, exact, out_size, 0ull, rel0,
-                    ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block,
-                    exact ? off : off + cnt);
-  __syncthreads();
-  if (tid == 0) {   // accept / reject like UncompressStream (huffman_dec.cpp:361-417)
-    int bad = sh.err;
-    if (tot < out_size) bad = 1;   // ran out of payload before the block was full
-    const unsigned long long E = sh.endbit;
-    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
-    if (bad) atomicMax(&df->status, fmt_err(7, 1));
   }
 }
 
@@ -3014,9 +3111,9 @@ __global__ __launch_bounds__(kDecThreads) void k_row_write_g(Geom g, DecWs ws, c
 // sub-sequence if its symbols touch the window -- about a quarter of the lanes of a
 // 16384-pixel row, the two at the edges for both neighbours --, OR-ing the literals
 // into the zeroed window in LDS exactly like the fused row kernel; the window then
-// leaves as 16-byte stores.  (k_row_write_g stores every group straight to HBM: 64
-// different cache lines per wave instruction, 3.5 ms for a 16384 x 16384 frame against
-// 1.0 ms for the same walk without the stores, plus 0.4 ms to clear the plane first.)
+// leaves as 16-byte stores.  (Storing every group straight to a pre-zeroed plane in HBM
+// -- 64 different cache lines per wave instruction -- was 3.5 ms for a 16384 x 16384 frame
+// against 1.0 ms for the same walk without the stores, plus 0.4 ms to clear the plane.)
 // Rows without a usable fixpoint from k_row_count are k_dec_huff's, as before.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRowWindow = 128u * 1024u;
@@ -3033,6 +3130,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
   const uint32_t *pre_start = ws.lane_start + ri * kDecThreads, *pre_off = ws.lane_off + ri * (kDecThreads + 4);
   // Everything from global memory in front of the first barrier.
   const uint32_t st_rel = pre_start[tid], off = pre_off[tid], nxt = pre_off[tid + 1];
+  const uint32_t nst_rel = tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u;   // the lane walks to its neighbour's start
   const uint32_t tot = pre_off[kDecThreads], usable = pre_off[kDecThreads + 2];
   const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
   if (tid == 0) { sh.flag = (df->status || usable == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
@@ -3049,12 +3147,9 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
   if (sh.flag) return;   // frame failed, or the row is k_dec_huff's
   const GrpTables tb = tables_of(&T);
   const unsigned long long P1 = 8ull * pay_len;
-  uint32_t sb = (uint32_t)((P1 + kDecThreads - 1) / kDecThreads);
-  sb = (sb + 31u) & ~31u;
-  sb = sb < kMinSubBits ? kMinSubBits : sb;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, ssize, 8ull * pay_off);
-  const uint32_t lim = sub_grid(rel0, (uint32_t)P1, sb, tid).lim;
+  const uint32_t lim = nst_rel < (uint32_t)P1 ? rel0 + nst_rel : rel0 + (uint32_t)P1;
   const uint32_t cnt = nxt - off;
   // The lane's symbols [off, off + cnt) against the window; positions are handed to the
   // write loops relative to the window's guard (they wrap below zero in front of it:
@@ -3280,18 +3375,10 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     }
 #undef HIMG_FUSED_LAUNCH
   } else {
-    // Symbols through HBM: the write pass stores the non-zero literals into the zeroed
-    // plane.  The clear (1 GiB for a 16384 x 16384 frame) and the predictor inverse go
-    // in FRONT of the join: the side stream is still walking the row headers and
-    // counting (a serial 1.1 ms walk at that size), this stream has nothing else to do.
-    static const int use_window = getenv("HIMG_ROW_WINDOW") ? atoi(getenv("HIMG_ROW_WINDOW")) : 1;
-    const bool window = use_window != 0 && (g.row_block % 16) == 0;
-    if (nrows > 0 && !window) {
-      prof_begin(prof, "memset", stream);
-      (void)hipMemset2DAsync(ws.fres_sym + (size_t)r0 * g.row_block, ws.fres_stride, 0,
-                             (size_t)nrows * g.row_block, (size_t)batch, stream);
-      prof_end(prof, stream);
-    }
+    // Symbols through HBM: every 128 KiB window of a row's symbols is assembled in LDS
+    // (k_row_window) and stored whole; rows whose block is not a multiple of 16 bytes
+    // (ragged widths of 1-3 channel frames) take k_dec_huff's 32 KiB windows.
+    const bool window = (g.row_block % 16) == 0;
     HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
                 dim3(64 * kUnpredWaves), g, ws);
     for (int k = 0; k < nseg; ++k) {
@@ -3310,11 +3397,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
         hipLaunchKernelGGL(k_row_window, dim3(nwin, b - a, batch), dim3(kDecThreads), lds, stream, g, ws, d_packed,
                            in_stride, d_sizes, a);
         prof_end(prof, stream);
-      } else {
-        HIMG_LAUNCH(k_row_write_g, dim3(b - a, batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes, a);
       }
       HIMG_LAUNCH(k_dec_huff, dim3(b - a, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, 1 + a, 1, 2);
+                  d_sizes, 1 + a, 1, window ? 2 : 1);
       if (g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0) HIMG_LAUNCH(k_tile_inv<true>, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
       else HIMG_LAUNCH(k_tile_inv<false>, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
     }

@@ -1320,9 +1320,11 @@ __device__ __forceinline__ int extra_bits_of(int sym) {
 // fres_rel != 0: lay out the FRES rows only, relative to the first row header
 // (no LRES, no container, no tree) -- every rank of a row-sharded encode runs
 // this identically and emits its rows at the same relative offsets.
+// [hr0, hr1): the rows whose size headers this call stores (a rank's own rows when `out`
+// is shared with other ranks / devices: nobody else's bytes are touched).
 __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc, uint8_t *out,
                                                size_t out_stride, uint32_t *sizes,
-                                               const uint32_t *row_bits_in, int fres_rel) {
+                                               const uint32_t *row_bits_in, int fres_rel, int hr0, int hr1) {
   __shared__ uint32_t sm[4];
   __shared__ uint32_t cost[2][kHistStride];
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -1379,7 +1381,7 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
       const unsigned long long p = pos + ex + hdr;  // first payload byte
       bit0[g.lres_spans + r] = 8ull * p;
       nbits[g.lres_spans + r] = b;
-      if (p + nbytes <= out_stride) {
+      if (p + nbytes <= out_stride && r >= hr0 && r < hr1) {
         if (hdr == 2) {
           o[p - 2] = (uint8_t)(nbytes & 255); o[p - 1] = (uint8_t)(nbytes >> 8);
         } else if (hdr == 4) {
@@ -1985,7 +1987,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(kTreeThreads), ws, 0);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
-              (const uint32_t *)nullptr, 0);
+              (const uint32_t *)nullptr, 0, 0, g.rows);
   launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
@@ -2032,7 +2034,7 @@ void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint3
 void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
                        const uint32_t *d_all_row_bits, uint8_t *d_rel, size_t rel_cap,
                        uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof) {
-  HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1);
+  HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1, r0, r1);
   if (r1 > r0)
     launch_emit(g, ws, d_rel, rel_cap, d_rel_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
 }
@@ -2054,7 +2056,7 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, 1), b256, g, ws);
   HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, 1), b256, g, ws, 0);
   HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 0);
-  HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0);
+  HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0, 0, 0);
   launch_emit(g, ws, d_out, out_cap, d_size, 0, g.lres_spans, 1, stream, prof);
   HIMG_LAUNCH(k_place_fres, dim3(1024), b256, g, ws, d_rel, rel_bytes, d_out, d_size);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, 1), b256, g, ws, d_out, out_cap, d_size);

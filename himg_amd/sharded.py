@@ -300,7 +300,7 @@ class ShardedDecoder:
         self.d_status = torch.zeros(2, dtype=torch.int32, device=dev)
         self.d_index = torch.zeros(2 * self.rows + 2, dtype=torch.int32, device=dev)   # offsets, lengths, first
         self.meta = torch.zeros(4 + 2 * self.rows, dtype=torch.int64, device=self.comm)
-        self.d_packed = None      # grown on demand, never zeroed: only the two ranges are read
+        self.d_packed = None      # grown on demand; the bytes behind the stream are zeroed per decode (_buffer)
         self.bytes_from_rank0 = 0
 
     def _s(self):
@@ -311,10 +311,15 @@ class ShardedDecoder:
         return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
 
     def _buffer(self, size):
+        """The stream buffer of this rank, with [size, size rounded up to 16, + 64) zeroed:
+        the row kernels read whole dwords and a few dwords ahead, rank 0 sends slices
+        rounded up past the end of the stream, and neither may see a previous frame's
+        bytes (a damaged last row must get the same verdict whatever was decoded before)."""
         import torch
         cap = (int(size) + 15) // 16 * 16 + 64
         if self.d_packed is None or self.d_packed.numel() < cap:
             self.d_packed = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        self.d_packed[int(size):cap].zero_()
         return self.d_packed
 
     def _index_rank0(self, packed):
@@ -469,11 +474,13 @@ def decode_sharded(engine, packed, width, height, channels=4, group=None, gather
     `engine` provides decode_index_device / decode_rows_indexed_device
     (himg_amd.Engine); `comm_device` is where the process group can move tensors
     (CUDA for nccl/RCCL, "cpu" for gloo)."""
-    key = (width, height, channels, id(group), str(device), str(comm_device), stream)
+    fix_t2 = bool(getattr(engine, "fix_t2", False))   # the engine's HIMG_OPT_FIX_T2: rank 0's host index follows it
+    key = (width, height, channels, id(group), str(device), str(comm_device), stream, fix_t2)
     cache = getattr(engine, "_sharded_decoders", None)
     if cache is None:
         cache = engine._sharded_decoders = {}
     dec = cache.get(key)
     if dec is None:
-        dec = cache[key] = ShardedDecoder(engine, width, height, channels, group, device, comm_device, stream)
+        dec = cache[key] = ShardedDecoder(engine, width, height, channels, group, device, comm_device, stream,
+                                          fix_t2=fix_t2)
     return dec.decode(packed, gather)

@@ -25,8 +25,14 @@ def kname(full):
             return n[:i]
     return n
 
-# Kernels that read their input as 16-byte-per-lane coalesced streams.
-STREAMING = {"k_lowres_avg", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_m", "k_lres_summary"}
+# Kernels that read their input as 16-byte-per-lane coalesced streams (matched on the
+# name in front of the template arguments; k_emit_t<8> / k_emit_t<1> are "k_emit_t").
+STREAMING = {"k_lowres_avg", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_t", "k_emit_m", "k_lres_summary",
+             "k_place_fres", "k_tile_inv"}
+
+
+def is_streaming(key):
+    return key.split("<")[0].split("[")[0].strip() in STREAMING
 
 # A kernel launched with several grid sizes per step (k_tok_hist: the LRES spans on the
 # side stream, then the FRES rows) is reported per grid: the largest under the kernel's
@@ -77,7 +83,7 @@ for k in sorted(acc, key=lambda k: -dur[k][0]):
         raw = row["FETCH_SIZE"] * 1024 / 1e6
         row["hbm_read_MB_raw"] = raw
         row["hbm_read_MB_x2"] = 2 * raw
-        row["hbm_read_MB_corrected"] = 2 * raw if k.split("<")[0].split("[")[0] in STREAMING else raw
+        row["hbm_read_MB_corrected"] = 2 * raw if is_streaming(k) else raw
     if "WRITE_SIZE" in row:
         row["hbm_write_MB"] = row["WRITE_SIZE"] * 1024 / 1e6
     out[k] = row
