@@ -1268,8 +1268,8 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
 // Returns false on a stream error; *end_bp = bit position where the block became
 // complete (~0u if it did not).
 // CLIP: as in lean_write; op and out_size then both count from the window's guard.
-template <bool CLIP = false>
-__device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uint32_t bp,
+template <bool CLIP = false, class RD = GReader>
+__device__ __forceinline__ bool exact_write(RD &rd, const GrpTables &t, uint32_t bp,
                                             uint32_t lim, uint32_t op, uint32_t out_size,
                                             uint8_t *lds_out, uint32_t *end_bp, uint32_t win_span = 0) {
   *end_bp = ~0u;
@@ -1289,10 +1289,10 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
     const int limk = (int)lim - kLutBits;
     uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
     while ((int)bp <= limk) {
-      const GReader saved = rd;
+      const RD saved = rd;
       uint32_t nbits, cnt, by;
       bool gbad = false;
-      lean_step<true>(rd, t, false, &nbits, &cnt, &by, &gbad);
+      lean_step<true, false, RD>(rd, t, false, &nbits, &cnt, &by, &gbad);
       if (gbad || !before(op + cnt, out_size)) { rd = saved; break; }
       if (!CLIP || op - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
         const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
@@ -1305,7 +1305,7 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
   }
   for (;;) {
     uint32_t nbits, cnt, by;
-    lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
+    lean_step<true, false, RD>(rd, t, true, &nbits, &cnt, &by, &bad);
     if (bad) return false;
     if (before(out_size, op + cnt)) return false;  // a zero run overruns the block
     if (by && (!CLIP || op - kWinGuard < win_span - kWinGuard)) lds_out[op] = (uint8_t)by;
@@ -1460,7 +1460,8 @@ struct PreLane {
 // LDS window `win` to `gout`.  Returns (to every lane) 0 when the stream is
 // accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
 // pre_start / pre_off (optional): the fixpoint of the stream's single chunk computed
-// beforehand by k_row_count (pre_off[kDecThreads + 2] != 0 says it is usable).
+// beforehand by k_row_count (pre_off[kRecLanes + kRecValid] != 0 says it is usable; lane t's
+// records are the even ones, 2 t).
 // GLOBAL (with FUSED false): the output goes straight to `gout`, PRE-ZEROED global
 // memory, without the LDS window (win may be nullptr) -- the LRES serial fallback.
 template <bool FUSED, bool GLOBAL = false>
@@ -1503,9 +1504,9 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     // (k_row_count_w: the first GROUP boundary at or past the nominal one), and a lane
     // owns exactly the tokens in front of its neighbour's first.
     uint32_t wlim = lim;
-    const bool pre = cur == 0 && (pl ? pl->valid != 0 : (pre_off && pre_off[kDecThreads + 2] != 0));
+    const bool pre = cur == 0 && (pl ? pl->valid != 0 : (pre_off && pre_off[kRecLanes + kRecValid] != 0));
     if (pre) {
-      const uint32_t ns = pl ? pl->nstart : (tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u);
+      const uint32_t ns = pl ? pl->nstart : (tid + 1 < kDecThreads ? pre_start[2 * tid + 2] : ~0u);
       wlim = ns < rel_end - rel0 ? rel0 + ns : rel_end;
     }
     if (pre && pl) {
@@ -1518,13 +1519,13 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
       st_rounds += pl->rounds;
     } else if (pre) {
       // One chunk, fixpoint done by k_row_count at twice the occupancy.
-      start = rel0 + pre_start[tid];
-      off = pre_off[tid];
-      const uint32_t nxt_off = pre_off[tid + 1];   // [kDecThreads] holds the total
+      start = rel0 + pre_start[2 * tid];
+      off = pre_off[2 * tid];
+      const uint32_t nxt_off = pre_off[2 * tid + 2];   // [kRecLanes] holds the total
       cnt = nxt_off - (uint32_t)off;
-      tot = pre_off[kDecThreads];
-      if (tid == last_active) endpos = rel0 + pre_off[kDecThreads + 1];
-      st_rounds += pre_off[kDecThreads + 3];
+      tot = pre_off[kRecLanes + kRecTot];
+      if (tid == last_active) endpos = rel0 + pre_off[kRecLanes + kRecEnd];
+      st_rounds += pre_off[kRecLanes + kRecRounds];
     } else {
       long long c_first = 0;
       lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false, lead_bits, &c_first);
@@ -1632,10 +1633,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
     if (use_row_count) {
-      pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+      pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes;
+      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr);
       // use_row_count == 2: rows with a usable fixpoint were written by k_row_window.
-      if (use_row_count == 2 && pre_off[kDecThreads + 2] != 0) return;
+      if (use_row_count == 2 && pre_off[kRecLanes + kRecValid] != 0) return;
     }
   }
   load_dec_tables(ws, df, f, strm, &T);
@@ -2552,10 +2553,12 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint32_t pre_lr[4] = {0, 0, 0, 0}, pre_off0 = 0, pre_len0 = 0;
   if constexpr (COLS == 512) {
     const size_t ri = (size_t)f * g.rows + (size_t)(r0 + (int)blockIdx.x);
-    const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + 4);
-    pl.start = ps[tid]; pl.off = po[tid]; pl.nxt = po[tid + 1];
-    pl.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
-    pl.tot = po[kDecThreads]; pl.endrel = po[kDecThreads + 1]; pl.valid = po[kDecThreads + 2]; pl.rounds = po[kDecThreads + 3];
+    const uint32_t *ps = ws.lane_start + ri * kRecLanes, *po = ws.lane_off + ri * (kRecLanes + kRecHdr);
+    if (po[kRecLanes + kRecDone]) return;   // k_dec_row_chan has decoded this row (wave-uniform: one scalar load)
+    pl.start = ps[2 * tid]; pl.off = po[2 * tid]; pl.nxt = po[2 * tid + 2];
+    pl.nstart = tid + 1 < kDecThreads ? ps[2 * tid + 2] : ~0u;
+    pl.tot = po[kRecLanes + kRecTot]; pl.endrel = po[kRecLanes + kRecEnd]; pl.valid = po[kRecLanes + kRecValid];
+    pl.rounds = po[kRecLanes + kRecRounds];
     pre_off0 = ws.row_off[ri]; pre_len0 = ws.row_len[ri];
     const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + (int)blockIdx.x;
     const int u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
@@ -2627,8 +2630,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
         p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
         (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, nullptr, nullptr,
         ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
-        ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
-        ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
+        ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes,
+        ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr));
   };
   int bad = 0;
   if constexpr (COLS == 512) {
@@ -2731,13 +2734,13 @@ __device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, Strea
   // block in the write pass and is rejected there like before.
   uint32_t tot;
   const uint32_t off = block_scan_u32d(min(cnt, 0x3fffffu), sm32, &tot);
-  l_start[tid] = start - rel0;
-  l_off[tid] = off;
-  if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
+  l_start[2 * tid] = start - rel0;   // (the even records: whole lanes)
+  l_off[2 * tid] = off;
+  if (tid == last_active) l_off[kRecLanes + kRecEnd] = endpos - rel0;
   if (tid == 0) {
-    l_off[kDecThreads] = tot;
-    l_off[kDecThreads + 3] = rounds | (min(sh->dbg[0], 4095u) << 8) | (min(sh->dbg[1], 4095u) << 20);
-    l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
+    l_off[kRecLanes + kRecTot] = tot;
+    l_off[kRecLanes + kRecRounds] = rounds | (min(sh->dbg[0], 4095u) << 8) | (min(sh->dbg[1], 4095u) << 20);
+    l_off[kRecLanes + kRecValid] = 1;   // (no fence: the consumer is a later kernel)
   }
   if ((tid & 63) == 0 && rc) {   // cycles / 16, slowest wave of the workgroup
     atomicMax(&rc[0], (uint32_t)((c_fix0 - c_in) >> 4));            // tables / payload staging
@@ -2798,10 +2801,10 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
   const int rb = r0 + (int)blockIdx.x * rows_per_wg;
   for (int r = rb; r < min(rb + rows_per_wg, r1); ++r) {
     const long long c_in = clock64();
-    uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+    uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes;
+    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr);
     uint32_t *rc = ws.rc_stats ? ws.rc_stats + ((size_t)f * g.rows + r) * 8 : nullptr;
-    if (tid == 0) { l_off[kDecThreads + 2] = 0; sh.dbg[0] = sh.dbg[1] = 0; }   // not usable until proven otherwise
+    if (tid == 0) { l_off[kRecLanes + kRecValid] = 0; l_off[kRecLanes + kRecDone] = 0; sh.dbg[0] = sh.dbg[1] = 0; }   // not usable until proven otherwise
     const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
     const unsigned long long rem = 8ull * pay_len;
     uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
@@ -2952,11 +2955,14 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     const int nn = df->s[1].num_nodes;
     for (int k = tid; k < nn; k += kDecThreads) nd[k] = nodes[k];
     const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
-    const uint2 *gc = reinterpret_cast<const uint2 *>(ws.gyc + ((size_t)f * 2 + 1) * (1u << kLutBits));
     for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
       const uint4 q = gg[k];
-      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);   // long-code descriptors
-      reinterpret_cast<uint2 *>(gy)[k] = gc[k];                  // count-only step words
+      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);   // bytes / long-code descriptors
+      // The step words of the WRITE pass's groups (at most four output bytes), not the
+      // count-only ones: the row kernels then follow exactly this kernel's chain of
+      // groups and land on every recorded boundary without a token-by-token tail
+      // (0.5 % more steps here than with the longer count-only groups).
+      reinterpret_cast<uint2 *>(gy)[k] = make_uint2(q.y, q.w);
     }
     const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
     for (int k = tid; k < kSubEntries / 2; k += kDecThreads) {
@@ -2971,9 +2977,11 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   const int r = r0 + (int)blockIdx.x * kCountRowsW + (tid >> 6);
   if (r >= r1) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
-  if (lane == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
+  uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes;
+  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr);
+  if (lane < kRecHdr) {   // not usable until proven otherwise; a boundary nobody reaches: no record
+    l_off[kRecLanes + lane] = (lane >= kRecChanFirst + 1 && lane < kRecChanFirst + 5) ? ~0u : 0u;
+  }
   const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
   const unsigned long long rem64 = 8ull * pay_len;
   uint32_t sb = (uint32_t)((rem64 + kDecThreads - 1) / kDecThreads);
@@ -2986,6 +2994,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
   const uint32_t rel_end = rel0 + rem;
   const uint32_t lead = (uint32_t)g.lead_bits;
+  // The symbols whose records the channel-by-channel row kernel looks up (k_dec_row_chan):
+  // the first symbol of channel planes 1.. and the block's last symbol.
+  const uint32_t plane = (uint32_t)g.row_block / (uint32_t)(g.C > 0 ? g.C : 1);
   uint32_t first = rel0;   // where the phase's first lane starts: exact
   uint32_t base = 0;       // symbols in front of the phase
   uint32_t rounds = 0;
@@ -3001,8 +3012,8 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     const bool active = q.active;
     const uint32_t pb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.b0);   // the phase's first lane: its nominal start
     if (pb0 >= rel_end) {   // a phase beyond the payload: its lanes own nothing
-      l_start[v] = rem;
-      l_off[v] = base;
+      l_start[2 * v] = rem; l_start[2 * v + 1] = rem;
+      l_off[2 * v] = base; l_off[2 * v + 1] = base;
       continue;
     }
     // STAGED: positions below are relative to the dword `w0` of the reader's window, the
@@ -3053,19 +3064,30 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     // whose start moves in a later round walks up to T again, and if it arrives at the
     // same boundary everything behind is what it already has.  A round after the first
     // then costs the wavefront kJoinBits instead of a whole sub-sequence.
+    // The walk is cut once more at M, the middle of the range: the boundary and the count
+    // there are the lane's second record (the channel-by-channel row kernel walks half
+    // ranges: twice as many lanes at work in its write passes).
     uint32_t T = (active ? b0 : rel_end - shift) + kJoinBits;
     if (T > lim || T < b0) T = lim;
-    uint32_t posT = ~0u, cT = 0;
+    uint32_t M = (active ? b0 : rel_end - shift) + ((lim - b0) >> 1);
+    if (M < T || !active) M = T;
+    uint32_t posT = ~0u, cT = 0, pm = start, midc = 0;
     for (;;) {
       if (dirty) {
         uint32_t p1, c1;
-        walk(start, T, &p1, &c1, at_start);
+        bool at = at_start;   // (register windows only: the reader stands at the walk's position)
+        walk(start, T, &p1, &c1, at);
+        at = at || start < T;
         if (p1 == posT) {
           cnt = c1 + (cnt - cT);
+          midc = c1 + (midc - cT);
         } else {
-          uint32_t c2;
-          walk(p1, lim, &endpos, &c2, start < T || at_start);
-          cnt = c1 + c2;
+          uint32_t c2, c3;
+          walk(p1, M, &pm, &c2, at);
+          at = at || p1 < M;
+          walk(pm, lim, &endpos, &c3, at);
+          midc = c1 + c2;
+          cnt = midc + c3;
         }
         posT = p1;
         cT = c1;
@@ -3079,6 +3101,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
       ++rounds;
       if (!__any(dirty ? 1 : 0)) break;
     }
+    if (!active) { pm = start; midc = 0; }
     // Exclusive prefix of the counts (k_row_count's clamp: see row_count_one).
     const uint32_t c = min(cnt, 0x3fffffu);
     uint32_t incl = c;
@@ -3087,9 +3110,18 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
       const uint32_t t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    l_start[v] = start + shift - rel0;
-    l_off[v] = base + incl - c;
-    if (v == q.last_active) l_off[kDecThreads + 1] = endpos + shift - rel0;
+    const uint32_t o0 = base + incl - c, o1 = o0 + min(midc, c), o2 = base + incl;
+    const uint32_t s0 = start + shift - rel0, s1 = pm + shift - rel0;
+    l_start[2 * v] = s0; l_start[2 * v + 1] = s1;
+    l_off[2 * v] = o0; l_off[2 * v + 1] = o1;
+    if (v == q.last_active) l_off[kRecLanes + kRecEnd] = endpos + shift - rel0;
+    // The records that hold the first symbol of a channel plane / the block's last symbol.
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) {
+      const uint32_t X = k < 4 ? (uint32_t)k * plane : (uint32_t)g.row_block - 1u;
+      if (o0 <= X && X < o1) { l_off[kRecLanes + kRecChanFirst + k] = 2u * (uint32_t)v; l_off[kRecLanes + kRecChanPos + k] = s0; }
+      if (o1 <= X && X < o2) { l_off[kRecLanes + kRecChanFirst + k] = 2u * (uint32_t)v + 1u; l_off[kRecLanes + kRecChanPos + k] = s1; }
+    }
     base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     // The next phase starts where this one's last lane ended (a phase of inactive lanes: nowhere).
     first = (uint32_t)__builtin_amdgcn_readlane((int)(active ? endpos + shift : rel_end), 63);
@@ -3098,9 +3130,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   if (sb <= kStageSubBits) phases(std::true_type{});
   else phases(std::false_type{});
   if (lane == 0) {
-    l_off[kDecThreads] = base;
-    l_off[kDecThreads + 3] = rounds;
-    l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
+    l_off[kRecLanes + kRecTot] = base;
+    l_off[kRecLanes + kRecRounds] = rounds;
+    l_off[kRecLanes + kRecValid] = 3;   // (no fence: the consumer is a later kernel)
   }
 }
 
@@ -3127,11 +3159,11 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
   const int wi = blockIdx.x, r = r0 + (int)blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   const size_t ri = (size_t)f * g.rows + r;
-  const uint32_t *pre_start = ws.lane_start + ri * kDecThreads, *pre_off = ws.lane_off + ri * (kDecThreads + 4);
+  const uint32_t *pre_start = ws.lane_start + ri * kRecLanes, *pre_off = ws.lane_off + ri * (kRecLanes + kRecHdr);
   // Everything from global memory in front of the first barrier.
-  const uint32_t st_rel = pre_start[tid], off = pre_off[tid], nxt = pre_off[tid + 1];
-  const uint32_t nst_rel = tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u;   // the lane walks to its neighbour's start
-  const uint32_t tot = pre_off[kDecThreads], usable = pre_off[kDecThreads + 2];
+  const uint32_t st_rel = pre_start[2 * tid], off = pre_off[2 * tid], nxt = pre_off[2 * tid + 2];
+  const uint32_t nst_rel = tid + 1 < kDecThreads ? pre_start[2 * tid + 2] : ~0u;   // the lane walks to its neighbour's start
+  const uint32_t tot = pre_off[kRecLanes + kRecTot], usable = pre_off[kRecLanes + kRecValid];
   const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
   if (tid == 0) { sh.flag = (df->status || usable == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
   load_dec_tables(ws, df, f, 1, &T);
@@ -3182,6 +3214,377 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
     if (bad) atomicMax(&df->status, fmt_err(7, 1));
   } else if (tid == 0 && sh.err) {
     atomicMax(&df->status, fmt_err(7, 1));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_dec_row_chan: one block row of a 4096-pixel RGBA frame per 512-lane workgroup, CHANNEL
+// BY CHANNEL -- so that TWO workgroups share a CU (k_dec_row_fused keeps the row's 128 KiB
+// of symbols in LDS: one workgroup per CU, and nothing overlaps its prologue, its barriers
+// or the latency-bound write pass).  The symbols of a block row are laid out channel-major
+// (encoder.cpp:320-323), so the write pass and the transform can take one 32 KiB channel
+// plane at a time:
+//   pass c:  the sub-sequences whose symbols fall into plane c (a contiguous range of
+//            k_row_count_w's HALF-lane records, found through the row's channel index) are
+//            walked from the payload staged in LDS (on demand, see LdsBits) and OR-ed into
+//            the zeroed plane, clipped like k_row_window; then lane = tile transforms the
+//            plane (tile_plane) and keeps its 64 result bytes in registers;
+//   finally: colour inverse and the pixel stores from the four planes' registers.
+// The walk follows k_row_count_w's chain of groups (same table, same start), so it lands on
+// every record's boundary without a token-by-token tail; only the half-lane in which the
+// block completes goes token by token, with the reference's end-of-block checks
+// (exact_write).  The next pass's records, low-res corners and payload are requested while
+// the current pass walks, and parked in the LDS buffer that pass has finished with.
+// Rows without full records (kRecValid != 3) are left to k_dec_row_fused (kRecDone stays 0).
+// ---------------------------------------------------------------------------
+constexpr int kChanThreads = 512;
+constexpr uint32_t kChanStageWords = 2688;                                            // payload dwords of one round (84 blocks of 32)
+constexpr uint32_t kChanStageAlloc = (kChanStageWords + kChanStageWords / 32u + 3u) & ~3u;   // in blocks of 33 (LdsBits)
+constexpr uint32_t kChanPlane = 32768;                                                // symbols of one channel plane (512 tiles)
+struct ChanShared { int flag, err; unsigned long long endbit; uint32_t ndone; };
+struct ChanLayout {
+  static constexpr uint32_t tab = 0;                                                  // uint2 grp[kTabEntries]
+  static constexpr uint32_t sym = tab + (uint32_t)kTabEntries * 8u;                   // guard + plane + guard
+  static constexpr uint32_t stage = sym + kChanPlane + 64u;                           // two staging buffers
+  static constexpr uint32_t unmap = stage + 2u * kChanStageAlloc * 4u;
+  static constexpr uint32_t shift = unmap + 512u;
+  static constexpr uint32_t shiftp = shift + 128u;
+  static constexpr uint32_t sh = shiftp + 288u;
+  static constexpr uint32_t total = sh + 64u;
+};
+static_assert(2u * ChanLayout::total <= 160u * 1024u, "two workgroups per CU");
+static_assert(kChanStageAlloc * 4u >= 5u * kChanThreads * 4u, "a finished staging buffer parks five words per lane");
+
+// Reader over the padded staging layout (register window; the exact path only).
+struct PaddedLds {
+  uint32_t base;
+  __device__ __forceinline__ uint32_t operator[](uint32_t j) const { return lds_ld32(base + ((j + (j >> 5)) << 2)); }
+};
+typedef ReaderT<PaddedLds> PReader;
+
+// The groups in [pos, lim) -- lim a boundary of the same chain -- from the staged payload
+// into the (clipped) plane in LDS: lean_write<true> over an LdsBits.
+__device__ __forceinline__ bool grp_write_lds(const LdsBits &bits, const GrpTables &t, uint32_t pos, uint32_t lim,
+                                              uint32_t op, uint8_t *lds_out, uint32_t win_span) {
+  bool bad = false;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
+  const uint32_t TM = ((1u << kLutBits) - 1u) << 3, TB = lds_addr(t.grp);
+  uint32_t tm = TM, tb = TB;
+  auto step = [&]() {
+#ifdef HIMG_X_NOWIN
+    uint32_t win = pos * 2654435761u;
+#else
+    uint32_t win = bits.window(pos);
+#endif
+    const uint2 e = lds_ld64(((win << 3) & tm) + tb);
+    uint32_t y = e.y, by = e.x, ntm = TM, ntb = TB;
+    if (__builtin_expect(y == 0, 0)) {
+      if ((by >> 31) && tm == TM) {
+        ntm = ((1u << (by & 255u)) - 1u) << 3;
+        ntb = TB + (((1u << kLutBits) + ((by >> 8) & 0xffffu)) << 3);
+        y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
+        by = 0;
+      } else {
+        BitWin64 rd;
+        rd.win = (unsigned long long)win | ((unsigned long long)bits.window(pos + 32u) << 32);
+        const int base = tm == TM ? 0 : kLutBits;
+        uint32_t len;
+        y = walk_token(rd, t, by, base, &len, &by, &bad);
+        pos += len - (uint32_t)base;
+        win = bits.window(pos);
+      }
+    }
+    tm = ntm; tb = ntb;
+    const uint32_t extra = __builtin_amdgcn_ubfe(win, y, y >> 5);
+    pos += y >> 27;
+#ifndef HIMG_X_NOOR
+    if (op - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
+      const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
+      atomicOr(&o32[op >> 2], (uint32_t)v);
+      atomicOr(&o32[(op >> 2) + 1], (uint32_t)(v >> 32));
+    }
+#endif
+    op += ((y >> 10) & 511u) + extra;
+  };
+  while (pos < lim) step();
+  if (tm != TM) step();
+  return !bad;
+}
+
+template <int COLS>
+__global__ __launch_bounds__(kChanThreads, 4) void k_dec_row_chan(Geom g, DecWs ws, const uint8_t *packed,
+                                                                 size_t in_stride, const uint32_t *sizes,
+                                                                 uint8_t *out_frames, int r0) {
+  static_assert(COLS == 512, "one lane per tile, 32 KiB planes");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint2 *s_grp = reinterpret_cast<uint2 *>(smem + ChanLayout::tab);
+  uint8_t *s_sym = smem + ChanLayout::sym;                       // kWinGuard bytes, the plane, the rest of the guard
+  uint32_t *s_stage = reinterpret_cast<uint32_t *>(smem + ChanLayout::stage);
+  int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + ChanLayout::unmap);
+  uint8_t *s_shift = smem + ChanLayout::shift;
+  uint32_t *s_shiftp = reinterpret_cast<uint32_t *>(smem + ChanLayout::shiftp);
+  ChanShared *sh = reinterpret_cast<ChanShared *>(smem + ChanLayout::sh);
+
+  const int f = blockIdx.y, tid = threadIdx.x, v = r0 + (int)blockIdx.x;
+  const long long c_in = clock64();
+  DecFrame *df = ws.frames + f;
+  const size_t ri = (size_t)f * g.rows + (size_t)v;
+  const uint32_t *ps = ws.lane_start + ri * kRecLanes;
+  uint32_t *po = ws.lane_off + ri * (kRecLanes + kRecHdr);
+  const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
+  // The row's header (wave-uniform loads) and everything else the first pass needs from
+  // global memory, all requested in front of the first barrier.
+  const uint32_t valid = po[kRecLanes + kRecValid], tot = po[kRecLanes + kRecTot];
+  uint32_t cfirst[5], cpos[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { cfirst[k] = po[kRecLanes + kRecChanFirst + k]; cpos[k] = po[kRecLanes + kRecChanPos + k]; }
+  const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
+  if (tid == 0) { sh->flag = (df->status || valid != 3u) ? 1 : 0; sh->err = 0; sh->endbit = ~0ull; }
+  const uint8_t *p = packed + (size_t)f * in_stride;
+  // The payload as dwords: bit `rel0 + x` of wbase[] is bit x of the row.
+  const uint32_t *wbase = reinterpret_cast<const uint32_t *>(p + (pay_off & ~3u));
+  const uint32_t rel0 = 8u * (pay_off & 3u);
+  const uint32_t jmax = ((ssize - 1u) >> 2) - (pay_off >> 2);
+  const uint32_t rem = 8u * pay_len, out_size = (uint32_t)g.row_block;
+  auto ldw = [&](uint32_t j) { return wbase[j < jmax ? j : jmax]; };
+
+  // What a pass needs per lane: its half-lane record, the next record (where its walk and
+  // its symbols end), the low-res corners of its tile in this channel, and its one or two
+  // 16-byte pieces of the round's payload.
+  struct PassIn { uint32_t pos0, pos1, off0, off1, lr; uint4 pay[2]; };
+  const int u = tid, u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
+  auto request = [&](int c, uint32_t hs, uint32_t ps_bits, PassIn *in, bool with_lr) {
+    const uint32_t h = hs + (uint32_t)tid;
+    const bool live = h < (uint32_t)kRecLanes;
+    in->pos0 = live ? ps[h] : rem;
+    in->pos1 = h + 1u < (uint32_t)kRecLanes ? ps[h + 1u] : rem;
+    in->off0 = live ? po[h] : tot;
+    in->off1 = live ? po[h + 1u] : tot;   // (po[kRecLanes] is the total)
+    if (with_lr) {
+      const uint8_t *m = low + (size_t)c * g.rows * COLS;
+      in->lr = (uint32_t)m[(size_t)v * COLS + u] | ((uint32_t)m[(size_t)v * COLS + u2] << 8) |
+               ((uint32_t)m[(size_t)v2 * COLS + u] << 16) | ((uint32_t)m[(size_t)v2 * COLS + u2] << 24);
+    }
+    const uint32_t w0 = (rel0 + ps_bits) >> 5;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t k = (uint32_t)tid + (uint32_t)q * kChanThreads;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (4u * k < kChanStageWords) {
+        const uint32_t w = w0 + 4u * k;
+        if (w + 3u <= jmax) {
+          const PackedU4 t4 = *reinterpret_cast<const PackedU4 *>(wbase + w);
+          x.x = t4.x; x.y = t4.y; x.z = t4.z; x.w = t4.w;
+        } else {
+          x.x = ldw(w); x.y = ldw(w + 1u); x.z = ldw(w + 2u); x.w = ldw(w + 3u);
+        }
+      }
+      in->pay[q] = x;
+    }
+  };
+  auto store_payload = [&](const PassIn &in, uint32_t *stage) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t k = (uint32_t)tid + (uint32_t)q * kChanThreads;
+      if (4u * k < kChanStageWords) {
+        uint32_t *d = stage + 4u * k + (k >> 3);   // blocks of 33, see LdsBits
+        d[0] = in.pay[q].x; d[1] = in.pay[q].y; d[2] = in.pay[q].z; d[3] = in.pay[q].w;
+        if ((k & 7u) == 0u && k) d[-1] = in.pay[q].x;
+      }
+    }
+  };
+
+  PassIn cur;
+  request(0, 0u, 0u, &cur, true);
+  // The decode tables (group table and second-level table, the interleaved form of the
+  // write pass; the tree nodes stay in global memory: only codes longer than both tables
+  // reach them) and the dequantiser's tables.
+  static_assert(kTabEntries / 2 == 3 * kChanThreads, "three table quad-words per lane");
+  uint4 t_tab[3];
+  {
+    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
+    t_tab[0] = gg[tid]; t_tab[1] = gg[tid + kChanThreads]; t_tab[2] = gs[tid];
+  }
+  if (tid < 256) {
+    const int sc = (int8_t)tid;
+    s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
+  } else if (tid < 384) {
+    s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
+  } else if (tid < 448) {
+    const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
+    s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
+  } else {
+    identity_test_words(df, tid - 448, s_shiftp + 64);
+  }
+  const int ycbcr = df->ycbcr;
+  reinterpret_cast<uint4 *>(s_grp)[tid] = t_tab[0];
+  reinterpret_cast<uint4 *>(s_grp)[tid + kChanThreads] = t_tab[1];
+  reinterpret_cast<uint4 *>(s_grp + (1 << kLutBits))[tid] = t_tab[2];
+  GrpTables tb;
+  tb.grp = s_grp; tb.gx = nullptr; tb.gy = nullptr;
+  tb.nd = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1);
+
+  uint32_t O[4][16];
+  long long c_write = 0, c_xf = 0, c_walk = 0, c_tail = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    // Pass c walks from `stage`; `other` held the pass before's payload and holds this
+    // pass's parked records now; behind this pass's walk it receives the next pass's payload.
+    uint32_t *stage = s_stage + (uint32_t)(c & 1) * kChanStageAlloc, *other = s_stage + (uint32_t)((c + 1) & 1) * kChanStageAlloc;
+    if (c > 0) {
+      __syncthreads();   // the transform of the pass before is done with the plane
+      cur.pos0 = other[5 * tid]; cur.pos1 = other[5 * tid + 1]; cur.off0 = other[5 * tid + 2];
+      cur.off1 = other[5 * tid + 3]; cur.lr = other[5 * tid + 4];
+    }
+    {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      for (uint32_t k = (uint32_t)tid; k < (kChanPlane + 64u) / 16u; k += kChanThreads) reinterpret_cast<uint4 *>(s_sym)[k] = z;
+    }
+    if (c == 0) store_payload(cur, stage);
+    __syncthreads();
+    if (c == 0 && sh->flag) return;   // (uniform; the frame failed, or the row is k_dec_row_fused's)
+    const long long c_w0 = clock64();
+    // The next pass's first round: requested now, consumed behind this pass's walk.
+    PassIn nxt;
+    if (c < 3) {
+      const uint32_t nhs = cfirst[c + 1];
+      request(c + 1, nhs < (uint32_t)kRecLanes ? nhs : (uint32_t)kRecLanes, nhs < (uint32_t)kRecLanes ? cpos[c + 1] : 0u, &nxt, true);
+    }
+
+    // ---- the write pass of plane c: rounds of up to 512 consecutive half-lanes (one round,
+    // unless the half-lanes outgrow the staging buffer) ----
+    const uint32_t w0s = (uint32_t)c * kChanPlane, w1s = w0s + kChanPlane, span = kChanPlane + kWinGuard;
+    uint32_t hs = c == 0 ? 0u : cfirst[c], psb = c == 0 ? 0u : cpos[c];
+    const uint32_t he = cfirst[c + 1] < (uint32_t)kRecLanes ? cfirst[c + 1] : (uint32_t)kRecLanes - 1u;
+    bool staged = true;   // `stage` holds this round's payload, `cur` its records
+    while (hs <= he) {
+      if (!staged) {      // a further round: fetched on the spot
+        __syncthreads();  // (everybody is done with the round before; sh->ndone is published)
+        psb = sh->ndone;
+        PassIn more;
+        request(c, hs, psb, &more, false);
+        store_payload(more, stage);
+        cur.pos0 = more.pos0; cur.pos1 = more.pos1; cur.off0 = more.off0; cur.off1 = more.off1;
+      }
+      const uint32_t w0 = (rel0 + psb) >> 5;
+      const uint32_t h = hs + (uint32_t)tid;
+      // The lane's walk fits the staged piece (a step reads two dwords at its position, the
+      // tree-walk path 32 bits further, the exact path's register window three dwords ahead).
+      const bool mine = h <= he && rel0 + cur.pos1 + 96u <= 32u * (w0 + kChanStageWords - 2u);
+      const uint32_t ndone = (uint32_t)__syncthreads_count(mine ? 1 : 0);   // (also: the payload is staged)
+      const long long c_k0 = clock64();
+      if (mine) {
+        LdsBits bits;
+        bits.base = lds_addr(stage);
+        const uint32_t a = rel0 + cur.pos0 - 32u * w0, b = rel0 + cur.pos1 - 32u * w0;
+        const bool inside = cur.off1 < out_size, exact = !inside && cur.off0 < out_size;
+        const bool touches = cur.off1 > cur.off0 && cur.off0 < w1s && cur.off1 > w0s;
+        const uint32_t op = cur.off0 - w0s + kWinGuard;
+        if (inside && touches) {
+          if (!grp_write_lds(bits, tb, a, b, op, s_sym, span)) sh->err = 1;
+        } else if (exact && touches) {
+          PReader rd;
+          rd.w.base = bits.base;
+          rd.jmax = kChanStageWords - 1u;
+          uint32_t end_bp = ~0u;
+          if (!exact_write<true, PReader>(rd, tb, a, b, op, out_size - w0s + kWinGuard, s_sym, &end_bp, span)) sh->err = 1;
+          if (end_bp != ~0u) sh->endbit = (unsigned long long)(end_bp + 32u * w0 - rel0);
+        }
+      }
+      c_walk += clock64() - c_k0;
+      if (ndone == 0) { if (tid == 0) sh->err = 1; break; }   // (a half-lane longer than the buffer: max_sub forbids it)
+      // Where the next round starts: the first half-lane that did not fit.
+      if ((uint32_t)tid == ndone) sh->ndone = cur.pos0;
+      if (ndone == (uint32_t)kChanThreads && tid == kChanThreads - 1) sh->ndone = cur.pos1;
+      hs += ndone;
+      staged = false;
+    }
+    // Behind the walk: the next pass's payload into the buffer the pass before has left.
+    const long long c_t0 = clock64();
+    if (c < 3) store_payload(nxt, other);
+    __syncthreads();   // the plane is complete, `stage` is free
+    if (c < 3) {       // park the next pass's records (lane-private words: no barrier)
+      stage[5 * tid] = nxt.pos0; stage[5 * tid + 1] = nxt.pos1; stage[5 * tid + 2] = nxt.off0;
+      stage[5 * tid + 3] = nxt.off1; stage[5 * tid + 4] = nxt.lr;
+    }
+    const long long c_x0 = clock64();
+    c_write += c_x0 - c_w0;
+    c_tail += c_x0 - c_t0;
+    // ---- the transform of plane c: lane = tile ----
+#ifndef HIMG_X_NOXF
+    {
+      const int chroma = (ycbcr && (c == 1 || c == 2)) ? 1 : 0;   // decoder.cpp:376
+      tile_plane<COLS>(s_sym + kWinGuard + u, COLS, s_unmap, s_shift + chroma * 64, s_shiftp + chroma * 32,
+                       cur.lr & 0xffffu, cur.lr >> 16, O[c], s_shiftp + 64 + 2 * chroma);
+    }
+#else
+    for (int i = 0; i < 16; ++i) O[c][i] = s_sym[kWinGuard + u + 512 * i];
+#endif
+    c_xf += clock64() - c_x0;
+  }
+  // Accept / reject like UncompressStream (huffman_dec.cpp:361-417).  (Behind the last
+  // pass's barrier: every walk has reported.)
+  if (tid == 0) {
+    int bad = sh->err;
+    if (tot < out_size) bad = 1;   // ran out of payload before the block was full
+    const unsigned long long E = sh->endbit, P1 = 8ull * pay_len;
+    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+    if (bad) atomicMax(&df->status, fmt_err(7, 1));
+    po[kRecLanes + kRecDone] = 1;
+  }
+  // ---- colour inverse (ycbcr.cpp:54-82, two pixels per packed operation) and the stores:
+  // a wavefront writes 2 KiB of contiguous pixels per pixel row ----
+  uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * 4);
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    uint32_t px[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t q0 = O[0][y * 2 + h], q1 = O[1][y * 2 + h], q2 = O[2][y * 2 + h], q3 = O[3][y * 2 + h];
+      if (ycbcr) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t sel = k ? 0x0c030c02u : 0x0c010c00u;
+          const dpk16 yy = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q0, sel));
+          const dpk16 cbq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q1, sel));
+          const dpk16 crq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q2, sel));
+          const dpk16 c255 = {255, 255}, c254 = {254, 254}, one = {1, 1};
+          const dpk16 cbv = cbq + cbq - c255, crv = crq + crq - c255;
+          // (cbv + crv + 2) >> 2 == (cb + cr - 254) >> 1 exactly.
+          const dpk16 gg = yy - ((cbq + crq - c254) >> one);
+          const uint32_t rs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + crv)));
+          const uint32_t gs = sat_pk_u8(__builtin_bit_cast(uint32_t, gg));
+          const uint32_t bs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + cbv)));
+          const uint32_t rg = __builtin_amdgcn_perm(gs, rs, 0x05010400u);            // r0 g0 r1 g1
+          const uint32_t ba = __builtin_amdgcn_perm(q3, bs, k ? 0x07010600u : 0x05010400u);  // b0 a0 b1 a1
+          px[4 * h + 2 * k] = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+          px[4 * h + 2 * k + 1] = __builtin_amdgcn_perm(ba, rg, 0x07060302u);
+        }
+      } else {
+        const uint32_t t0 = __builtin_amdgcn_perm(q1, q0, 0x05010400u), t1 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
+        const uint32_t w0 = __builtin_amdgcn_perm(q3, q2, 0x05010400u), w1 = __builtin_amdgcn_perm(q3, q2, 0x07030602u);
+        px[4 * h + 0] = __builtin_amdgcn_perm(w0, t0, 0x05040100u);
+        px[4 * h + 1] = __builtin_amdgcn_perm(w0, t0, 0x07060302u);
+        px[4 * h + 2] = __builtin_amdgcn_perm(w1, t1, 0x05040100u);
+        px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
+      }
+    }
+    uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * 4;
+    uint4 o0, o1;
+    o0.x = px[0]; o0.y = px[1]; o0.z = px[2]; o0.w = px[3];
+    o1.x = px[4]; o1.y = px[5]; o1.z = px[6]; o1.w = px[7];
+    reinterpret_cast<uint4 *>(dst)[0] = o0;
+    reinterpret_cast<uint4 *>(dst)[1] = o1;
+  }
+  if ((tid & 63) == 0) {   // cycle stamps like k_dec_row_fused's (tools/dec_stats_batch.py): the slowest wave counts
+    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + v + 1) * 8;
+    atomicMax(&st[2], (uint32_t)(c_xf >> 4));
+    atomicMax(&st[3], (uint32_t)((clock64() - c_in) >> 4));
+    atomicMax(&st[5], (uint32_t)(c_write >> 4));
+    atomicMax(&st[1], (uint32_t)(c_walk >> 4));    // the walks alone (slowest wave)
+    atomicMax(&st[4], (uint32_t)(c_tail >> 4));    // behind the walks: prefetched payload to LDS, barrier
+    if (tid == 0) { st[0] = 1; st[6] = pay_len; st[7] = out_size; }
   }
 }
 
@@ -3296,8 +3699,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // (ds == nullptr: everything in line.)
   // Batches: one wavefront per row (k_row_count_w) -- from 8192 rows per call, below that
   // the 1024-lane kernel keeps the GPU busier (HIMG_COUNT_WAVE=0 / 1 forces either).
-  static const int cw_env = getenv("HIMG_COUNT_WAVE") ? atoi(getenv("HIMG_COUNT_WAVE")) : -1;
-  const bool count_wave = cw_env >= 0 ? cw_env != 0 : all_rows >= 8192;
+  const bool count_wave = g.count_wave >= 0 ? g.count_wave != 0 : all_rows >= 8192;   // HIMG_OPT_COUNT_WAVE
   auto row_count = [&](hipStream_t s, int a, int b) {
     if (b <= a) return;
     prof_begin(prof, "k_row_count", s);
@@ -3366,8 +3768,26 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       if (ds) (void)hipStreamWaitEvent(stream, ds->ev_cnt[k], 0);
       else row_count(stream, a, b);
       if (b <= a) continue;
-      prof_begin(prof, "k_dec_row_fused", stream);
       const bool whole4 = g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0;   // FULL4
+      // 4096-pixel RGBA rows with k_row_count_w's half-lane records: channel by channel,
+      // two workgroups per CU (HIMG_OPT_ROW_CHAN; by default where the streams' density
+      // suits it).  Rows it leaves alone (no full records) fall to k_dec_row_fused, which
+      // skips the rows marked done.
+      const bool chan = count_wave && g.W == 4096 && whole4 && g.row_chan != 0;
+      if (chan) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_chan<512>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        prof_begin(prof, "k_dec_row_chan", stream);
+#ifdef HIMG_X_ONEWG
+        const uint32_t chan_lds = 100u * 1024u;
+#else
+        const uint32_t chan_lds = ChanLayout::total;
+#endif
+        hipLaunchKernelGGL((k_dec_row_chan<512>), dim3(b - a, batch), dim3(kChanThreads), chan_lds, stream, g, ws,
+                           d_packed, in_stride, d_sizes, d_out, a);
+        prof_end(prof, stream);
+      }
+      prof_begin(prof, "k_dec_row_fused", stream);
       if (g.W == 4096 && whole4) HIMG_FUSED_LAUNCH(512, a, b);
       else if (whole4) HIMG_FUSED_LAUNCH(-1, a, b);
       else HIMG_FUSED_LAUNCH(0, a, b);

@@ -1905,7 +1905,7 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
 constexpr int kEmitRows = 8;   // (2 / 4 / 6 rows per workgroup: 3.35 / 2.99 / 3.49 ms per 64 frames, 8: 2.92)
 static void launch_emit(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_stride, const uint32_t *d_sizes,
                         int sp0, int sp1, int batch, hipStream_t stream, Profiler *prof) {
-  static const int rows_env = getenv("HIMG_EMIT_ROWS") ? atoi(getenv("HIMG_EMIT_ROWS")) : -1;
+  const int rows_env = g.emit_rows;   // HIMG_OPT_EMIT_ROWS (-1: by the number of rows)
   const int l1 = sp0 < g.lres_spans ? (sp1 < g.lres_spans ? sp1 : g.lres_spans) : sp0;   // [sp0, l1): LRES spans
   if (l1 > sp0) {
     prof_begin(prof, "k_emit", stream);

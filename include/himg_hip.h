@@ -55,6 +55,16 @@ const char *himg_hip_last_error(const himg_hip_ctx *ctx);
  * accepts decode identically either way.  Also enabled by HIMG_FIX_T2=1 in the
  * environment (for callers that only see the C++ classes). */
 #define HIMG_OPT_FIX_T2 1
+/* Kernel-variant selectors (tuning / test knobs; results are identical either way).
+ * value -1 = by launch size (the default), 0 / 1 = force off / on:
+ *   HIMG_OPT_COUNT_WAVE  FRES row index records by a wavefront per row (batches) instead of
+ *                        a workgroup per row (single frames)            [env HIMG_COUNT_WAVE]
+ *   HIMG_OPT_EMIT_ROWS   bit packing of FRES rows by a wavefront per row (batches) [env HIMG_EMIT_ROWS]
+ *   HIMG_OPT_ROW_CHAN    4096-pixel RGBA block rows decoded channel by channel, two
+ *                        workgroups per CU (needs the wavefront-per-row records) [env HIMG_ROW_CHAN] */
+#define HIMG_OPT_COUNT_WAVE 2
+#define HIMG_OPT_EMIT_ROWS 3
+#define HIMG_OPT_ROW_CHAN 4
 int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value);
 
 /* Upper bound of the packed size of one frame (bytes), a multiple of 256.
