@@ -35,7 +35,7 @@ struct Geom {
   int lead_bits;             // decoder: lead-in before a lane's nominal start (lean_fixpoint; 0 = start blind)
   // Kernel variants (context options, see himg_hip.h HIMG_OPT_*): -1 = chosen by the launch size.
   int count_wave;            // decoder: k_row_count_w (a wavefront per row) instead of k_row_count
-  int row_chan;              // decoder: k_dec_row_chan (channel by channel, two workgroups per CU) for 4096-pixel RGBA rows
+  int row_pair;              // decoder: k_dec_row_pair (channel by channel, two workgroups per CU) for 4096-pixel RGBA rows
   int emit_rows;             // encoder: k_emit_t<8> (a wavefront per row) instead of a workgroup per row
   long long frame_bytes;     // W*H*stride
   long long fres_size;       // rows*row_block
@@ -95,7 +95,8 @@ enum RecHdr {                      // index - kRecLanes into a row's lane_off ar
   kRecRounds = 3,                  // diagnostics
   kRecChanFirst = 4,               // [4] record that holds symbol c * plane (c = 1..3 in [5..7]; [4] = 0), [8]: symbol row_block - 1
   kRecChanPos = 9,                 // [5] bit position of those five records
-  kRecDone = 14,                   // 1: k_dec_row_chan has decoded the row
+  kRecDone = 14,                   // 1: a row kernel that works from the half-lane records has decoded the row
+  kRecQtr = 15,                    // 1: lane_qtr holds a boundary inside every half-lane (k_row_count_w)
 };
 
 struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
@@ -134,6 +135,8 @@ struct DecWs {
   // (bits from the chunk start) and the exclusive prefix of the symbol counts.
   uint32_t *lane_start;      // [f][rows][kRecLanes]
   uint32_t *lane_off;        // [f][rows][kRecLanes + kRecHdr]: offsets, then the header (RecHdr)
+  uint32_t *lane_qtr;        // [f][rows][kRecLanes]: per half-lane record a boundary near its middle: bits behind the
+                             // record's position [11:0] | symbols in front of it [31:12] (two chains per half-lane)
   uint32_t *parse_stats;     // [f][4] k_dec_parse phase cycles / 16
   uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
   uint32_t *rc_stats;        // [f][rows][8] k_row_count phase cycles / 16 (slowest wave)
