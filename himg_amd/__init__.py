@@ -267,8 +267,9 @@ class Engine:
         return [o.ravel()[: ws[i] * hs[i] * cs[i]].reshape(hs[i], ws[i], cs[i]) for i, o in enumerate(outs)]
 
     def set_option(self, option, value):
-        """himg_hip_set_option; option names: "fix_t2" (see include/himg_hip.h)."""
-        opt = {"fix_t2": 1}[option] if isinstance(option, str) else int(option)
+        """himg_hip_set_option; option names: "fix_t2", and the kernel-variant selectors
+        "count_wave" / "emit_rows" (-1 = by launch size, 0 / 1 = force; see include/himg_hip.h)."""
+        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3}[option] if isinstance(option, str) else int(option)
         self._check(lib().himg_hip_set_option(self._ctx, opt, int(value)), "set_option")
         if opt == 1:
             self.fix_t2 = bool(value)   # (the row-sharded decoder's host index follows it, sharded.py)

@@ -35,7 +35,6 @@ struct Geom {
   int lead_bits;             // decoder: lead-in before a lane's nominal start (lean_fixpoint; 0 = start blind)
   // Kernel variants (context options, see himg_hip.h HIMG_OPT_*): -1 = chosen by the launch size.
   int count_wave;            // decoder: k_row_count_w (a wavefront per row) instead of k_row_count
-  int row_pair;              // decoder: k_dec_row_pair (channel by channel, two workgroups per CU) for 4096-pixel RGBA rows
   int emit_rows;             // encoder: k_emit_t<8> (a wavefront per row) instead of a workgroup per row
   long long frame_bytes;     // W*H*stride
   long long fres_size;       // rows*row_block
@@ -83,21 +82,6 @@ constexpr int kDecThreads = 1024;
 constexpr int kSubEntries = 1024;  // second-level decode table (codes longer than kLutBits)
 constexpr int kSubMaxBits = 6;     // widest second-level sub-table
 constexpr int kLresSubBits = 256;  // parallel LRES decode: payload bits per lane of a chunk (kDecThreads lanes)
-// k_row_count's records of one FRES row: two per lane of the 1024-lane grid -- the lane's
-// first owned token and, for the wavefront-per-row count kernel, a boundary near the middle
-// of its range (record 2 t + 1; the row kernels that walk whole lanes read the even ones).
-constexpr int kRecLanes = 2 * kDecThreads;
-constexpr int kRecHdr = 16;        // header words behind the kRecLanes offsets, see RecHdr
-enum RecHdr {                      // index - kRecLanes into a row's lane_off array
-  kRecTot = 0,                     // symbols of the row (so that offsets[kRecLanes] closes the last record)
-  kRecEnd = 1,                     // where the chain ends, bits from the row's first
-  kRecValid = 2,                   // 0: no records; 1: even records only; 3: all records and the channel index below
-  kRecRounds = 3,                  // diagnostics
-  kRecChanFirst = 4,               // [4] record that holds symbol c * plane (c = 1..3 in [5..7]; [4] = 0), [8]: symbol row_block - 1
-  kRecChanPos = 9,                 // [5] bit position of those five records
-  kRecDone = 14,                   // 1: a row kernel that works from the half-lane records has decoded the row
-  kRecQtr = 15,                    // 1: lane_qtr holds a boundary inside every half-lane (k_row_count_w)
-};
 
 struct DecStream {           // one Huffman stream (LRES or FRES) of one frame
   uint32_t payload_off;      // byte offset (in the packed stream) after the aligned tree
@@ -133,10 +117,11 @@ struct DecWs {
   uint8_t *low;              size_t plane_stride;
   // k_row_count -> k_dec_row_fused: per FRES row and lane the first owned token
   // (bits from the chunk start) and the exclusive prefix of the symbol counts.
-  uint32_t *lane_start;      // [f][rows][kRecLanes]
-  uint32_t *lane_off;        // [f][rows][kRecLanes + kRecHdr]: offsets, then the header (RecHdr)
-  uint32_t *lane_qtr;        // [f][rows][kRecLanes]: per half-lane record a boundary near its middle: bits behind the
-                             // record's position [11:0] | symbols in front of it [31:12] (two chains per half-lane)
+  uint32_t *lane_start;      // [f][rows][kDecThreads]
+  uint32_t *lane_off;        // [f][rows][kDecThreads + 4]: offsets, then total, chain end (bits), valid flag
+                             // (1: the lanes' ranges are divided at token boundaries and a consumer finishes its
+                             // range token by token; 3: k_row_count_w -- at boundaries of the WRITE pass's chain
+                             // of groups: a consumer that walks those groups from its start lands on its limit)
   uint32_t *parse_stats;     // [f][4] k_dec_parse phase cycles / 16
   uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
   uint32_t *rc_stats;        // [f][rows][8] k_row_count phase cycles / 16 (slowest wave)

@@ -116,7 +116,7 @@ struct himg_hip_ctx {
   int max_sub = 4096;      // HIMG_MAX_SUB_BITS: test knob, see Geom::max_sub
   int lead_bits = 96;      // HIMG_LEAD_BITS: tuning knob, see Geom::lead_bits
   int lres_serial = 0;     // HIMG_FORCE_LRES_SERIAL=1: test knob, see Geom::lres_serial
-  int count_wave = -1, emit_rows = -1, row_pair = -1;   // HIMG_OPT_COUNT_WAVE / _EMIT_ROWS / _ROW_PAIR (-1: by launch size)
+  int count_wave = -1, emit_rows = -1;   // HIMG_OPT_COUNT_WAVE / _EMIT_ROWS (-1: by launch size)
   // Batched host API: H2D of frame i+1, kernels of frame i and D2H of frame i-1 overlap
   // on three streams; staging is double buffered.
   struct Pipe {
@@ -204,7 +204,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->max_sub = 4096;
   g->lead_bits = 96;
   g->lres_serial = 0;
-  g->count_wave = g->row_pair = g->emit_rows = -1;
+  g->count_wave = g->emit_rows = -1;
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
   return true;
@@ -241,7 +241,6 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   }
   if (const char *e = std::getenv("HIMG_COUNT_WAVE")) ctx->count_wave = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_EMIT_ROWS")) ctx->emit_rows = atoi(e) ? 1 : 0;
-  if (const char *e = std::getenv("HIMG_ROW_PAIR")) ctx->row_pair = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_LEAD_BITS")) {
     const int v = std::atoi(e);
     if (v >= 0 && v <= 4096) ctx->lead_bits = v;
@@ -335,7 +334,6 @@ extern "C" int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value) {
   const int tri = value < 0 ? -1 : (value ? 1 : 0);
   if (option == HIMG_OPT_COUNT_WAVE) { ctx->count_wave = tri; return HIMG_OK; }
   if (option == HIMG_OPT_EMIT_ROWS) { ctx->emit_rows = tri; return HIMG_OK; }
-  if (option == HIMG_OPT_ROW_PAIR) { ctx->row_pair = tri; return HIMG_OK; }
   return fail(ctx, HIMG_ERR_ARG, "unknown option");
 }
 
@@ -474,7 +472,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_gyc.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
       !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 8) ||
-      !ctx->d_lane.reserve((size_t)batch * g.rows * (3 * himg_dev::kRecLanes + himg_dev::kRecHdr) * 4) ||
+      !ctx->d_lane.reserve((size_t)batch * g.rows * (2 * kDecThreads + 4) * 4) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
       !ctx->d_sizes.reserve((size_t)batch * 4) ||
@@ -486,8 +484,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.gyc = (uint32_t *)ctx->d_gyc.p;
   w.sub = (uint2 *)ctx->d_sub.p;
   w.lane_start = (uint32_t *)ctx->d_lane.p;
-  w.lane_off = w.lane_start + (size_t)batch * g.rows * himg_dev::kRecLanes;
-  w.lane_qtr = w.lane_off + (size_t)batch * g.rows * (himg_dev::kRecLanes + himg_dev::kRecHdr);
+  w.lane_off = w.lane_start + (size_t)batch * g.rows * kDecThreads;
   w.row_off = (uint32_t *)ctx->d_rows.p;
   w.row_len = w.row_off + (size_t)batch * g.rows;
   w.lres_sym = (uint8_t *)ctx->d_lres.p; w.lres_stride = lres;
@@ -611,7 +608,6 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   g.count_wave = ctx->count_wave;
-  g.row_pair = ctx->row_pair;
   if (g.rows + 1 > 65535 || batch * g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if ((in_stride & 3) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
     return fail(ctx, HIMG_ERR_ARG, "in_stride must be a multiple of 4; buffers 16-byte aligned");
@@ -625,14 +621,6 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   ctx->last_stream = s;
   rc = stage_sizes(ctx, h_sizes, batch, s);
   if (rc) return rc;
-  if (g.row_pair < 0) {
-    // The plane-pair row kernel stages a row's whole payload in LDS (68 KiB at most; denser
-    // rows are left to the whole-row kernel one by one): worth launching while the mean
-    // row is well below that.  The streams' sizes are known here.
-    size_t mx = 0;
-    for (int i = 0; i < batch; ++i) mx = std::max(mx, (size_t)h_sizes[i]);
-    g.row_pair = (double)mx / (double)g.rows <= 56.0 * 1024.0 ? 1 : 0;
-  }
   launch_decode(g, ctx->dec_ws, batch, (const uint8_t *)d_packed, in_stride,
                 (const uint32_t *)ctx->d_sizes.p, (uint8_t *)d_out, d_status, s, &ctx->prof,
                 ctx->allow_fused, ctx->use_side ? &ctx->dstr : nullptr, 0,
@@ -654,7 +642,6 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
   g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   g.count_wave = ctx->count_wave;
-  g.row_pair = ctx->row_pair;
   if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
   if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))
@@ -726,7 +713,6 @@ extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void
   g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   g.count_wave = ctx->count_wave;
-  g.row_pair = ctx->row_pair;
   if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
   if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))

@@ -1210,9 +1210,12 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
 // front of the window or inside it (win_span = window bytes + kWinGuard: one unsigned
 // compare), so the two dwords it touches stay inside [0, win_span + 8).
 constexpr uint32_t kWinGuard = 16;
+// chain: [bp, lim) is a stretch of k_row_count_w's chain of groups (lane_off's valid flag
+// 3): the groups taken from bp end exactly at lim, one loop without a token-by-token tail.
 template <bool CLIP = false>
 __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint32_t bp,
-                                           uint32_t lim, uint32_t op, uint8_t *lds_out, uint32_t win_span = 0) {
+                                           uint32_t lim, uint32_t op, uint8_t *lds_out, uint32_t win_span = 0,
+                                           bool chain = false) {
   bool bad = false;
   if (bp < lim) {
     rd.init(bp);
@@ -1250,6 +1253,11 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       op += ((y >> 10) & 511u) + extra;
       bp += adv + n;
     };
+    if (chain) {   // (uniform per row)
+      while (bp < lim) step();
+      if (tm != TM) step();
+      return !bad;
+    }
     while ((int)bp <= limk) step();
     if (tm != TM) step();
     while (bp < lim) {
@@ -1268,8 +1276,8 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
 // Returns false on a stream error; *end_bp = bit position where the block became
 // complete (~0u if it did not).
 // CLIP: as in lean_write; op and out_size then both count from the window's guard.
-template <bool CLIP = false, class RD = GReader>
-__device__ __forceinline__ bool exact_write(RD &rd, const GrpTables &t, uint32_t bp,
+template <bool CLIP = false>
+__device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uint32_t bp,
                                             uint32_t lim, uint32_t op, uint32_t out_size,
                                             uint8_t *lds_out, uint32_t *end_bp, uint32_t win_span = 0) {
   *end_bp = ~0u;
@@ -1289,10 +1297,10 @@ __device__ __forceinline__ bool exact_write(RD &rd, const GrpTables &t, uint32_t
     const int limk = (int)lim - kLutBits;
     uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
     while ((int)bp <= limk) {
-      const RD saved = rd;
+      const GReader saved = rd;
       uint32_t nbits, cnt, by;
       bool gbad = false;
-      lean_step<true, false, RD>(rd, t, false, &nbits, &cnt, &by, &gbad);
+      lean_step<true>(rd, t, false, &nbits, &cnt, &by, &gbad);
       if (gbad || !before(op + cnt, out_size)) { rd = saved; break; }
       if (!CLIP || op - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
         const unsigned long long v = (unsigned long long)by << (8u * (op & 3u));
@@ -1305,7 +1313,7 @@ __device__ __forceinline__ bool exact_write(RD &rd, const GrpTables &t, uint32_t
   }
   for (;;) {
     uint32_t nbits, cnt, by;
-    lean_step<true, false, RD>(rd, t, true, &nbits, &cnt, &by, &bad);
+    lean_step<true>(rd, t, true, &nbits, &cnt, &by, &bad);
     if (bad) return false;
     if (before(out_size, op + cnt)) return false;  // a zero run overruns the block
     if (by && (!CLIP || op - kWinGuard < win_span - kWinGuard)) lds_out[op] = (uint8_t)by;
@@ -1460,8 +1468,7 @@ struct PreLane {
 // LDS window `win` to `gout`.  Returns (to every lane) 0 when the stream is
 // accepted like UncompressStream accepts it (huffman_dec.cpp:361-417).
 // pre_start / pre_off (optional): the fixpoint of the stream's single chunk computed
-// beforehand by k_row_count (pre_off[kRecLanes + kRecValid] != 0 says it is usable; lane t's
-// records are the even ones, 2 t).
+// beforehand by k_row_count (pre_off[kDecThreads + 2] != 0 says it is usable).
 // GLOBAL (with FUSED false): the output goes straight to `gout`, PRE-ZEROED global
 // memory, without the LDS window (win may be nullptr) -- the LRES serial fallback.
 template <bool FUSED, bool GLOBAL = false>
@@ -1504,9 +1511,10 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     // (k_row_count_w: the first GROUP boundary at or past the nominal one), and a lane
     // owns exactly the tokens in front of its neighbour's first.
     uint32_t wlim = lim;
-    const bool pre = cur == 0 && (pl ? pl->valid != 0 : (pre_off && pre_off[kRecLanes + kRecValid] != 0));
+    const uint32_t pre_valid = cur != 0 ? 0u : pl ? pl->valid : pre_off ? pre_off[kDecThreads + 2] : 0u;
+    const bool pre = pre_valid != 0, chain = pre_valid == 3u;
     if (pre) {
-      const uint32_t ns = pl ? pl->nstart : (tid + 1 < kDecThreads ? pre_start[2 * tid + 2] : ~0u);
+      const uint32_t ns = pl ? pl->nstart : (tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u);
       wlim = ns < rel_end - rel0 ? rel0 + ns : rel_end;
     }
     if (pre && pl) {
@@ -1519,13 +1527,13 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
       st_rounds += pl->rounds;
     } else if (pre) {
       // One chunk, fixpoint done by k_row_count at twice the occupancy.
-      start = rel0 + pre_start[2 * tid];
-      off = pre_off[2 * tid];
-      const uint32_t nxt_off = pre_off[2 * tid + 2];   // [kRecLanes] holds the total
+      start = rel0 + pre_start[tid];
+      off = pre_off[tid];
+      const uint32_t nxt_off = pre_off[tid + 1];   // [kDecThreads] holds the total
       cnt = nxt_off - (uint32_t)off;
-      tot = pre_off[kRecLanes + kRecTot];
-      if (tid == last_active) endpos = rel0 + pre_off[kRecLanes + kRecEnd];
-      st_rounds += pre_off[kRecLanes + kRecRounds];
+      tot = pre_off[kDecThreads];
+      if (tid == last_active) endpos = rel0 + pre_off[kDecThreads + 1];
+      st_rounds += pre_off[kDecThreads + 3];
     } else {
       long long c_first = 0;
       lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false, lead_bits, &c_first);
@@ -1540,7 +1548,7 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     if (FUSED) {
       uint32_t end_bp = ~0u;
       if (inside) {
-        if (!lean_write(rd, tb, start, wlim, (uint32_t)opl, lds_out)) sh->err = 1;
+        if (!lean_write(rd, tb, start, wlim, (uint32_t)opl, lds_out, 0u, chain)) sh->err = 1;
       } else if (exact) {
         if (!exact_write(rd, tb, start, wlim, (uint32_t)opl, out_size, lds_out, &end_bp)) sh->err = 1;
       }
@@ -1633,10 +1641,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out_size = (uint32_t)g.row_block;
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
     if (use_row_count) {
-      pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes;
-      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr);
+      pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
       // use_row_count == 2: rows with a usable fixpoint were written by k_row_window.
-      if (use_row_count == 2 && pre_off[kRecLanes + kRecValid] != 0) return;
+      if (use_row_count == 2 && pre_off[kDecThreads + 2] != 0) return;
     }
   }
   load_dec_tables(ws, df, f, strm, &T);
@@ -2334,70 +2342,6 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
   (void)shift;
 }
 
-// The last step of a lane pair (transform_store_pair, k_dec_row_pair): lane half s holds
-// pixel rows 4s..4s+3 of all four channels of tile u (ch*[r*2+h]: row 4s+r, x = 4h..4h+3,
-// clamped bytes): colour inverse on packed pairs (ycbcr.cpp:54-82), two 16-byte stores per
-// pixel row.
-template <bool FULL4>
-__device__ __forceinline__ void finish_rows_pair(const Geom &g, const uint32_t ch0[8], const uint32_t ch1[8],
-                                                 const uint32_t ch2[8], const uint32_t ch3[8], int ycbcr, int u, int s,
-                                                 int v, uint8_t *img) {
-  const int C = FULL4 ? 4 : g.C;
-    const int bw = FULL4 ? 8 : min(8, g.W - 8 * u);
-    const int bh = FULL4 ? 8 : min(8, g.H - 8 * v);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int y = 4 * s + rr;
-      uint32_t px[8];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const uint32_t q0 = ch0[rr * 2 + h], q1 = ch1[rr * 2 + h], q2 = ch2[rr * 2 + h], q3 = ch3[rr * 2 + h];
-        if (ycbcr) {  // ycbcr.cpp:54-82, two pixels per packed op
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const uint32_t sel = k ? 0x0c030c02u : 0x0c010c00u;
-            const dpk16 yy = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q0, sel));
-            const dpk16 cbq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q1, sel));
-            const dpk16 crq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q2, sel));
-            const dpk16 c255 = {255, 255}, c254 = {254, 254}, one = {1, 1};
-            const dpk16 cbv = cbq + cbq - c255, crv = crq + crq - c255;
-            // (cbv + crv + 2) >> 2 == (cb + cr - 254) >> 1 exactly.
-            const dpk16 gg = yy - ((cbq + crq - c254) >> one);
-            const uint32_t rs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + crv)));
-            const uint32_t gs = sat_pk_u8(__builtin_bit_cast(uint32_t, gg));
-            const uint32_t bs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + cbv)));
-            const uint32_t rg = __builtin_amdgcn_perm(gs, rs, 0x05010400u);            // r0 g0 r1 g1
-            const uint32_t ba = __builtin_amdgcn_perm(q3, bs, k ? 0x07010600u : 0x05010400u);  // b0 a0 b1 a1
-            px[4 * h + 2 * k] = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
-            px[4 * h + 2 * k + 1] = __builtin_amdgcn_perm(ba, rg, 0x07060302u);
-          }
-        } else {
-          const uint32_t t0 = __builtin_amdgcn_perm(q1, q0, 0x05010400u), t1 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
-          const uint32_t w0 = __builtin_amdgcn_perm(q3, q2, 0x05010400u), w1 = __builtin_amdgcn_perm(q3, q2, 0x07030602u);
-          px[4 * h + 0] = __builtin_amdgcn_perm(w0, t0, 0x05040100u);
-          px[4 * h + 1] = __builtin_amdgcn_perm(w0, t0, 0x07060302u);
-          px[4 * h + 2] = __builtin_amdgcn_perm(w1, t1, 0x05040100u);
-          px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
-        }
-      }
-      if (FULL4 || y < bh) {
-        uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * C;
-        if (FULL4 || (C == 4 && bw == 8)) {
-          uint4 o0, o1;
-          o0.x = px[0]; o0.y = px[1]; o0.z = px[2]; o0.w = px[3];
-          o1.x = px[4]; o1.y = px[5]; o1.z = px[6]; o1.w = px[7];
-          reinterpret_cast<uint4 *>(dst)[0] = o0;
-          reinterpret_cast<uint4 *>(dst)[1] = o1;
-        } else {
-#pragma unroll
-          for (int x = 0; x < 8; ++x)
-            if (x < bw)
-              for (int c = 0; c < C; ++c) dst[x * C + c] = (uint8_t)(px[x] >> (8 * c));
-        }
-      }
-    }
-}
-
 // One lane of a lane pair (lanes l and l + 32 of a wave: each half-wave then reads
 // 32 adjacent symbol bytes of ONE plane per LDS instruction, free of bank
 // conflicts): lane s transforms channels 2s and 2s+1 of tile u in block row v
@@ -2464,7 +2408,59 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
       ch0[i] = ra[0]; ch2[i] = ra[1];
       ch1[i] = rb[0]; ch3[i] = rb[1];
     }
-    finish_rows_pair<FULL4>(g, ch0, ch1, ch2, ch3, ycbcr, u, s, v, img);
+    const int bw = FULL4 ? 8 : min(8, g.W - 8 * u);
+    const int bh = FULL4 ? 8 : min(8, g.H - 8 * v);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int y = 4 * s + rr;
+      uint32_t px[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t q0 = ch0[rr * 2 + h], q1 = ch1[rr * 2 + h], q2 = ch2[rr * 2 + h], q3 = ch3[rr * 2 + h];
+        if (ycbcr) {  // ycbcr.cpp:54-82, two pixels per packed op
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const uint32_t sel = k ? 0x0c030c02u : 0x0c010c00u;
+            const dpk16 yy = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q0, sel));
+            const dpk16 cbq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q1, sel));
+            const dpk16 crq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q2, sel));
+            const dpk16 c255 = {255, 255}, c254 = {254, 254}, one = {1, 1};
+            const dpk16 cbv = cbq + cbq - c255, crv = crq + crq - c255;
+            // (cbv + crv + 2) >> 2 == (cb + cr - 254) >> 1 exactly.
+            const dpk16 gg = yy - ((cbq + crq - c254) >> one);
+            const uint32_t rs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + crv)));
+            const uint32_t gs = sat_pk_u8(__builtin_bit_cast(uint32_t, gg));
+            const uint32_t bs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + cbv)));
+            const uint32_t rg = __builtin_amdgcn_perm(gs, rs, 0x05010400u);            // r0 g0 r1 g1
+            const uint32_t ba = __builtin_amdgcn_perm(q3, bs, k ? 0x07010600u : 0x05010400u);  // b0 a0 b1 a1
+            px[4 * h + 2 * k] = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+            px[4 * h + 2 * k + 1] = __builtin_amdgcn_perm(ba, rg, 0x07060302u);
+          }
+        } else {
+          const uint32_t t0 = __builtin_amdgcn_perm(q1, q0, 0x05010400u), t1 = __builtin_amdgcn_perm(q1, q0, 0x07030602u);
+          const uint32_t w0 = __builtin_amdgcn_perm(q3, q2, 0x05010400u), w1 = __builtin_amdgcn_perm(q3, q2, 0x07030602u);
+          px[4 * h + 0] = __builtin_amdgcn_perm(w0, t0, 0x05040100u);
+          px[4 * h + 1] = __builtin_amdgcn_perm(w0, t0, 0x07060302u);
+          px[4 * h + 2] = __builtin_amdgcn_perm(w1, t1, 0x05040100u);
+          px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
+        }
+      }
+      if (FULL4 || y < bh) {
+        uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * C;
+        if (FULL4 || (C == 4 && bw == 8)) {
+          uint4 o0, o1;
+          o0.x = px[0]; o0.y = px[1]; o0.z = px[2]; o0.w = px[3];
+          o1.x = px[4]; o1.y = px[5]; o1.z = px[6]; o1.w = px[7];
+          reinterpret_cast<uint4 *>(dst)[0] = o0;
+          reinterpret_cast<uint4 *>(dst)[1] = o1;
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; ++x)
+            if (x < bw)
+              for (int c = 0; c < C; ++c) dst[x * C + c] = (uint8_t)(px[x] >> (8 * c));
+        }
+      }
+    }
 }
 
 // tile_plane's identity test, by one wavefront (l = 0..63).  n = the largest code with
@@ -2565,12 +2561,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint32_t pre_lr[4] = {0, 0, 0, 0}, pre_off0 = 0, pre_len0 = 0;
   if constexpr (COLS == 512) {
     const size_t ri = (size_t)f * g.rows + (size_t)(r0 + (int)blockIdx.x);
-    const uint32_t *ps = ws.lane_start + ri * kRecLanes, *po = ws.lane_off + ri * (kRecLanes + kRecHdr);
-    if (po[kRecLanes + kRecDone]) return;   // k_dec_row_pair has decoded this row (wave-uniform: one scalar load)
-    pl.start = ps[2 * tid]; pl.off = po[2 * tid]; pl.nxt = po[2 * tid + 2];
-    pl.nstart = tid + 1 < kDecThreads ? ps[2 * tid + 2] : ~0u;
-    pl.tot = po[kRecLanes + kRecTot]; pl.endrel = po[kRecLanes + kRecEnd]; pl.valid = po[kRecLanes + kRecValid];
-    pl.rounds = po[kRecLanes + kRecRounds];
+    const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + 4);
+    pl.start = ps[tid]; pl.off = po[tid]; pl.nxt = po[tid + 1];
+    pl.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
+    pl.tot = po[kDecThreads]; pl.endrel = po[kDecThreads + 1]; pl.valid = po[kDecThreads + 2]; pl.rounds = po[kDecThreads + 3];
     pre_off0 = ws.row_off[ri]; pre_len0 = ws.row_len[ri];
     const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + (int)blockIdx.x;
     const int u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
@@ -2642,8 +2636,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
         p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
         (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, nullptr, nullptr,
         ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
-        ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes,
-        ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr));
+        ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
+        ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
   };
   int bad = 0;
   if constexpr (COLS == 512) {
@@ -2746,13 +2740,13 @@ __device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, Strea
   // block in the write pass and is rejected there like before.
   uint32_t tot;
   const uint32_t off = block_scan_u32d(min(cnt, 0x3fffffu), sm32, &tot);
-  l_start[2 * tid] = start - rel0;   // (the even records: whole lanes)
-  l_off[2 * tid] = off;
-  if (tid == last_active) l_off[kRecLanes + kRecEnd] = endpos - rel0;
+  l_start[tid] = start - rel0;
+  l_off[tid] = off;
+  if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
   if (tid == 0) {
-    l_off[kRecLanes + kRecTot] = tot;
-    l_off[kRecLanes + kRecRounds] = rounds | (min(sh->dbg[0], 4095u) << 8) | (min(sh->dbg[1], 4095u) << 20);
-    l_off[kRecLanes + kRecValid] = 1;   // (no fence: the consumer is a later kernel)
+    l_off[kDecThreads] = tot;
+    l_off[kDecThreads + 3] = rounds | (min(sh->dbg[0], 4095u) << 8) | (min(sh->dbg[1], 4095u) << 20);
+    l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
   }
   if ((tid & 63) == 0 && rc) {   // cycles / 16, slowest wave of the workgroup
     atomicMax(&rc[0], (uint32_t)((c_fix0 - c_in) >> 4));            // tables / payload staging
@@ -2813,10 +2807,10 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
   const int rb = r0 + (int)blockIdx.x * rows_per_wg;
   for (int r = rb; r < min(rb + rows_per_wg, r1); ++r) {
     const long long c_in = clock64();
-    uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes;
-    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr);
+    uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
     uint32_t *rc = ws.rc_stats ? ws.rc_stats + ((size_t)f * g.rows + r) * 8 : nullptr;
-    if (tid == 0) { l_off[kRecLanes + kRecValid] = 0; l_off[kRecLanes + kRecDone] = 0; sh.dbg[0] = sh.dbg[1] = 0; }   // not usable until proven otherwise
+    if (tid == 0) { l_off[kDecThreads + 2] = 0; sh.dbg[0] = sh.dbg[1] = 0; }   // not usable until proven otherwise
     const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
     const unsigned long long rem = 8ull * pay_len;
     uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
@@ -2971,9 +2965,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
       const uint4 q = gg[k];
       reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);   // bytes / long-code descriptors
       // The step words of the WRITE pass's groups (at most four output bytes), not the
-      // count-only ones: the row kernels then follow exactly this kernel's chain of
-      // groups and land on every recorded boundary without a token-by-token tail
-      // (0.5 % more steps here than with the longer count-only groups).
+      // count-only ones: a row kernel that walks those groups from a lane's recorded start
+      // follows exactly this kernel's chain and lands on the next lane's start -- no
+      // token-by-token tail there (1.3 % more steps here than with the longer groups).
       reinterpret_cast<uint2 *>(gy)[k] = make_uint2(q.y, q.w);
     }
     const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
@@ -2989,11 +2983,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   const int r = r0 + (int)blockIdx.x * kCountRowsW + (tid >> 6);
   if (r >= r1) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
-  uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kRecLanes;
-  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kRecLanes + kRecHdr);
-  if (lane < kRecHdr) {   // not usable until proven otherwise; a boundary nobody reaches: no record
-    l_off[kRecLanes + lane] = (lane >= kRecChanFirst + 1 && lane < kRecChanFirst + 5) ? ~0u : 0u;
-  }
+  uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
+  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+  if (lane == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
   const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
   const unsigned long long rem64 = 8ull * pay_len;
   uint32_t sb = (uint32_t)((rem64 + kDecThreads - 1) / kDecThreads);
@@ -3006,13 +2998,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   const uint32_t rel0 = rd.attach(p, sizes[f], 8ull * pay_off);
   const uint32_t rel_end = rel0 + rem;
   const uint32_t lead = (uint32_t)g.lead_bits;
-  // The symbols whose records the plane-pair row kernel looks up (k_dec_row_pair):
-  // the first symbol of channel planes 1.. and the block's last symbol.
-  const uint32_t plane = (uint32_t)g.row_block / (uint32_t)(g.C > 0 ? g.C : 1);
   uint32_t first = rel0;   // where the phase's first lane starts: exact
   uint32_t base = 0;       // symbols in front of the phase
   uint32_t rounds = 0;
-  int qbad = 0;            // a boundary that does not fit lane_qtr's fields
   uint32_t *stage = s_stage + (tid >> 6) * kStageAlloc;
   LdsBits bits;
   bits.base = lds_addr(stage);
@@ -3025,10 +3013,8 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     const bool active = q.active;
     const uint32_t pb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.b0);   // the phase's first lane: its nominal start
     if (pb0 >= rel_end) {   // a phase beyond the payload: its lanes own nothing
-      l_start[2 * v] = rem; l_start[2 * v + 1] = rem;
-      l_off[2 * v] = base; l_off[2 * v + 1] = base;
-      uint32_t *l_qtr = ws.lane_qtr + ((size_t)f * g.rows + r) * kRecLanes;
-      l_qtr[2 * v] = 0; l_qtr[2 * v + 1] = 0;
+      l_start[v] = rem;
+      l_off[v] = base;
       continue;
     }
     // STAGED: positions below are relative to the dword `w0` of the reader's window, the
@@ -3079,41 +3065,19 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     // whose start moves in a later round walks up to T again, and if it arrives at the
     // same boundary everything behind is what it already has.  A round after the first
     // then costs the wavefront kJoinBits instead of a whole sub-sequence.
-    // The walk is cut once more at M, the middle of the range: the boundary and the count
-    // there are the lane's second record (the channel-by-channel row kernel walks half
-    // ranges: twice as many lanes at work in its write passes).
     uint32_t T = (active ? b0 : rel_end - shift) + kJoinBits;
     if (T > lim || T < b0) T = lim;
-    uint32_t M = (active ? b0 : rel_end - shift) + ((lim - b0) >> 1);
-    if (M < T || !active) M = T;
-    // ... and inside either half (lane_qtr: the row kernel walks a half-lane as two chains).
-    uint32_t Q1 = (active ? b0 : M) + ((M - b0) >> 1), Q3 = M + ((lim - M) >> 1);
-    if (Q1 < T || !active) Q1 = T;
-    if (Q1 > M) Q1 = M;
-    if (!active) Q3 = M;
-    uint32_t posT = ~0u, cT = 0, pm = start, midc = 0, pq1 = start, q1c = 0, pq3 = start, q3c = 0;
+    uint32_t posT = ~0u, cT = 0;
     for (;;) {
       if (dirty) {
         uint32_t p1, c1;
-        bool at = at_start;   // (register windows only: the reader stands at the walk's position)
-        walk(start, T, &p1, &c1, at);
-        at = at || start < T;
+        walk(start, T, &p1, &c1, at_start);
         if (p1 == posT) {
-          const uint32_t d = c1 - cT;
-          cnt += d; midc += d; q1c += d;   // (q3c counts from the middle: unchanged)
+          cnt = c1 + (cnt - cT);
         } else {
-          uint32_t c2, c3, c4, c5;
-          walk(p1, Q1, &pq1, &c2, at);
-          at = at || p1 < Q1;
-          walk(pq1, M, &pm, &c3, at);
-          at = at || pq1 < M;
-          walk(pm, Q3, &pq3, &c4, at);
-          at = at || pm < Q3;
-          walk(pq3, lim, &endpos, &c5, at);
-          q1c = c1 + c2;
-          midc = q1c + c3;
-          q3c = c4;
-          cnt = midc + c4 + c5;
+          uint32_t c2;
+          walk(p1, lim, &endpos, &c2, start < T || at_start);
+          cnt = c1 + c2;
         }
         posT = p1;
         cT = c1;
@@ -3127,15 +3091,6 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
       ++rounds;
       if (!__any(dirty ? 1 : 0)) break;
     }
-    if (!active) { pm = start; midc = 0; pq1 = start; q1c = 0; pq3 = start; q3c = 0; }
-    {
-      // The boundary inside either half: bits behind the half's record | symbols in front << 12.
-      const uint32_t d1 = pq1 - start, d3 = pq3 - pm;
-      if (d1 >= 4096u || d3 >= 4096u || q1c >= (1u << 20) || q3c >= (1u << 20)) qbad = 1;
-      uint32_t *l_qtr = ws.lane_qtr + ((size_t)f * g.rows + r) * kRecLanes;
-      l_qtr[2 * v] = (d1 & 4095u) | (q1c << 12);
-      l_qtr[2 * v + 1] = (d3 & 4095u) | (q3c << 12);
-    }
     // Exclusive prefix of the counts (k_row_count's clamp: see row_count_one).
     const uint32_t c = min(cnt, 0x3fffffu);
     uint32_t incl = c;
@@ -3144,18 +3099,9 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
       const uint32_t t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    const uint32_t o0 = base + incl - c, o1 = o0 + min(midc, c), o2 = base + incl;
-    const uint32_t s0 = start + shift - rel0, s1 = pm + shift - rel0;
-    l_start[2 * v] = s0; l_start[2 * v + 1] = s1;
-    l_off[2 * v] = o0; l_off[2 * v + 1] = o1;
-    if (v == q.last_active) l_off[kRecLanes + kRecEnd] = endpos + shift - rel0;
-    // The records that hold the first symbol of a channel plane / the block's last symbol.
-#pragma unroll
-    for (int k = 1; k <= 4; ++k) {
-      const uint32_t X = k < 4 ? (uint32_t)k * plane : (uint32_t)g.row_block - 1u;
-      if (o0 <= X && X < o1) { l_off[kRecLanes + kRecChanFirst + k] = 2u * (uint32_t)v; l_off[kRecLanes + kRecChanPos + k] = s0; }
-      if (o1 <= X && X < o2) { l_off[kRecLanes + kRecChanFirst + k] = 2u * (uint32_t)v + 1u; l_off[kRecLanes + kRecChanPos + k] = s1; }
-    }
+    l_start[v] = start + shift - rel0;
+    l_off[v] = base + incl - c;
+    if (v == q.last_active) l_off[kDecThreads + 1] = endpos + shift - rel0;
     base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     // The next phase starts where this one's last lane ended (a phase of inactive lanes: nowhere).
     first = (uint32_t)__builtin_amdgcn_readlane((int)(active ? endpos + shift : rel_end), 63);
@@ -3163,12 +3109,10 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   };
   if (sb <= kStageSubBits) phases(std::true_type{});
   else phases(std::false_type{});
-  const int any_qbad = __any(qbad);
   if (lane == 0) {
-    l_off[kRecLanes + kRecTot] = base;
-    l_off[kRecLanes + kRecRounds] = rounds;
-    l_off[kRecLanes + kRecQtr] = any_qbad ? 0u : 1u;
-    l_off[kRecLanes + kRecValid] = 3;   // (no fence: the consumer is a later kernel)
+    l_off[kDecThreads] = base;
+    l_off[kDecThreads + 3] = rounds;
+    l_off[kDecThreads + 2] = 3;   // boundaries of the write pass's chain of groups (no fence: the consumer is a later kernel)
   }
 }
 
@@ -3195,11 +3139,11 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
   const int wi = blockIdx.x, r = r0 + (int)blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   const size_t ri = (size_t)f * g.rows + r;
-  const uint32_t *pre_start = ws.lane_start + ri * kRecLanes, *pre_off = ws.lane_off + ri * (kRecLanes + kRecHdr);
+  const uint32_t *pre_start = ws.lane_start + ri * kDecThreads, *pre_off = ws.lane_off + ri * (kDecThreads + 4);
   // Everything from global memory in front of the first barrier.
-  const uint32_t st_rel = pre_start[2 * tid], off = pre_off[2 * tid], nxt = pre_off[2 * tid + 2];
-  const uint32_t nst_rel = tid + 1 < kDecThreads ? pre_start[2 * tid + 2] : ~0u;   // the lane walks to its neighbour's start
-  const uint32_t tot = pre_off[kRecLanes + kRecTot], usable = pre_off[kRecLanes + kRecValid];
+  const uint32_t st_rel = pre_start[tid], off = pre_off[tid], nxt = pre_off[tid + 1];
+  const uint32_t nst_rel = tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u;   // the lane walks to its neighbour's start
+  const uint32_t tot = pre_off[kDecThreads], usable = pre_off[kDecThreads + 2];
   const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
   if (tid == 0) { sh.flag = (df->status || usable == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
   load_dec_tables(ws, df, f, 1, &T);
@@ -3229,7 +3173,7 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
     uint32_t end_bp = ~0u;
     const uint32_t op = off - w0 + kWinGuard;
     if (inside) {
-      if (!lean_write<true>(rd, tb, rel0 + st_rel, lim, op, win, span)) sh.err = 1;
+      if (!lean_write<true>(rd, tb, rel0 + st_rel, lim, op, win, span, usable == 3u)) sh.err = 1;
     } else if (exact) {
       if (!exact_write<true>(rd, tb, rel0 + st_rel, lim, op, rel_out, win, &end_bp, span)) sh.err = 1;
       if (end_bp != ~0u) sh.endbit = (unsigned long long)(end_bp - rel0);
@@ -3250,323 +3194,6 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
     if (bad) atomicMax(&df->status, fmt_err(7, 1));
   } else if (tid == 0 && sh.err) {
     atomicMax(&df->status, fmt_err(7, 1));
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_dec_row_pair: one block row of a 4096-pixel RGBA frame per 1024-lane workgroup, in TWO
-// passes over channel-plane pairs (the row's symbols are channel-major, encoder.cpp:320-323),
-// from k_row_count_w's half-lane records:
-//   * only 64 KiB of symbols are resident at a time, so the row's whole PAYLOAD fits in LDS
-//     beside them (blocks of 33 dwords, see LdsBits) and a step fetches its 32 stream bits on
-//     demand -- 26 vector instructions per step where k_dec_row_fused's register window
-//     needs 38 (its refill is paid by the whole wavefront on every step);
-//   * a pass walks the 1024 half-lanes whose symbols fall into its two planes, one per lane,
-//     each as TWO chains (lane_qtr: a boundary inside every half-lane): the walk is a
-//     dependent chain -- window read, table read, next position -- and at four wavefronts
-//     per SIMD it is bound by that latency, not by issue; two independent chains per lane
-//     hide it;
-//   * the walks follow k_row_count_w's chain of groups (same table, same starts) and land on
-//     every recorded boundary: no token-by-token tails; only the half-lane in which the
-//     block completes goes token by token, with the reference's end-of-block checks.
-// Transform and stores are k_dec_row_fused's (tile_plane, finish_rows_pair): in pass p lane
-// half s of a lane pair transforms plane 2 p + s of its tile.
-// Rows without full records, or with more payload than the staging area holds, are left to
-// k_dec_row_fused (kRecDone stays 0).
-// ---------------------------------------------------------------------------
-constexpr uint32_t kChanPlane = 32768;                                                // symbols of one channel plane (512 tiles)
-constexpr uint32_t kPairStageWords = 17408;                                           // payload dwords the staging area holds (544 blocks of 32)
-constexpr uint32_t kPairStageAlloc = (kPairStageWords + kPairStageWords / 32u + 3u) & ~3u;
-struct PairShared { int flag, err; unsigned long long endbit; uint32_t npos; };
-struct PairLayout {
-  static constexpr uint32_t tab = 0;                                                  // uint2 grp[kTabEntries]
-  static constexpr uint32_t sym = tab + (uint32_t)kTabEntries * 8u;                   // guard + two planes + guard
-  static constexpr uint32_t stage = sym + 2u * kChanPlane + 64u;
-  static constexpr uint32_t unmap = stage + kPairStageAlloc * 4u;
-  static constexpr uint32_t shift = unmap + 512u;
-  static constexpr uint32_t shiftp = shift + 128u;
-  static constexpr uint32_t sh = shiftp + 288u;
-  static constexpr uint32_t total = sh + 64u;
-};
-static_assert(PairLayout::total <= 160u * 1024u, "the LDS of one CU");
-
-// Reader over the padded staging layout (register window; the exact path only).
-struct PaddedLds {
-  uint32_t base;
-  __device__ __forceinline__ uint32_t operator[](uint32_t j) const { return lds_ld32(base + ((j + (j >> 5)) << 2)); }
-};
-typedef ReaderT<PaddedLds> PReader;
-
-// Two chains of groups per lane, [pa, la) to op `opa` and [pb, lb) to `opb` -- la / lb
-// boundaries of the same chains (k_row_count_w's records) -- from the staged payload into the
-// clipped planes in LDS: lean_write<true>'s step over an LdsBits, twice per iteration and
-// interleaved, so that one chain's LDS round trips hide behind the other's arithmetic.
-__device__ __forceinline__ bool grp_write2_lds(const LdsBits &bits, const GrpTables &t, uint32_t pa, uint32_t la,
-                                               uint32_t opa, uint32_t pb, uint32_t lb, uint32_t opb,
-                                               uint8_t *lds_out, uint32_t win_span) {
-  bool bad = false;
-  uint32_t *o32 = reinterpret_cast<uint32_t *>(lds_out);
-  const uint32_t TM = ((1u << kLutBits) - 1u) << 3, TB = lds_addr(t.grp);
-  uint32_t tma = TM, tba = TB, tmb = TM, tbb = TB;   // the table either chain's next step indexes (long codes: two steps)
-  // A step whose table word is 0: the first half of a code longer than the table (the next
-  // step indexes its second-level table), or the tree walk.
-  auto resolve = [&](uint32_t &y, uint32_t &by, uint32_t &win, uint32_t &pos, uint32_t tm, uint32_t &ntm, uint32_t &ntb) {
-    if ((by >> 31) && tm == TM) {
-      ntm = ((1u << (by & 255u)) - 1u) << 3;
-      ntb = TB + (((1u << kLutBits) + ((by >> 8) & 0xffffu)) << 3);
-      y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
-      by = 0;
-    } else {
-      BitWin64 rd;
-      rd.win = (unsigned long long)win | ((unsigned long long)bits.window(pos + 32u) << 32);
-      const int base = tm == TM ? 0 : kLutBits;
-      uint32_t len;
-      y = walk_token(rd, t, by, base, &len, &by, &bad);
-      pos += len - (uint32_t)base;
-      win = bits.window(pos);
-    }
-  };
-  while (pa < la || pb < lb) {
-    const bool A = pa < la, B = pb < lb;
-#ifdef HIMG_X_NOWIN
-    uint32_t wa = pa * 2654435761u, wb = pb * 2654435761u;
-#else
-    uint32_t wa = bits.window(pa), wb = bits.window(pb);
-#endif
-    const uint2 ea = lds_ld64(((wa << 3) & tma) + tba), eb = lds_ld64(((wb << 3) & tmb) + tbb);
-    uint32_t ya = ea.y, bya = ea.x, yb = eb.y, byb = eb.x;
-    uint32_t ntma = TM, ntba = TB, ntmb = TM, ntbb = TB;
-    if (__builtin_expect(A && ya == 0, 0)) resolve(ya, bya, wa, pa, tma, ntma, ntba);
-    if (__builtin_expect(B && yb == 0, 0)) resolve(yb, byb, wb, pb, tmb, ntmb, ntbb);
-    tma = ntma; tba = ntba; tmb = ntmb; tbb = ntbb;
-    const uint32_t xa = __builtin_amdgcn_ubfe(wa, ya, ya >> 5), xb = __builtin_amdgcn_ubfe(wb, yb, yb >> 5);
-#ifndef HIMG_X_NOOR
-#ifdef HIMG_X_ONEOR
-    if (A && opa - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) atomicOr(&o32[opa >> 2], bya);
-    if (B && opb - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) atomicOr(&o32[opb >> 2], byb);
-#else
-    if (A && opa - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
-      const unsigned long long v = (unsigned long long)bya << (8u * (opa & 3u));
-      atomicOr(&o32[opa >> 2], (uint32_t)v);
-      atomicOr(&o32[(opa >> 2) + 1], (uint32_t)(v >> 32));
-    }
-    if (B && opb - (kWinGuard - 8u) < win_span - (kWinGuard - 8u)) {
-      const unsigned long long v = (unsigned long long)byb << (8u * (opb & 3u));
-      atomicOr(&o32[opb >> 2], (uint32_t)v);
-      atomicOr(&o32[(opb >> 2) + 1], (uint32_t)(v >> 32));
-    }
-#endif
-#endif
-    if (A) { pa += ya >> 27; opa += ((ya >> 10) & 511u) + xa; }
-    if (B) { pb += yb >> 27; opb += ((yb >> 10) & 511u) + xb; }
-  }
-  return !bad;
-}
-
-template <int COLS>
-__global__ __launch_bounds__(kDecThreads) void k_dec_row_pair(Geom g, DecWs ws, const uint8_t *packed,
-                                                              size_t in_stride, const uint32_t *sizes,
-                                                              uint8_t *out_frames, int r0) {
-  static_assert(COLS == 512, "two lanes per tile, 32 KiB planes");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint2 *s_grp = reinterpret_cast<uint2 *>(smem + PairLayout::tab);
-  uint8_t *s_sym = smem + PairLayout::sym;                       // kWinGuard bytes, the two planes, the rest of the guard
-  uint32_t *s_stage = reinterpret_cast<uint32_t *>(smem + PairLayout::stage);
-  int16_t *s_unmap = reinterpret_cast<int16_t *>(smem + PairLayout::unmap);
-  uint8_t *s_shift = smem + PairLayout::shift;
-  uint32_t *s_shiftp = reinterpret_cast<uint32_t *>(smem + PairLayout::shiftp);
-  PairShared *sh = reinterpret_cast<PairShared *>(smem + PairLayout::sh);
-
-  const int f = blockIdx.y, tid = threadIdx.x, v = r0 + (int)blockIdx.x;
-  const long long c_in = clock64();
-  DecFrame *df = ws.frames + f;
-  const size_t ri = (size_t)f * g.rows + (size_t)v;
-  const uint32_t *ps = ws.lane_start + ri * kRecLanes, *pq = ws.lane_qtr + ri * kRecLanes;
-  uint32_t *po = ws.lane_off + ri * (kRecLanes + kRecHdr);
-  const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
-  // The row's header (wave-uniform loads) and everything else the first pass needs from
-  // global memory, all requested in front of the first barrier.
-  const uint32_t valid = po[kRecLanes + kRecValid], qtr = po[kRecLanes + kRecQtr], tot = po[kRecLanes + kRecTot];
-  const uint32_t h_mid = po[kRecLanes + kRecChanFirst + 2];    // the record that holds the first symbol of plane 2
-  const uint32_t h_last = po[kRecLanes + kRecChanFirst + 4];   // ... the block's last symbol
-  const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
-  const uint8_t *p = packed + (size_t)f * in_stride;
-  // The payload as dwords: bit `rel0 + x` of wbase[] is bit x of the row.
-  const uint32_t *wbase = reinterpret_cast<const uint32_t *>(p + (pay_off & ~3u));
-  const uint32_t rel0 = 8u * (pay_off & 3u);
-  const uint32_t jmax = ((ssize - 1u) >> 2) - (pay_off >> 2);
-  const uint32_t rem = 8u * pay_len, out_size = (uint32_t)g.row_block;
-  // Dwords to stage: the payload, what the walks may read behind it (a step two dwords at
-  // its position, the tree-walk path 32 bits further, the exact path's register window
-  // three dwords ahead).
-  const uint32_t need_words = ((rel0 + rem + 160u) >> 5) + 4u;
-  if (tid == 0) {
-    sh->flag = (df->status || valid != 3u || qtr == 0u || need_words > kPairStageWords || pay_len > (1u << 20)) ? 1 : 0;
-    sh->err = 0; sh->endbit = ~0ull;
-  }
-  auto ldw = [&](uint32_t j) { return wbase[j < jmax ? j : jmax]; };
-
-  // What a pass needs per lane: a half-lane record, the next one (where its walk and its
-  // symbols end), the boundary inside it, and the low-res corners of the lane's tile in
-  // the plane it transforms.
-  struct PassIn { uint32_t pos0, pos1, off0, off1, q, lr; };
-  const int u = pair_tile(tid), s = pair_half(tid);
-  const int u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
-  auto request = [&](int plane, uint32_t hs, PassIn *in, bool with_lr) {
-    const uint32_t h = hs + (uint32_t)tid;
-    const bool live = h < (uint32_t)kRecLanes;
-    in->pos0 = live ? ps[h] : rem;
-    in->pos1 = h + 1u < (uint32_t)kRecLanes ? ps[h + 1u] : rem;
-    in->off0 = live ? po[h] : tot;
-    in->off1 = live ? po[h + 1u] : tot;   // (po[kRecLanes] is the total)
-    in->q = live ? pq[h] : 0u;
-    if (with_lr) {
-      const uint8_t *m = low + (size_t)plane * g.rows * COLS;
-      in->lr = (uint32_t)m[(size_t)v * COLS + u] | ((uint32_t)m[(size_t)v * COLS + u2] << 8) |
-               ((uint32_t)m[(size_t)v2 * COLS + u] << 16) | ((uint32_t)m[(size_t)v2 * COLS + u2] << 24);
-    }
-  };
-  PassIn cur;
-  request(s, 0u, &cur, true);
-  // The decode tables (group table and second-level table in the write pass's interleaved
-  // form; the tree nodes stay in global memory: only codes longer than both tables reach
-  // them) and the dequantiser's tables.
-  {
-    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
-    const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
-    const uint4 t0 = gg[tid];
-    uint4 t1 = make_uint4(0, 0, 0, 0);
-    if (tid < kSubEntries / 2) t1 = gs[tid];
-    reinterpret_cast<uint4 *>(s_grp)[tid] = t0;
-    if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(s_grp + (1 << kLutBits))[tid] = t1;
-  }
-  if (tid < 256) {
-    const int sc = (int8_t)tid;
-    s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
-  } else if (tid < 384) {
-    s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
-  } else if (tid < 448) {
-    const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
-    s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
-  } else if (tid < 512) {
-    identity_test_words(df, tid - 448, s_shiftp + 64);
-  }
-  const int ycbcr = df->ycbcr;
-  // The row's payload -> LDS, 16 bytes per lane and step (blocks of 33 dwords, see LdsBits).
-  if (need_words <= kPairStageWords) {
-    for (uint32_t k = (uint32_t)tid; 4u * k < need_words; k += (uint32_t)kDecThreads) {
-      const uint32_t w = 4u * k;
-      uint4 x;
-      if (w + 3u <= jmax) {
-        const PackedU4 t4 = *reinterpret_cast<const PackedU4 *>(wbase + w);
-        x.x = t4.x; x.y = t4.y; x.z = t4.z; x.w = t4.w;
-      } else {
-        x.x = ldw(w); x.y = ldw(w + 1u); x.z = ldw(w + 2u); x.w = ldw(w + 3u);
-      }
-      uint32_t *d = s_stage + 4u * k + (k >> 3);
-      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
-      if ((k & 7u) == 0u && k) d[-1] = x.x;
-    }
-  }
-  GrpTables tb;
-  tb.grp = s_grp; tb.gx = nullptr; tb.gy = nullptr;
-  tb.nd = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1);
-  LdsBits bits;
-  bits.base = lds_addr(s_stage);
-
-  uint32_t QA[16], QB[16];
-  long long c_write = 0, c_xf = 0, c_walk = 0;
-  bool dead = false;
-  auto pass = [&](auto pc, uint32_t (&O)[16]) {
-    constexpr int P = decltype(pc)::value;
-    if (P > 0) __syncthreads();   // the transform of the pass before is done with the planes
-    {
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      for (uint32_t k = (uint32_t)tid; k < (2u * kChanPlane + 64u) / 16u; k += (uint32_t)kDecThreads) reinterpret_cast<uint4 *>(s_sym)[k] = z;
-    }
-    __syncthreads();
-    if (P == 0 && sh->flag) { dead = true; return; }   // (uniform; the frame failed, or the row is k_dec_row_fused's)
-    const long long c_w0 = clock64();
-    // The second pass's records: requested now, consumed behind this pass's walk.
-    PassIn nxt;
-    if (P == 0) request(2 + s, h_mid < (uint32_t)kRecLanes ? h_mid : (uint32_t)kRecLanes, &nxt, true);
-    // ---- the write pass of planes 2 P, 2 P + 1: rounds of 1024 consecutive half-lanes (one
-    // round, unless a pair of planes takes more than half of the row's half-lanes) ----
-    const uint32_t w0s = (uint32_t)P * 2u * kChanPlane, w1s = w0s + 2u * kChanPlane, span = 2u * kChanPlane + kWinGuard;
-    uint32_t hs = P == 0 ? 0u : h_mid;
-    const uint32_t he_raw = P == 0 ? h_mid : h_last;
-    const uint32_t he = he_raw < (uint32_t)kRecLanes ? he_raw : (uint32_t)kRecLanes - 1u;
-    bool have = true;   // `cur` holds this round's records
-    while (hs <= he) {
-      if (!have) request(0, hs, &cur, false);
-      const uint32_t h = hs + (uint32_t)tid;
-      const long long c_k0 = clock64();
-      if (h <= he) {
-        const uint32_t a = rel0 + cur.pos0, b = rel0 + cur.pos1;
-        const bool inside = cur.off1 < out_size, exact = !inside && cur.off0 < out_size;
-        const bool touches = cur.off1 > cur.off0 && cur.off0 < w1s && cur.off1 > w0s;
-        const uint32_t op = cur.off0 - w0s + kWinGuard;
-        if (inside && touches) {
-          const uint32_t m = a + (cur.q & 4095u);   // the boundary inside the half-lane: two chains
-          if (!grp_write2_lds(bits, tb, a, m, op, m, b, op + (cur.q >> 12), s_sym, span)) sh->err = 1;
-        } else if (exact && touches) {
-          PReader rd;
-          rd.w.base = bits.base;
-          rd.jmax = kPairStageWords - 1u;
-          uint32_t end_bp = ~0u;
-          if (!exact_write<true, PReader>(rd, tb, a, b, op, out_size - w0s + kWinGuard, s_sym, &end_bp, span)) sh->err = 1;
-          if (end_bp != ~0u) sh->endbit = (unsigned long long)(end_bp - rel0);
-        }
-      }
-      c_walk += clock64() - c_k0;
-      hs += (uint32_t)kDecThreads;
-      have = false;
-    }
-    __syncthreads();   // the planes are complete
-    const long long c_x0 = clock64();
-    c_write += c_x0 - c_w0;
-    // ---- the transform: lane half s of a lane pair takes plane 2 P + s of tile u ----
-    {
-      const int c = 2 * P + s;
-      const int chroma = (ycbcr && (c == 1 || c == 2)) ? 1 : 0;   // decoder.cpp:376
-      tile_plane<COLS>(s_sym + kWinGuard + (uint32_t)s * kChanPlane + u, COLS, s_unmap, s_shift + chroma * 64,
-                       s_shiftp + chroma * 32, cur.lr & 0xffffu, cur.lr >> 16, O, s_shiftp + 64 + 2 * chroma);
-    }
-    c_xf += clock64() - c_x0;
-    if (P == 0) cur = nxt;
-  };
-  pass(std::integral_constant<int, 0>{}, QA);
-  if (dead) return;
-  pass(std::integral_constant<int, 1>{}, QB);
-  // Accept / reject like UncompressStream (huffman_dec.cpp:361-417).  (Behind the second
-  // pass's barrier: every walk has reported.)
-  if (tid == 0) {
-    int bad = sh->err;
-    if (tot < out_size) bad = 1;   // ran out of payload before the block was full
-    const unsigned long long E = sh->endbit, P1 = 8ull * pay_len;
-    if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
-    if (bad) atomicMax(&df->status, fmt_err(7, 1));
-    po[kRecLanes + kRecDone] = 1;
-  }
-  // The lane pair swaps halves (one v_permlane32_swap per register pair): lower lanes hold
-  // planes 0 (QA) and 2 (QB), upper lanes 1 and 3; afterwards either half holds its four
-  // pixel rows of all four channels.
-  uint32_t ch0[8], ch1[8], ch2[8], ch3[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const auto ra = __builtin_amdgcn_permlane32_swap(QA[i], QA[8 + i], false, false);
-    const auto rb = __builtin_amdgcn_permlane32_swap(QB[i], QB[8 + i], false, false);
-    ch0[i] = ra[0]; ch1[i] = ra[1];
-    ch2[i] = rb[0]; ch3[i] = rb[1];
-  }
-  finish_rows_pair<true>(g, ch0, ch1, ch2, ch3, ycbcr, u, s, v, out_frames + (size_t)f * ((size_t)g.W * g.H * 4));
-  if ((tid & 63) == 0) {   // cycle stamps like k_dec_row_fused's (tools/dec_stats_batch.py): the slowest wave counts
-    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + v + 1) * 8;
-    atomicMax(&st[1], (uint32_t)(c_walk >> 4));    // the walks alone
-    atomicMax(&st[2], (uint32_t)(c_xf >> 4));
-    atomicMax(&st[3], (uint32_t)((clock64() - c_in) >> 4));
-    atomicMax(&st[5], (uint32_t)(c_write >> 4));
-    if (tid == 0) { st[0] = 1; st[6] = pay_len; st[7] = out_size; }
   }
 }
 
@@ -3750,21 +3377,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       if (ds) (void)hipStreamWaitEvent(stream, ds->ev_cnt[k], 0);
       else row_count(stream, a, b);
       if (b <= a) continue;
-      const bool whole4 = g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0;   // FULL4
-      // 4096-pixel RGBA rows with k_row_count_w's half-lane records: two passes over channel
-      // plane pairs, the payload staged in LDS, two chains per lane (HIMG_OPT_ROW_PAIR; on by
-      // default).  Rows it leaves alone (no full records, more payload than the staging area
-      // holds) fall to k_dec_row_fused, which skips the rows marked done.
-      const bool pair = count_wave && g.W == 4096 && whole4 && g.row_pair != 0;
-      if (pair) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_pair<512>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairLayout::total);
-        prof_begin(prof, "k_dec_row_pair", stream);
-        hipLaunchKernelGGL((k_dec_row_pair<512>), dim3(b - a, batch), dim3(kDecThreads), PairLayout::total, stream, g, ws,
-                           d_packed, in_stride, d_sizes, d_out, a);
-        prof_end(prof, stream);
-      }
       prof_begin(prof, "k_dec_row_fused", stream);
+      const bool whole4 = g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0;   // FULL4
       if (g.W == 4096 && whole4) HIMG_FUSED_LAUNCH(512, a, b);
       else if (whole4) HIMG_FUSED_LAUNCH(-1, a, b);
       else HIMG_FUSED_LAUNCH(0, a, b);

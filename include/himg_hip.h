@@ -59,13 +59,9 @@ const char *himg_hip_last_error(const himg_hip_ctx *ctx);
  * value -1 = by launch size (the default), 0 / 1 = force off / on:
  *   HIMG_OPT_COUNT_WAVE  FRES row index records by a wavefront per row (batches) instead of
  *                        a workgroup per row (single frames)            [env HIMG_COUNT_WAVE]
- *   HIMG_OPT_EMIT_ROWS   bit packing of FRES rows by a wavefront per row (batches) [env HIMG_EMIT_ROWS]
- *   HIMG_OPT_ROW_PAIR    4096-pixel RGBA block rows decoded in two passes over channel-plane
- *                        pairs with the row's payload staged in LDS (needs the
- *                        wavefront-per-row records)                      [env HIMG_ROW_PAIR] */
+ *   HIMG_OPT_EMIT_ROWS   bit packing of FRES rows by a wavefront per row (batches) [env HIMG_EMIT_ROWS] */
 #define HIMG_OPT_COUNT_WAVE 2
 #define HIMG_OPT_EMIT_ROWS 3
-#define HIMG_OPT_ROW_PAIR 4
 int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value);
 
 /* Upper bound of the packed size of one frame (bytes), a multiple of 256.

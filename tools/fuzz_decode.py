@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""One-off decoder fuzz (GPU box): N single-bit flips per stream, GPU vs oracle.
+"""Decoder fuzz, long form (GPU box): N mutated streams per geometry and per form of the FRES
+row index kernel (HIMG_OPT_COUNT_WAVE 0 / 1), GPU vs oracle: same accept / reject, same
+pixels.  tests/test_gpu_fuzz.py is the bounded version that runs with the suite; this one's
+output is kept as profiles/r04_fuzz_decode.txt.
 Usage: python tools/fuzz_decode.py [N]"""
 import os, struct, sys
 import numpy as np
@@ -17,9 +20,13 @@ def chunks(stream):
     return out
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-eng = himg_amd.Engine(0)
+engines = []
+for cw in (0, 1):
+    e = himg_amd.Engine(0)
+    e.set_option("count_wave", cw)
+    engines.append((cw, e))
 rng = np.random.default_rng(7)
-bad_cases = 0
+bad_cases = total = 0
 for kind, w, h, q in [("randtile", 4096, 64, 50), ("randtile", 4096, 32, 90), ("gradn", 1024, 256, 70),
                       ("rand", 512, 128, 50), ("randtile", 200, 116, 70), ("randtile", 4400, 40, 90),
                       ("rand", 4400, 16, 90), ("randtile", 8192, 64, 70), ("rand", 16384, 40, 90)]:
@@ -43,14 +50,16 @@ for kind, w, h, q in [("randtile", 4096, 64, 50), ("randtile", 4096, 32, 90), ("
         for _ in range(nflip):
             bad[int(rng.integers(off, off + span))] ^= 1 << int(rng.integers(0, 8))
         rc, pix = ol.oracle_decode(bad)
-        try:
-            got = eng.decode(bad)
-            ok = True
-        except himg_amd.HimgError as e:
-            ok, got = False, e.code
-        if (rc == 0) != ok or (ok and not np.array_equal(got.ravel(), pix.ravel())):
-            bad_cases += 1
-            print("MISMATCH", kind, w, h, q, "mutation", t, "oracle rc", rc, "gpu", "ok" if ok else got)
+        for cw, eng in engines:
+            try:
+                got = eng.decode(bad)
+                ok = True
+            except himg_amd.HimgError as e:
+                ok, got = False, e.code
+            total += 1
+            if (rc == 0) != ok or (ok and not np.array_equal(got.ravel(), pix.ravel())):
+                bad_cases += 1
+                print("MISMATCH", kind, w, h, q, "mutation", t, "count_wave", cw, "oracle rc", rc, "gpu", "ok" if ok else got)
         acc += rc == 0; rej += rc != 0
-    print(kind, w, h, q, "accepted", acc, "rejected", rej)
-print("mismatches:", bad_cases)
+    print(kind, w, h, q, "accepted", acc, "rejected", rej, flush=True)
+print("decodes compared:", total, "mismatches:", bad_cases)
