@@ -142,7 +142,7 @@ struct himg_hip_ctx {
   bool dec_valid = false;
 
   // Staging for the host-buffer API.
-  DevBuf h_in, h_out, h_sizes, h_status;
+  DevBuf h_in, h_out, h_sizes, h_status, h_index;
 
   // Packed sizes handed to the decoder: the caller's array (or a by-value argument)
   // may be gone before an asynchronous copy reads it, so the sizes are first copied
@@ -308,7 +308,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
                    &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_gyc, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
-                   &ctx->h_out, &ctx->h_sizes, &ctx->h_status};
+                   &ctx->h_out, &ctx->h_sizes, &ctx->h_status, &ctx->h_index};
   for (DevBuf *b : all) b->release();
   delete ctx;
 }
@@ -937,10 +937,31 @@ static int decode_core(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_s
       !ctx->h_status.reserve(256))
     return fail(ctx, HIMG_ERR_HIP, "staging allocation failed");
   ctx->host_bytes = 0;
+  // (The row kernels read whole dwords and a few dwords ahead: nothing of the stream decoded
+  // before may lie behind this one.)
+  HIP_TRY(ctx, hipMemset((uint8_t *)ctx->h_in.p + (packed_size & ~(size_t)15), 0, in_cap - (packed_size & ~(size_t)15)));
   HIP_TRY(ctx, hipMemcpy(ctx->h_in.p, packed, packed_size, hipMemcpyHostToDevice));
   const uint32_t sz32 = (uint32_t)packed_size;
-  int rc = himg_hip_decode_device(ctx, ctx->h_in.p, in_cap, &sz32, 1, *W, *H, *C, ctx->h_out.p,
-                                  (int32_t *)ctx->h_status.p, nullptr);
+  // The stream is in host memory: the FRES rows are indexed HERE -- the walk over the row
+  // size headers (huffman_dec.cpp:232-248) is a chain of dependent reads, microseconds on
+  // a CPU and 0.24 ms of a 0.41 ms decode as k_dec_rowwalk's 512 dependent HBM loads -- and
+  // the index goes up with the stream.  A stream the host walk does not accept (damaged
+  // headers, a geometry it does not index) takes the device walk, which words the verdict.
+  int rc = -1;
+  {
+    std::vector<uint32_t> index(2 * (size_t)g.rows);
+    uint32_t first = 0;
+    int w2 = 0, h2 = 0, c2 = 0;
+    if (g.rows >= 2 && ctx->h_index.reserve(round_up(index.size() * 4, 256)) &&
+        himg_hip_index_host(packed, packed_size, ctx->fix_t2, &w2, &h2, &c2, index.data(), (size_t)g.rows, &first) == HIMG_OK) {
+      HIP_TRY(ctx, hipMemcpy(ctx->h_index.p, index.data(), index.size() * 4, hipMemcpyHostToDevice));
+      rc = himg_hip_decode_rows_indexed_device(ctx, ctx->h_in.p, sz32, *W, *H, *C, 0, g.rows, (const uint32_t *)ctx->h_index.p,
+                                               ctx->h_out.p, (int32_t *)ctx->h_status.p, nullptr);
+    }
+  }
+  if (rc == -1)
+    rc = himg_hip_decode_device(ctx, ctx->h_in.p, in_cap, &sz32, 1, *W, *H, *C, ctx->h_out.p,
+                                (int32_t *)ctx->h_status.p, nullptr);
   if (rc) return rc;
   int32_t st = 0;
   HIP_TRY(ctx, hipMemcpy(&st, ctx->h_status.p, 4, hipMemcpyDeviceToHost));

@@ -738,7 +738,8 @@ __device__ __forceinline__ uint32_t wave_prev(uint32_t identity, uint32_t v) {
 
 // Exclusive block scan (256 threads) of zero-run summaries; `carry` is the state
 // before this block of symbols.  Returns the exclusive prefix; *total receives
-// the state after the block.  `sm` needs 4 entries.
+// the state after the block.  `sm` needs NW entries (NW wavefronts in the workgroup).
+template <int NW = 4>
 __device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total) {
   const int lane = lane_id(), wave = wave_id();
   const uint32_t inclp = wave_scan_zrp(zr_pack(mine));
@@ -746,7 +747,7 @@ __device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total
   const ZR ex = zr_unpack(wave_prev(kZrIdentity, inclp));
   __syncthreads();
   ZR pre = carry, tot = carry;
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
     if (w < wave) pre = zr_combine(pre, sm[w]);
     tot = zr_combine(tot, sm[w]);
   }
@@ -987,19 +988,24 @@ __global__ __launch_bounds__(256) void k_lres_summary(Geom g, EncWs ws) {
 // pair -- is counted with ONE LDS atomic in a 2-D histogram [run][symbol] (which
 // also spreads the hot symbols over more addresses); the pairs are folded into
 // the 261 token bins at the end.  Longer runs are counted token by token.
-__global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
+// NT lanes per span: 256 (batches: eight workgroups per CU), or 1024 for a SINGLE frame --
+// its 512 rows are 512 workgroups, a quarter of the chip's slots at 256 lanes, and a row is
+// 16 iterations of three barriers each; with 1024 lanes it is four iterations and the chip
+// is full (latency: 84 -> 3x us).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist[kHistStride];
   // [zeros in front, kPairRuns = that many or more][literal]; rows 257 words apart: the
   // hot literals (+-1, +-2) of the eight rows then lie in different banks.
   __shared__ uint32_t hist2[kPairRuns + 1][257];
   __shared__ uint32_t hrun[kRunTab + 1];   // runs of kPairRuns..278 zeros, by exact length
-  __shared__ uint32_t s_sym[8 * 256];      // [word][lane]: the lane's 32 symbols of this iteration
-  __shared__ ZR sm[4];
+  __shared__ uint32_t s_sym[8 * NT];      // [word][lane]: the lane's 32 symbols of this iteration
+  __shared__ ZR sm[NT / 64];
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
-  for (int k = threadIdx.x; k < kHistStride; k += 256) hist[k] = 0;
-  for (int k = threadIdx.x; k < (kPairRuns + 1) * 257; k += 256) (&hist2[0][0])[k] = 0;
-  for (int k = threadIdx.x; k < kRunTab + 1; k += 256) hrun[k] = 0;
+  for (int k = threadIdx.x; k < kHistStride; k += NT) hist[k] = 0;
+  for (int k = threadIdx.x; k < (kPairRuns + 1) * 257; k += NT) (&hist2[0][0])[k] = 0;
+  for (int k = threadIdx.x; k < kRunTab + 1; k += NT) hrun[k] = 0;
   ZR carry;
   carry.tz = span_carry_in(g, ws, sp, f);
   carry.az = 0;
@@ -1008,20 +1014,20 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   // with 32 symbols the busiest lane is 1.6x the mean instead of 1.9x with 16; the
   // scans and the barrier are paid half as often per symbol.  The lane's symbols sit
   // in LDS (transposed), where the walk fetches them by position.
-  for (int base = 0; base < s.len; base += 2 * kIterSyms) {
+  for (int base = 0; base < s.len; base += 32 * NT) {
     const int off = base + threadIdx.x * 32;
     const int nvalid = max(0, min(32, s.len - off));
     uint32_t w[8];
     load16(s.sym + off, s.len - off, w);
     load16(s.sym + off + 16, s.len - off - 16, w + 4);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s_sym[q * 256 + threadIdx.x] = w[q];
+    for (int q = 0; q < 8; ++q) s_sym[q * NT + threadIdx.x] = w[q];
     const uint32_t mask = nonzero_mask16(w, min(nvalid, 16)) | (nonzero_mask16(w + 4, max(nvalid - 16, 0)) << 16);
     ZR mine;
     mine.tz = mask ? nvalid - (32 - __clz(mask)) : nvalid;
     mine.az = mask ? 0 : 1;
     ZR total;
-    const ZR ex = block_scan_zr(mine, carry, sm, &total);
+    const ZR ex = block_scan_zr<NT / 64>(mine, carry, sm, &total);
     carry = total;
     carry.az = 0;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
       const int k = __ffs(m) - 1;
       m &= m - 1;
       const int run = k - prev - 1;
-      const int sym = mysym[(k >> 2) * 1024 + (k & 3)];
+      const int sym = mysym[(k >> 2) * (4 * NT) + (k & 3)];
       prev = k;
       // The literal always counts in the 2-D histogram (row kPairRuns: after a longer
       // run -- no branch around the common case); a longer run counts on its own.
@@ -1051,8 +1057,8 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __syncthreads();
   // Fold the pairs: the literal of every pair, and its run token (huffman_enc.cpp:
   // 111-141: one zero = literal 0, two = 256, three to six = 257).
-  {
-    const int sym = threadIdx.x;   // 256 threads = 256 literal values
+  if (threadIdx.x < 256) {
+    const int sym = threadIdx.x;   // one lane per literal value
     uint32_t lit = 0, r1 = hist2[1][sym], r2 = hist2[2][sym], r3 = 0;
 #pragma unroll
     for (int r = 0; r <= kPairRuns; ++r) lit += hist2[r][sym];
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
     if (r2) atomicAdd(&hist[256], r2);
     if (r3) atomicAdd(&hist[257], r3);
   }
-  for (int r = kPairRuns + (int)threadIdx.x; r < kRunTab; r += 256) {   // 7..22 -> 258, 23..278 -> 259
+  for (int r = kPairRuns + (int)threadIdx.x; r < kRunTab; r += NT) {   // 7..22 -> 258, 23..278 -> 259
     const uint32_t c = hrun[r];
     if (c) atomicAdd(&hist[r <= 22 ? 258 : 259], c);
   }
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   uint32_t *sh = (s.is_lres ? ws.span_hist_l + ((size_t)f * g.lres_spans + sp) * kHistStride
                             : ws.span_hist_f + ((size_t)f * g.rows + (sp - g.lres_spans)) * kHistStride);
   uint32_t *gh = ws.hist + ((size_t)f * 2 + (s.is_lres ? 0 : 1)) * kHistStride;
-  for (int k = threadIdx.x; k < kHistStride; k += 256) {
+  for (int k = threadIdx.x; k < kHistStride; k += NT) {
     const uint32_t c = hist[k];
     sh[k] = c;
     if (c && k < kNumSym) atomicAdd(&gh[k], c);
@@ -1309,8 +1315,38 @@ __device__ __forceinline__ int extra_bits_of(int sym) {
 }
 
 // ---------------------------------------------------------------------------
+// k_span_bits: payload bits of every span = its token histogram . (code length + extra
+// bits) (huffman_enc.cpp:298-338 without re-reading the symbols), one WAVEFRONT per span:
+// five coalesced loads per lane and a wave reduction.  (As a loop of 261 dependent loads
+// per span inside k_sizes' single workgroup this was 25 us of a single frame's encode.)
+// Spans [sp0, sp1) of every frame, span index as in get_span (LRES spans, then FRES rows);
+// bits_out (optional): where the FRES rows' counts go instead of ws.span_bits (row-sharded
+// encode: [row - first row]).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_span_bits(Geom g, EncWs ws, int sp0, int sp1, uint32_t *bits_out) {
+  const int f = blockIdx.y, lane = lane_id();
+  const int sp = sp0 + (int)blockIdx.x * 4 + wave_id();
+  if (sp >= sp1) return;
+  const bool lres = sp < g.lres_spans;
+  const uint32_t *h = lres ? ws.span_hist_l + ((size_t)f * g.lres_spans + sp) * kHistStride
+                           : ws.span_hist_f + ((size_t)f * g.rows + (sp - g.lres_spans)) * kHistStride;
+  const uint32_t *len = ws.lens + ((size_t)f * 2 + (lres ? 0 : 1)) * kHistStride;
+  uint32_t b = 0;
+#pragma unroll
+  for (int j = 0; j < (kNumSym + 63) / 64; ++j) {
+    const int k = lane + 64 * j;
+    if (k < kNumSym) b += h[k] * (len[k] + (uint32_t)extra_bits_of(k));
+  }
+  b = wave_scan_add(b);   // lane 63: the span's total
+  if (lane == 63) {
+    if (bits_out && !lres) bits_out[sp - sp0] = b;
+    else ws.span_bits[(size_t)f * (g.lres_spans + g.rows) + sp] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_sizes: one workgroup per frame.  Span bit counts follow from the span
-// histograms and the code lengths, so the symbols are not re-read.  Writes every
+// histograms and the code lengths (k_span_bits), so the symbols are not re-read.  Writes every
 // container byte that is not entropy payload: RIFF/FRMT/LMAP/'LRES' head, both
 // serialised trees, QCFG/FMAP/'FRES', the per-row size headers
 // (huffman_enc.cpp:342-352) and all size fields (encoder.cpp:131-137,347-350).
@@ -1326,18 +1362,12 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
                                                size_t out_stride, uint32_t *sizes,
                                                const uint32_t *row_bits_in, int fres_rel, int hr0, int hr1) {
   __shared__ uint32_t sm[4];
-  __shared__ uint32_t cost[2][kHistStride];
   const int f = blockIdx.x, tid = threadIdx.x;
   uint8_t *o = out + (size_t)f * out_stride;
   const int nsp = g.lres_spans + g.rows;
   uint64_t *bit0 = ws.span_bit0 + (size_t)f * nsp;
   uint32_t *nbits = ws.span_bits + (size_t)f * nsp;
 
-  for (int k = tid; k < 2 * kHistStride; k += 256) {
-    const int s = k / kHistStride, sym = k % kHistStride;
-    cost[s][sym] = sym < kNumSym ? ws.lens[((size_t)f * 2 + s) * kHistStride + sym] + extra_bits_of(sym) : 0;
-  }
-  __syncthreads();
   const uint32_t tree_l = fres_rel ? 0u : ws.tree_nbytes[(size_t)f * 2 + 0];
   const uint32_t tree_f = fres_rel ? 0u : ws.tree_nbytes[(size_t)f * 2 + 1];
 
@@ -1345,14 +1375,10 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
   unsigned long long run = 8ull * (kHeadLen + tree_l);
   for (int base = 0; base < (fres_rel ? 0 : g.lres_spans); base += 256) {
     const int s = base + tid;
-    uint32_t b = 0;
-    if (s < g.lres_spans) {
-      const uint32_t *h = ws.span_hist_l + ((size_t)f * g.lres_spans + s) * kHistStride;
-      for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[0][k];
-    }
+    const uint32_t b = s < g.lres_spans ? nbits[s] : 0u;   // k_span_bits
     uint32_t tot;
     const uint32_t ex = block_scan_u32(b, sm, &tot);
-    if (s < g.lres_spans) { bit0[s] = run + ex; nbits[s] = b; }
+    if (s < g.lres_spans) bit0[s] = run + ex;
     run += tot;
   }
   const unsigned long long lres_end_bit = run;
@@ -1366,12 +1392,7 @@ __global__ __launch_bounds__(256) void k_sizes(Geom g, EncWs ws, StaticChunks sc
     const int r = base + tid;
     uint32_t b = 0, nbytes = 0, hdr = 0;
     if (r < g.rows) {
-      if (row_bits_in) {
-        b = row_bits_in[r];
-      } else {
-        const uint32_t *h = ws.span_hist_f + ((size_t)f * g.rows + r) * kHistStride;
-        for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[1][k];
-      }
+      b = row_bits_in ? row_bits_in[r] : nbits[g.lres_spans + r];   // (k_span_bits / the other ranks' rows)
       nbytes = (b + 7) >> 3;
       hdr = g.use_blocks ? (nbytes <= 0x7fffu ? 2u : 4u) : 0u;
     }
@@ -1460,15 +1481,19 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) { return wave_scan
 // barrier above is program order inside one wavefront, nobody waits for a slower
 // wavefront's busiest lane, and a workgroup of eight waves shares one set of tables
 // (46 KiB for eight spans against 8 x 24.5).
-template <int ROWS>
-__global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : 256) void k_emit_t(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
+// WIDE (with ROWS == 1): 1024 lanes per span, 16384 symbols per iteration -- the FRES rows of
+// a SINGLE frame: 512 workgroups of 256 lanes are a quarter of the chip's slots and 32
+// iterations of three barriers per row; 1024 lanes fill the chip and take eight.
+template <int ROWS, bool WIDE = false>
+__global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : (WIDE ? 1024 : 256)) void k_emit_t(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
                                                                        const uint32_t *sizes, int sp0, int sp1) {
-  constexpr int NT = ROWS > 1 ? 64 : 256;          // lanes that work on one span
+  static_assert(!WIDE || ROWS == 1, "the wide form takes one span per workgroup");
+  constexpr int NT = ROWS > 1 ? 64 : (WIDE ? 1024 : 256);   // lanes that work on one span
   constexpr int NG = ROWS > 1 ? ROWS : 1;          // spans per workgroup
   constexpr int NWAVE = NT / 64;                   // wavefronts per span
   // (staging words per span, a power of two: 256 per wavefront send too many iterations to the
   // window-by-window path -- 3.26 ms per 64 frames against 2.92 --, 1024 cost a workgroup per CU)
-  constexpr int kStage = ROWS > 1 ? 512 : kStageWords;
+  constexpr int kStage = ROWS > 1 ? 512 : (WIDE ? 4 * kStageWords : kStageWords);
   constexpr uint32_t kWindow = (uint32_t)(kStage - 4) * 32u;                // + carry word + 46-bit spill
   constexpr int kIter = NT * 16;                                            // symbols per iteration
   __shared__ uint32_t stage_all[NG * kStage];
@@ -1479,8 +1504,8 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : 256) void k_emit_t(Geom g, E
   __shared__ uint32_t s_pair[kPairRuns + 1][256];   // row kPairRuns: zeros ("not merged")
   __shared__ uint32_t s_run[kRunTab + 1];   // run token of r zeros: bits | length << 24 (0: not representable; [kRunTab] = 0)
   __shared__ uint32_t s_priv_all[NG * (kPrivWords + 1) * NT];   // [word][lane]: the bits a lane assembled this iteration (+ one row that absorbs an overflowing lane's stores)
-  __shared__ ZR sm_zr[2][4];
-  __shared__ uint32_t sm_u[2][4];
+  __shared__ ZR sm_zr[2][NWAVE];
+  __shared__ uint32_t sm_u[2][NWAVE];
 
   const int f = blockIdx.y;
   const int grp = ROWS > 1 ? (int)threadIdx.x / NT : 0;
@@ -1577,7 +1602,7 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : 256) void k_emit_t(Geom g, E
       __syncthreads();
       tot = pre;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NWAVE; ++k) {
         if (k < wave) pre = zr_combine(pre, sm_zr[par][k]);
         tot = zr_combine(tot, sm_zr[par][k]);
       }
@@ -1628,7 +1653,7 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : 256) void k_emit_t(Geom g, E
       if (lane == 63) sm_u[par][wave] = bincl;
       any_ovf = __syncthreads_or(ovf ? 1 : 0);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NWAVE; ++k) {
         if (k < wave) bpre += sm_u[par][k];
         iter_bits += sm_u[par][k];
       }
@@ -1792,21 +1817,6 @@ __global__ __launch_bounds__(256) void k_padfix(Geom g, EncWs ws, uint8_t *out, 
 // Row-sharded (multi-GPU) helpers.
 // ---------------------------------------------------------------------------
 
-// Payload bits of the local block rows [r0, r0+n) from their span histograms and
-// the (globally agreed) FRES code lengths.
-__global__ __launch_bounds__(256) void k_row_bits(Geom g, EncWs ws, int r0, int n, uint32_t *bits_out) {
-  __shared__ uint32_t cost[kHistStride];
-  for (int k = threadIdx.x; k < kHistStride; k += 256)
-    cost[k] = k < kNumSym ? ws.lens[(size_t)1 * kHistStride + k] + extra_bits_of(k) : 0;
-  __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t *h = ws.span_hist_f + (size_t)(r0 + i) * kHistStride;
-  uint32_t b = 0;
-  for (int k = 0; k < kNumSym; ++k) b += h[k] * cost[k];
-  bits_out[i] = b;
-}
-
 // Copy the gathered FRES rows (headers + payloads, laid out relative to the first
 // row header) behind the FRES tree of the final stream.  The destination offset
 // is data dependent (LRES size) and lives on the device.
@@ -1898,20 +1908,39 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
 #undef HIMG_PIX
 }
 
+constexpr long long kWideRows = 1024;   // up to this many FRES rows per call: 1024 lanes per row (k_tok_hist, k_emit)
+
+// k_tok_hist over the FRES rows [r0, r1) of every frame: a workgroup of 256 lanes per row,
+// or of 1024 when there are too few rows to fill the GPU that way (a single frame).
+static void launch_tok_hist_rows(const Geom &g, const EncWs &ws, int r0, int r1, int batch, hipStream_t stream,
+                                 Profiler *prof) {
+  if (r1 <= r0) return;
+  prof_begin(prof, "k_tok_hist", stream);
+  if ((long long)(r1 - r0) * batch <= kWideRows && g.row_block >= 32768)
+    hipLaunchKernelGGL(k_tok_hist<1024>, dim3(r1 - r0, batch), dim3(1024), 0, stream, g, ws, g.lres_spans + r0);
+  else
+    hipLaunchKernelGGL(k_tok_hist<256>, dim3(r1 - r0, batch), dim3(256), lds_pad(), stream, g, ws, g.lres_spans + r0);
+  prof_end(prof, stream);
+}
+
 // k_emit over the spans [sp0, sp1) of every frame: LRES spans (they meet at bit positions:
 // one workgroup each), then the FRES rows -- a wavefront each, eight to a workgroup, when
 // there are enough of them to fill the GPU that way (batches); a single frame keeps one
 // workgroup per row (HIMG_EMIT_ROWS=0 / 1 forces either).
 constexpr int kEmitRows = 8;   // (2 / 4 / 6 rows per workgroup: 3.35 / 2.99 / 3.49 ms per 64 frames, 8: 2.92)
+// lres_stream: where the LRES spans' launch goes (the caller's stream, or a side stream the
+// caller has forked and will join: the two launches touch disjoint bytes).
 static void launch_emit(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_stride, const uint32_t *d_sizes,
-                        int sp0, int sp1, int batch, hipStream_t stream, Profiler *prof) {
+                        int sp0, int sp1, int batch, hipStream_t stream, Profiler *prof,
+                        hipStream_t lres_stream = nullptr) {
   const int rows_env = g.emit_rows;   // HIMG_OPT_EMIT_ROWS (-1: by the number of rows)
   const int l1 = sp0 < g.lres_spans ? (sp1 < g.lres_spans ? sp1 : g.lres_spans) : sp0;   // [sp0, l1): LRES spans
   if (l1 > sp0) {
-    prof_begin(prof, "k_emit", stream);
-    hipLaunchKernelGGL(k_emit_t<1>, dim3(l1 - sp0, batch), dim3(256), lds_pad(), stream, g, ws, d_out, out_stride,
+    hipStream_t ls = lres_stream ? lres_stream : stream;
+    prof_begin(prof, "k_emit", ls);
+    hipLaunchKernelGGL(k_emit_t<1>, dim3(l1 - sp0, batch), dim3(256), lds_pad(), ls, g, ws, d_out, out_stride,
                        d_sizes, sp0, l1);
-    prof_end(prof, stream);
+    prof_end(prof, ls);
   }
   if (sp1 > l1) {
     const long long rows = (long long)(sp1 - l1) * batch;
@@ -1920,6 +1949,9 @@ static void launch_emit(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t o
     if (by_wave)
       hipLaunchKernelGGL(k_emit_t<kEmitRows>, dim3((sp1 - l1 + kEmitRows - 1) / kEmitRows, batch), dim3(64 * kEmitRows),
                          lds_pad(), stream, g, ws, d_out, out_stride, d_sizes, l1, sp1);
+    else if (rows <= kWideRows && g.row_block >= 32768)   // a single frame (or two): 1024 lanes per row
+      hipLaunchKernelGGL((k_emit_t<1, true>), dim3(sp1 - l1, batch), dim3(1024), lds_pad(), stream, g, ws, d_out,
+                         out_stride, d_sizes, l1, sp1);
     else
       hipLaunchKernelGGL(k_emit_t<1>, dim3(sp1 - l1, batch), dim3(256), lds_pad(), stream, g, ws, d_out, out_stride,
                          d_sizes, l1, sp1);
@@ -1971,7 +2003,7 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
     HIMG_LAUNCH(k_lres_predict, dim3((g.mcols + 3) / 4, g.mrows, batch * g.C), dim3(64), g, ws.low,
                 ws.plane_stride, ws.lres_sym, ws.lres_stride, lt);
     HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, batch), b256, g, ws);
-    HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, batch), b256, g, ws, 0);
+    HIMG_LAUNCH(k_tok_hist<256>, dim3(g.lres_spans, batch), b256, g, ws, 0);
     stream = stream_saved;
   }
   if (side) (void)hipEventRecord(ev_join, side);
@@ -1983,14 +2015,23 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
-  HIMG_LAUNCH_PAD(k_tok_hist, dim3(g.rows, batch), b256, g, ws, g.lres_spans);   // FRES rows
+  launch_tok_hist_rows(g, ws, 0, g.rows, batch, stream, prof);   // FRES rows
   if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(kTreeThreads), ws, 0);
+  HIMG_LAUNCH(k_span_bits, dim3((nsp + 3) / 4, batch), b256, g, ws, 0, nsp, (uint32_t *)nullptr);
   HIMG_LAUNCH(k_sizes, dim3(batch), b256, g, ws, sc, d_out, out_stride, d_sizes,
               (const uint32_t *)nullptr, 0, 0, g.rows);
-  launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof);
+  // The LRES spans' bit packing (1/64 of the symbols, 20 us of a single frame's 130) beside
+  // the FRES rows': forked to the side stream again, joined behind the pad-bit fix-up.
+  if (side) {
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+  }
+  launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof, side);
+  if (side) (void)hipEventRecord(ev_join, side);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
+  if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
 }
 
 // ---- row-sharded encode of ONE frame (see himg_hip.h, "row-sharded encode") ----
@@ -2021,14 +2062,14 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
   HIMG_LAUNCH(k_lowres_blend, dim3(gx, (l1 - r0 + kBlendRows - 1) / kBlendRows, g.C), b256, g, ws.avg, ws.low,
               ws.plane_stride, r0, l1);
   launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
-  HIMG_LAUNCH(k_tok_hist, dim3(r1 - r0, 1), b256, g, ws, g.lres_spans + r0);
+  launch_tok_hist_rows(g, ws, r0, r1, 1, stream, prof);
 }
 
 void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
                            hipStream_t stream, Profiler *prof) {
   HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 1);
   if (r1 > r0)
-    HIMG_LAUNCH(k_row_bits, dim3((r1 - r0 + 255) / 256), dim3(256), g, ws, r0, r1 - r0, d_bits_out);
+    HIMG_LAUNCH(k_span_bits, dim3((r1 - r0 + 3) / 4, 1), dim3(256), g, ws, g.lres_spans + r0, g.lres_spans + r1, d_bits_out);
 }
 
 void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
@@ -2054,8 +2095,9 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
   HIMG_LAUNCH(k_lres_predict, dim3((g.mcols + 3) / 4, g.mrows, g.C), dim3(64), g, ws.low, ws.plane_stride,
               ws.lres_sym, ws.lres_stride, lt);
   HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, 1), b256, g, ws);
-  HIMG_LAUNCH(k_tok_hist, dim3(g.lres_spans, 1), b256, g, ws, 0);
+  HIMG_LAUNCH(k_tok_hist<256>, dim3(g.lres_spans, 1), b256, g, ws, 0);
   HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 0);
+  HIMG_LAUNCH(k_span_bits, dim3((g.lres_spans + 3) / 4, 1), b256, g, ws, 0, g.lres_spans, (uint32_t *)nullptr);
   HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0, 0, 0);
   launch_emit(g, ws, d_out, out_cap, d_size, 0, g.lres_spans, 1, stream, prof);
   HIMG_LAUNCH(k_place_fres, dim3(1024), b256, g, ws, d_rel, rel_bytes, d_out, d_size);
