@@ -104,6 +104,12 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
 };
 
 constexpr int kLresMemoWords = 6;
+// Header words behind a row's kDecThreads lane offsets (lane_off): [0] symbols of the row,
+// [1] where the chain ends (bits), [2] valid flag, [3] diagnostics, [4] 1: lane_q holds
+// three more boundaries inside every lane's range (wide rows), [8 + w] the QUARTER record
+// (4 * lane + k) that holds the first symbol of window w of the row's symbols (w >= 1).
+constexpr int kRecHdr = 72;
+constexpr int kRecWin = 8;
 struct DecWs {
   DecFrame *frames;          // [f]
   uint32_t *nodes;           // [f][2][522]  child a | child b << 10 | (symbol + 1) << 20 (1023: no child; 0: a branch)
@@ -118,10 +124,14 @@ struct DecWs {
   // k_row_count -> k_dec_row_fused: per FRES row and lane the first owned token
   // (bits from the chunk start) and the exclusive prefix of the symbol counts.
   uint32_t *lane_start;      // [f][rows][kDecThreads]
-  uint32_t *lane_off;        // [f][rows][kDecThreads + 4]: offsets, then total, chain end (bits), valid flag
+  uint32_t *lane_off;        // [f][rows][kDecThreads + kRecHdr]: offsets, then total, chain end (bits), valid flag
                              // (1: the lanes' ranges are divided at token boundaries and a consumer finishes its
                              // range token by token; 3: k_row_count_w -- at boundaries of the WRITE pass's chain
                              // of groups: a consumer that walks those groups from its start lands on its limit)
+  // Rows too wide for the LDS (k_row_window): three more boundaries inside every lane's range,
+  // so that a 128 KiB window of the row's symbols has 1024 sub-sequences to walk, not 256.
+  uint32_t *lane_q;          // [f][rows][6][kDecThreads]: positions of the boundaries at 1/4, 1/2, 3/4 (bits from the
+                             // row's first), then the output offsets there; nullptr for rows the fused kernel takes
   uint32_t *parse_stats;     // [f][4] k_dec_parse phase cycles / 16
   uint32_t *stats;           // [f][rows+1][8] k_dec_huff counters (chunks, rounds, cycle splits)
   uint32_t *rc_stats;        // [f][rows][8] k_row_count phase cycles / 16 (slowest wave)
@@ -158,6 +168,10 @@ struct DecStreams {
   hipEvent_t ev_walk[kWalkSegs] = {}, ev_cnt[kWalkSegs] = {};
   int walk_segs = 0;             // HIMG_WALK_SEGS at context creation (0: by frame size)
 };
+
+// The fused row kernel serves this geometry (a block row's symbols and the decode tables fit
+// the LDS of one CU); otherwise the rows go through 128 KiB windows (k_row_window).
+bool dec_rows_fit_lds(const Geom &g);
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,

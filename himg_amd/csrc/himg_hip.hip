@@ -472,7 +472,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
       !ctx->d_grp.reserve((size_t)batch * 2 * (1u << kLutBits) * 8) ||
       !ctx->d_gyc.reserve((size_t)batch * 2 * (1u << kLutBits) * 4) ||
       !ctx->d_sub.reserve((size_t)batch * 2 * kSubEntries * 8) ||
-      !ctx->d_lane.reserve((size_t)batch * g.rows * (2 * kDecThreads + 4) * 4) ||
+      !ctx->d_lane.reserve((size_t)batch * g.rows * (2 * kDecThreads + himg_dev::kRecHdr + (himg_dev::dec_rows_fit_lds(g) ? 0 : 6 * kDecThreads)) * 4) ||
       !ctx->d_rows.reserve((size_t)batch * g.rows * 4 * 2) || !ctx->d_lres.reserve(lres * batch) ||
       !ctx->d_fres.reserve(fres * batch) || !ctx->d_planes.reserve(plane * batch) ||
       !ctx->d_sizes.reserve((size_t)batch * 4) ||
@@ -485,6 +485,7 @@ static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.sub = (uint2 *)ctx->d_sub.p;
   w.lane_start = (uint32_t *)ctx->d_lane.p;
   w.lane_off = w.lane_start + (size_t)batch * g.rows * kDecThreads;
+  w.lane_q = himg_dev::dec_rows_fit_lds(g) ? nullptr : w.lane_off + (size_t)batch * g.rows * (kDecThreads + himg_dev::kRecHdr);
   w.row_off = (uint32_t *)ctx->d_rows.p;
   w.row_len = w.row_off + (size_t)batch * g.rows;
   w.lres_sym = (uint8_t *)ctx->d_lres.p; w.lres_stride = lres;

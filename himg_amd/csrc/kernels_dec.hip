@@ -1113,13 +1113,18 @@ __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t 
 // phase survives thousands of tokens there -- every round moves every lane of such a
 // stretch to one of the same few phases again, and the correction passes along the
 // chain one lane per round: rounds that are look-ups instead of decodes.
-template <bool SOA = false, class RD = GReader, int MEMO = 0>
+// NQ > 0: the lane's walk is cut at NQ more marks (mark[k], non-decreasing, between the
+// re-join point and lim): on return mark[k] = the first token boundary at or past the mark
+// and mcnt[k] = the symbols of the lane's tokens in front of it (k_row_count for rows that
+// go through windows: four records per lane).
+template <bool SOA = false, class RD = GReader, int MEMO = 0, int NQ = 0>
 __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, StreamShared *sh,
                                               uint32_t first, bool active, uint32_t lim,
                                               uint32_t *start_io, uint32_t *endpos_io,
                                               uint32_t *cnt_io, uint32_t *rounds, bool warm,
                                               uint32_t lead_bits, long long *c_first = nullptr,
-                                              long long *c_phase = nullptr, uint32_t *memo = nullptr) {
+                                              long long *c_phase = nullptr, uint32_t *memo = nullptr,
+                                              uint32_t *mark = nullptr, uint32_t *mcnt = nullptr) {
   const int tid = threadIdx.x;
   const long long t_in = clock64();
   uint32_t start = *start_io, endpos = *endpos_io, cnt = *cnt_io;
@@ -1154,6 +1159,16 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
   uint32_t T = nominal + kJoinBits;
   if (T > lim || T < nominal) T = lim;
   uint32_t posT = ~0u, cT = 0;
+  uint32_t mk[NQ > 0 ? NQ : 1], mp[NQ > 0 ? NQ : 1], mc[NQ > 0 ? NQ : 1];
+  if (NQ > 0) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      uint32_t m = mark[k];
+      if (m < T) m = T;
+      if (m > lim) m = lim;
+      mk[k] = m; mp[k] = start; mc[k] = 0;
+    }
+  }
   for (;;) {
     bool hit = false;
     if (MEMO > 0 && dirty) {
@@ -1167,12 +1182,28 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
       lean_count<SOA>(rd, tb, start, T, &p1, &c1);
       if (p1 == posT) {
         cnt = c1 + (cnt - cT);
+        if (NQ > 0) {
+#pragma unroll
+          for (int k = 0; k < NQ; ++k) mc[k] += c1 - cT;
+        }
         if (*rounds) atomicAdd(&sh->dbg[0], 1u);
       } else {
         if (*rounds) atomicAdd(&sh->dbg[1], 1u);
-        uint32_t c2;
-        lean_count<SOA>(rd, tb, p1, lim, &endpos, &c2, start < T);
-        cnt = c1 + c2;
+        uint32_t c2, pos = p1, acc = c1;
+        bool at = start < T;   // the reader stands at `pos`
+        if (NQ > 0) {
+#pragma unroll
+          for (int k = 0; k < NQ; ++k) {
+            uint32_t ck;
+            lean_count<SOA>(rd, tb, pos, mk[k], &mp[k], &ck, at);
+            at = at || pos < mk[k];
+            pos = mp[k];
+            acc += ck;
+            mc[k] = acc;
+          }
+        }
+        lean_count<SOA>(rd, tb, pos, lim, &endpos, &c2, at);
+        cnt = acc + c2;
       }
       posT = p1;
       cT = c1;
@@ -1197,6 +1228,10 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
   *start_io = start;
   *endpos_io = endpos;
   *cnt_io = cnt;
+  if (NQ > 0) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) { mark[k] = active ? mp[k] : start; mcnt[k] = active ? mc[k] : 0u; }
+  }
 }
 
 // Write pass of one lane straight into LDS: the tokens that start in [bp, lim)
@@ -1210,6 +1245,9 @@ __device__ __forceinline__ void lean_fixpoint(RD &rd, const GrpTables &tb, Strea
 // front of the window or inside it (win_span = window bytes + kWinGuard: one unsigned
 // compare), so the two dwords it touches stay inside [0, win_span + 8).
 constexpr uint32_t kWinGuard = 16;
+constexpr uint32_t kRowWindow = 128u * 1024u;   // k_row_window: symbols of a row per workgroup (64 KiB windows, two
+                                                // workgroups per CU: 1.12 -> 1.69 ms at 16384^2 -- half the lanes idle,
+                                                // the per-workgroup costs twice)
 // chain: [bp, lim) is a stretch of k_row_count_w's chain of groups (lane_off's valid flag
 // 3): the groups taken from bp end exactly at lim, one loop without a token-by-token tail.
 template <bool CLIP = false>
@@ -1642,7 +1680,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_huff(Geom g, DecWs ws, cons
     out = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)r * g.row_block;
     if (use_row_count) {
       pre_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+      pre_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + kRecHdr);
       // use_row_count == 2: rows with a usable fixpoint were written by k_row_window.
       if (use_row_count == 2 && pre_off[kDecThreads + 2] != 0) return;
     }
@@ -2561,7 +2599,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint32_t pre_lr[4] = {0, 0, 0, 0}, pre_off0 = 0, pre_len0 = 0;
   if constexpr (COLS == 512) {
     const size_t ri = (size_t)f * g.rows + (size_t)(r0 + (int)blockIdx.x);
-    const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + 4);
+    const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + kRecHdr);
     pl.start = ps[tid]; pl.off = po[tid]; pl.nxt = po[tid + 1];
     pl.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
     pl.tot = po[kDecThreads]; pl.endrel = po[kDecThreads + 1]; pl.valid = po[kDecThreads + 2]; pl.rounds = po[kDecThreads + 3];
@@ -2637,7 +2675,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
         (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, nullptr, nullptr,
         ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
         ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
-        ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4));
+        ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + kRecHdr));
   };
   int bad = 0;
   if constexpr (COLS == 512) {
@@ -2719,10 +2757,15 @@ __device__ __forceinline__ uint32_t block_scan_u32d(uint32_t v, uint32_t *sm, ui
   return pre + incl - v;
 }
 
-template <class RD>
+// QTR: three more boundaries inside every lane's range (lean_fixpoint's marks at 1/4, 1/2,
+// 3/4) go to l_q ([6][kDecThreads]: positions, then output offsets), and the quarter
+// records that hold the first symbol of every 128 KiB window of the row's symbols to the
+// header (k_row_window then has 1024 sub-sequences per window to walk instead of 256).
+template <class RD, bool QTR = false>
 __device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, StreamShared *sh, uint32_t *sm32,
                                               uint32_t rel0, uint32_t rem, uint32_t sb, uint32_t lead_bits,
-                                              uint32_t *l_start, uint32_t *l_off, uint32_t *rc, long long c_in) {
+                                              uint32_t *l_start, uint32_t *l_off, uint32_t *rc, long long c_in,
+                                              uint32_t *l_q = nullptr, uint32_t out_size = 0, uint32_t window = 0) {
   const int tid = threadIdx.x;
   const uint32_t rel_end = rel0 + rem;
   const SubGrid sg = sub_grid(rel0, rem, sb, tid);
@@ -2732,20 +2775,51 @@ __device__ __forceinline__ void row_count_one(RD &rd, const GrpTables &tb, Strea
   uint32_t start = active ? my_b0 : rel_end, endpos = start, cnt = 0, rounds = 0;
   long long c_phase[2] = {0, 0};
   const long long c_fix0 = clock64();
-  lean_fixpoint<true>(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, lead_bits, nullptr, c_phase);
+  uint32_t mark[3] = {0, 0, 0}, mcnt[3] = {0, 0, 0};
+  if (QTR) {
+    const uint32_t q = active ? (lim - my_b0) >> 2 : 0u;
+    mark[0] = start + q; mark[1] = start + 2u * q; mark[2] = start + 3u * q;
+    lean_fixpoint<true, RD, 0, 3>(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, lead_bits, nullptr,
+                                  c_phase, nullptr, mark, mcnt);
+  } else {
+    lean_fixpoint<true>(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &rounds, false, lead_bits, nullptr, c_phase);
+  }
   const long long c_fix1 = clock64();
   // 32-bit scan: a lane's count is clamped to 2^22 - 1, more than a whole row holds
   // (the caller only comes here for rows below 2^22 symbols), so 1024 of them cannot
   // wrap, valid streams are exact, and a lane that claims more still overruns the
   // block in the write pass and is rejected there like before.
   uint32_t tot;
-  const uint32_t off = block_scan_u32d(min(cnt, 0x3fffffu), sm32, &tot);
+  const uint32_t cc = min(cnt, 0x3fffffu);
+  const uint32_t off = block_scan_u32d(cc, sm32, &tot);
   l_start[tid] = start - rel0;
   l_off[tid] = off;
+  if (QTR) {
+    uint32_t o[5];
+    o[0] = off; o[4] = off + cc;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      o[k + 1] = off + min(mcnt[k], cc);
+      l_q[k * kDecThreads + tid] = mark[k] - rel0;
+      l_q[(3 + k) * kDecThreads + tid] = o[k + 1];
+    }
+    // The quarter record that holds the first symbol of window w (w >= 1).
+    if (window && cc) {
+      for (uint32_t w = (o[0] + window - 1u) / window; w * window < o[4] && w * window < out_size && w < (uint32_t)(kRecHdr - kRecWin); ++w) {
+        if (w == 0) continue;
+        const uint32_t X = w * window;
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) if (X >= o[j]) k = j;
+        l_off[kDecThreads + kRecWin + w] = 4u * (uint32_t)tid + (uint32_t)k;
+      }
+    }
+  }
   if (tid == last_active) l_off[kDecThreads + 1] = endpos - rel0;
   if (tid == 0) {
     l_off[kDecThreads] = tot;
     l_off[kDecThreads + 3] = rounds | (min(sh->dbg[0], 4095u) << 8) | (min(sh->dbg[1], 4095u) << 20);
+    l_off[kDecThreads + 4] = QTR ? 1u : 0u;
     l_off[kDecThreads + 2] = 1;   // (no fence: the consumer is a later kernel)
   }
   if ((tid & 63) == 0 && rc) {   // cycles / 16, slowest wave of the workgroup
@@ -2808,9 +2882,10 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
   for (int r = rb; r < min(rb + rows_per_wg, r1); ++r) {
     const long long c_in = clock64();
     uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+    uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + kRecHdr);
     uint32_t *rc = ws.rc_stats ? ws.rc_stats + ((size_t)f * g.rows + r) * 8 : nullptr;
     if (tid == 0) { l_off[kDecThreads + 2] = 0; sh.dbg[0] = sh.dbg[1] = 0; }   // not usable until proven otherwise
+    if (tid >= kRecWin && tid < kRecHdr) l_off[kDecThreads + tid] = ~0u;            // no window index yet (k_row_window checks what it finds)
     const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
     const unsigned long long rem = 8ull * pay_len;
     uint32_t sb = (uint32_t)((rem + kDecThreads - 1) / kDecThreads);
@@ -2834,7 +2909,11 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
       row_count_one(lr, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
     } else {
       __syncthreads();   // the tables are in / the previous row is done with the exchange slots
-      row_count_one(rd, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
+      if (ws.lane_q)     // rows that go through windows: four records per lane
+        row_count_one<GReader, true>(rd, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in,
+                                     ws.lane_q + ((size_t)f * g.rows + r) * (6 * kDecThreads), (uint32_t)g.row_block, kRowWindow);
+      else
+        row_count_one(rd, tb, &sh, sm32, rel0, (uint32_t)rem, sb, (uint32_t)g.lead_bits, l_start, l_off, rc, c_in);
     }
   }
 }
@@ -2984,7 +3063,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   if (r >= r1) return;
   const uint8_t *p = packed + (size_t)f * in_stride;
   uint32_t *l_start = ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads;
-  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + 4);
+  uint32_t *l_off = ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + kRecHdr);
   if (lane == 0) l_off[kDecThreads + 2] = 0;   // not usable until proven otherwise
   const uint32_t pay_off = ws.row_off[(size_t)f * g.rows + r], pay_len = ws.row_len[(size_t)f * g.rows + r];
   const unsigned long long rem64 = 8ull * pay_len;
@@ -3112,6 +3191,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
   if (lane == 0) {
     l_off[kDecThreads] = base;
     l_off[kDecThreads + 3] = rounds;
+    l_off[kDecThreads + 4] = 0;   // one record per lane (no boundaries inside the lanes' ranges)
     l_off[kDecThreads + 2] = 3;   // boundaries of the write pass's chain of groups (no fence: the consumer is a later kernel)
   }
 }
@@ -3128,7 +3208,6 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
 // against 1.0 ms for the same walk without the stores, plus 0.4 ms to clear the plane.)
 // Rows without a usable fixpoint from k_row_count are k_dec_huff's, as before.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kRowWindow = 128u * 1024u;
 struct WinShared { int flag, err; unsigned long long endbit; };
 __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, const uint8_t *packed,
                                                             size_t in_stride, const uint32_t *sizes, int r0) {
@@ -3139,45 +3218,86 @@ __global__ __launch_bounds__(kDecThreads) void k_row_window(Geom g, DecWs ws, co
   const int wi = blockIdx.x, r = r0 + (int)blockIdx.y, f = blockIdx.z, tid = threadIdx.x;
   DecFrame *df = ws.frames + f;
   const size_t ri = (size_t)f * g.rows + r;
-  const uint32_t *pre_start = ws.lane_start + ri * kDecThreads, *pre_off = ws.lane_off + ri * (kDecThreads + 4);
+  const uint32_t *pre_start = ws.lane_start + ri * kDecThreads, *pre_off = ws.lane_off + ri * (kDecThreads + kRecHdr);
+  const uint32_t *lq = ws.lane_q ? ws.lane_q + ri * (6 * kDecThreads) : nullptr;
   // Everything from global memory in front of the first barrier.
-  const uint32_t st_rel = pre_start[tid], off = pre_off[tid], nxt = pre_off[tid + 1];
-  const uint32_t nst_rel = tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u;   // the lane walks to its neighbour's start
   const uint32_t tot = pre_off[kDecThreads], usable = pre_off[kDecThreads + 2];
+  const bool quarters = lq != nullptr && pre_off[kDecThreads + 4] != 0;   // four records per lane (k_row_count for wide rows)
   const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri], ssize = sizes[f];
-  if (tid == 0) { sh.flag = (df->status || usable == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
-  load_dec_tables(ws, df, f, 1, &T);
+  const unsigned long long P1 = 8ull * pay_len;
+  // Record q of the row (quarters: 4 * lane + k, else the lane): where its tokens start (bits
+  // from the row's first) and its first symbol; the record behind it closes its range.
+  const uint32_t nrec = quarters ? 4u * (uint32_t)kDecThreads : (uint32_t)kDecThreads;
+  auto rec_pos = [&](uint32_t q) -> uint32_t {
+    if (q >= nrec) return (uint32_t)P1;
+    if (!quarters) return pre_start[q];
+    const uint32_t t = q >> 2, k = q & 3u;
+    return k == 0 ? pre_start[t] : lq[(k - 1u) * kDecThreads + t];
+  };
+  auto rec_off = [&](uint32_t q) -> uint32_t {
+    if (q >= nrec) return tot;
+    if (!quarters) return pre_off[q];
+    const uint32_t t = q >> 2, k = q & 3u;
+    return k == 0 ? pre_off[t] : lq[(2u + k) * kDecThreads + t];
+  };
   const uint32_t out_size = (uint32_t)g.row_block;
   const uint32_t w0 = (uint32_t)wi * kRowWindow, w1 = min(w0 + kRowWindow, out_size);
+  // The window's first record, from the row's index.  (Checked below by the lane that gets
+  // it: a record that does not hold the window's first symbol -- stale words -- sends the
+  // workgroup through all records instead.)
+  uint32_t q0 = 0;
+  if (quarters && wi > 0 && wi < kRecHdr - kRecWin) {
+    const uint32_t c = pre_off[kDecThreads + kRecWin + wi];
+    if (c < nrec) q0 = c;
+  }
+  uint32_t q = q0 + (uint32_t)tid;
+  uint32_t st_rel = rec_pos(q), nst_rel = rec_pos(q + 1u), off = rec_off(q), nxt = rec_off(q + 1u);
+  if (tid == 0) { sh.flag = (df->status || usable == 0) ? 1 : 0; sh.err = 0; sh.endbit = ~0ull; }
+  load_dec_tables(ws, df, f, 1, &T);
   const uint32_t span = (w1 - w0) + kWinGuard;           // guard + window bytes
   {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
     for (uint32_t k = tid; k < (span + kWinGuard + 15u) / 16u; k += kDecThreads) reinterpret_cast<uint4 *>(win)[k] = z;
   }
-  __syncthreads();
+  const int stale = __syncthreads_or((tid == 0 && q0 != 0 && !(off <= w0 && w0 < nxt)) ? 1 : 0);
   if (sh.flag) return;   // frame failed, or the row is k_dec_huff's
+  if (stale) {           // (uniform) the index did not name the window's first record: from the row's first
+    q = (uint32_t)tid;
+    st_rel = rec_pos(q); nst_rel = rec_pos(q + 1u); off = rec_off(q); nxt = rec_off(q + 1u);
+  }
   const GrpTables tb = tables_of(&T);
-  const unsigned long long P1 = 8ull * pay_len;
   GReader rd;
   const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, ssize, 8ull * pay_off);
-  const uint32_t lim = nst_rel < (uint32_t)P1 ? rel0 + nst_rel : rel0 + (uint32_t)P1;
-  const uint32_t cnt = nxt - off;
-  // The lane's symbols [off, off + cnt) against the window; positions are handed to the
-  // write loops relative to the window's guard (they wrap below zero in front of it:
-  // the clip test is one unsigned compare).
-  const bool inside = off + cnt < out_size, exact = !inside && off < out_size;
-  const bool touches = cnt > 0 && off < w1 && off + cnt > w0;
   const uint32_t rel_out = out_size - w0 + kWinGuard;    // the block's end, same origin
-  if (touches || (exact && wi == (int)((out_size - 1u) / kRowWindow))) {
-    uint32_t end_bp = ~0u;
-    const uint32_t op = off - w0 + kWinGuard;
-    if (inside) {
-      if (!lean_write<true>(rd, tb, rel0 + st_rel, lim, op, win, span, usable == 3u)) sh.err = 1;
-    } else if (exact) {
-      if (!exact_write<true>(rd, tb, rel0 + st_rel, lim, op, rel_out, win, &end_bp, span)) sh.err = 1;
-      if (end_bp != ~0u) sh.endbit = (unsigned long long)(end_bp - rel0);
+  // Rounds of 1024 consecutive records (one round with one record per lane; with quarters
+  // one per window unless the window's symbols take more than a quarter of the payload).
+  for (;;) {
+    if (q < nrec) {
+      const uint32_t lim = nst_rel < (uint32_t)P1 ? rel0 + nst_rel : rel0 + (uint32_t)P1;
+      const uint32_t cnt = nxt - off;
+      // The record's symbols [off, off + cnt) against the window; positions are handed to the
+      // write loops relative to the window's guard (they wrap below zero in front of it:
+      // the clip test is one unsigned compare).
+      const bool inside = off + cnt < out_size, exact = !inside && off < out_size;
+      const bool touches = cnt > 0 && off < w1 && off + cnt > w0;
+      if (touches || (exact && wi == (int)((out_size - 1u) / kRowWindow))) {
+        uint32_t end_bp = ~0u;
+        const uint32_t op = off - w0 + kWinGuard;
+        if (inside) {
+          if (!lean_write<true>(rd, tb, rel0 + st_rel, lim, op, win, span, usable == 3u)) sh.err = 1;
+        } else if (exact) {
+          if (!exact_write<true>(rd, tb, rel0 + st_rel, lim, op, rel_out, win, &end_bp, span)) sh.err = 1;
+          if (end_bp != ~0u) sh.endbit = (unsigned long long)(end_bp - rel0);
+        }
+      }
     }
+    // Another round while the records behind this one can still reach the window.
+    const uint32_t qn = q - (uint32_t)tid + (uint32_t)kDecThreads;   // (uniform)
+    const int more = __syncthreads_or((tid == kDecThreads - 1 && q < nrec && nxt < w1) ? 1 : 0);
+    if (!more || qn >= nrec) break;
+    q = qn + (uint32_t)tid;
+    st_rel = rec_pos(q); nst_rel = rec_pos(q + 1u); off = rec_off(q); nxt = rec_off(q + 1u);
   }
   __syncthreads();
   // The window leaves as 16-byte stores (row blocks and windows are multiples of 16).
@@ -3230,6 +3350,8 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
     hipLaunchKernelGGL(name, grid, block, 0, stream, __VA_ARGS__); \
     prof_end(prof, stream);                                    \
   } while (0)
+
+bool dec_rows_fit_lds(const Geom &g) { return fused_layout(g.row_block).total <= 160u * 1024u; }
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
