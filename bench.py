@@ -636,9 +636,15 @@ def main():
             if os.path.exists(tpath) and std:
                 tj = json.load(open(tpath))
                 per_frame = {k.split("<")[0]: v for k, v in tj.get("bytes_per_frame", {}).items()}
-                if key in per_frame:
-                    traffic = per_frame[key] * G
-                    traffic_src = "profiles/traffic.json (PMC passes at commit %s, not this run)" % tj.get("git_sha", "?")
+                per_launch = {k.split("<")[0]: v for k, v in tj.get("bytes_per_launch", {}).items()}
+                if key in per_launch and tj.get("frames_per_launch") == G:
+                    traffic = per_launch[key]          # read: the PMC passes ran this launch size
+                    traffic_src = "profiles/traffic.json (PMC passes at commit %s with %d frames per launch, not this run)" % (
+                        tj.get("git_sha", "?"), G)
+                elif key in per_frame:
+                    traffic = per_frame[key] * G       # scaled from %d frames per launch
+                    traffic_src = "profiles/traffic.json (PMC passes at commit %s with %s frames per launch, scaled; not this run)" % (
+                        tj.get("git_sha", "?"), tj.get("frames_per_launch", "?"))
                 pmc = tj.get("valu", {})
             # VALU issue of that kernel from the same PMC passes: the SIMD issue time of its
             # instruction count at the kernel's class-weighted measured cost

@@ -102,6 +102,8 @@ def lib():
     L.himg_hip_shard_row_bits.argtypes = [vp, vp, vp, vp]
     L.himg_hip_shard_emit.argtypes = [vp, vp, vp, sz, vp, vp]
     L.himg_hip_shard_assemble.argtypes = [vp, vp, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.himg_hip_shard_head.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.himg_hip_shard_finish.argtypes = [vp, vp, sz, vp, vp]
     L.himg_hip_debug_read.argtypes = [vp, i32, i32, vp, sz, P(sz)]
     L.himg_hip_profile_enable.argtypes = [vp, i32]
     L.himg_hip_profile_reset.argtypes = [vp]
@@ -341,6 +343,15 @@ class Engine:
                                            _ptr(d_rel), rel_bytes, _ptr(d_out), out_cap,
                                            _ptr(d_size), _ptr(d_status), C.c_void_p(stream))
         self._check(rc, "shard_assemble")
+
+    def shard_head(self, d_low_full, d_all_row_bits, d_out, out_cap, d_size, d_head, d_status, stream=0):
+        rc = lib().himg_hip_shard_head(self._ctx, _ptr(d_low_full), _ptr(d_all_row_bits), _ptr(d_out), out_cap,
+                                       _ptr(d_size), _ptr(d_head), _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "shard_head")
+
+    def shard_finish(self, d_out, out_cap, d_size, stream=0):
+        rc = lib().himg_hip_shard_finish(self._ctx, _ptr(d_out), out_cap, _ptr(d_size), C.c_void_p(stream))
+        self._check(rc, "shard_finish")
 
     # introspection ---------------------------------------------------------------
     def debug_read(self, what, frame, nbytes, dtype=np.uint8, decoder=False):

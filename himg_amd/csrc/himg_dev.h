@@ -193,6 +193,12 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
                            const uint8_t *d_rel, size_t rel_bytes, uint8_t *d_out, size_t out_cap,
                            uint32_t *d_size, hipStream_t stream, Profiler *prof);
 
+void launch_shard_head(const Geom &g, const EncWs &ws, const StaticChunks &sc, const LresTables &lt,
+                       const uint32_t *d_all_row_bits, uint8_t *d_out, size_t out_cap, uint32_t *d_size,
+                       uint32_t *d_head, int r0, int r1, hipStream_t stream, Profiler *prof);
+void launch_shard_finish(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_cap, const uint32_t *d_size,
+                         hipStream_t stream, Profiler *prof);
+
 // Stage timing hook: called before/after every kernel launch when profiling.
 void prof_begin(Profiler *p, const char *stage, hipStream_t s);
 void prof_end(Profiler *p, hipStream_t s);

@@ -1235,6 +1235,34 @@ extern "C" int himg_hip_shard_assemble(himg_hip_ctx *ctx, const uint8_t *d_low_f
   return HIMG_OK;
 }
 
+extern "C" int himg_hip_shard_head(himg_hip_ctx *ctx, const uint8_t *d_low_full, const uint32_t *d_all_row_bits,
+                                   void *d_out, size_t out_cap, uint32_t *d_size, uint32_t *d_head,
+                                   int32_t *d_status, void *stream) {
+  if (!ctx || !ctx->shard.valid || !d_low_full || !d_all_row_bits || !d_out || !d_size || !d_head)
+    return HIMG_ERR_ARG;
+  if ((out_cap & 255) || ((uintptr_t)d_out & 15)) return fail(ctx, HIMG_ERR_ARG, "bad output buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto &sh = ctx->shard;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->enc_ws.low, d_low_full, (size_t)sh.g.C * sh.g.rows * sh.g.cols,
+                              hipMemcpyDeviceToDevice, s));
+  launch_shard_head(sh.g, ctx->enc_ws, sh.sc, sh.lt, d_all_row_bits, (uint8_t *)d_out, out_cap, d_size, d_head,
+                    sh.r0, sh.r1, s, &ctx->prof);
+  if (d_status)
+    hipLaunchKernelGGL(k_copy_status, dim3(1), dim3(64), 0, s, ctx->enc_ws.status, d_status, 1);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_shard_finish(himg_hip_ctx *ctx, void *d_out, size_t out_cap, const uint32_t *d_size,
+                                     void *stream) {
+  if (!ctx || !ctx->shard.valid || !d_out || !d_size) return HIMG_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  launch_shard_finish(ctx->shard.g, ctx->enc_ws, (uint8_t *)d_out, out_cap, d_size, (hipStream_t)stream, &ctx->prof);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Introspection.
 // ---------------------------------------------------------------------------

@@ -2104,4 +2104,48 @@ void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &s
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, 1), b256, g, ws, d_out, out_cap, d_size);
 }
 
+// Rank 0 of a row-sharded encode, final-placement form: everything of the stream that does
+// not come from another rank goes straight into the stream buffer -- container, LRES stream,
+// FRES tree, EVERY row's size header (rank 0 knows all row sizes) and the payloads of its own
+// rows [r0, r1) -- and d_head tells the host where the first row header lies ([0], bytes)
+// and how long the stream is ([1]): the other ranks' packed rows are then received at their
+// final offsets (no relative buffer on rank 0, no 262 MB k_place_fres copy at 16384^2), and
+// all of this runs while the peers still pack and send.  launch_shard_finish resolves the
+// stale pad bits (trap T1) once every row has arrived.
+__global__ void k_shard_head_info(Geom g, EncWs ws, const uint32_t *size, uint32_t *head) {
+  const uint32_t b0 = ws.span_bits[g.lres_spans];   // row 0
+  const uint32_t n0 = (b0 + 7) >> 3;
+  const uint32_t hdr0 = g.use_blocks ? (n0 <= 0x7fffu ? 2u : 4u) : 0u;
+  head[0] = (uint32_t)(ws.span_bit0[g.lres_spans] >> 3) - hdr0;
+  head[1] = size[0];
+}
+
+void launch_shard_head(const Geom &g, const EncWs &ws, const StaticChunks &sc, const LresTables &lt,
+                       const uint32_t *d_all_row_bits, uint8_t *d_out, size_t out_cap, uint32_t *d_size,
+                       uint32_t *d_head, int r0, int r1, hipStream_t stream, Profiler *prof) {
+  const dim3 b256(256);
+  (void)hipMemsetAsync(ws.hist, 0, kHistStride * sizeof(uint32_t), stream);  // LRES histogram only
+  {
+    const size_t start = (size_t)(kHeadLen & ~3);
+    size_t width = (size_t)g.lres_size + kTreeStride + 64;
+    if (start + width > out_cap) width = out_cap - start;
+    (void)hipMemsetAsync(d_out + start, 0, width, stream);
+  }
+  HIMG_LAUNCH(k_lres_predict, dim3((g.mcols + 3) / 4, g.mrows, g.C), dim3(64), g, ws.low, ws.plane_stride,
+              ws.lres_sym, ws.lres_stride, lt);
+  HIMG_LAUNCH(k_lres_summary, dim3(g.lres_spans, 1), b256, g, ws);
+  HIMG_LAUNCH(k_tok_hist<256>, dim3(g.lres_spans, 1), b256, g, ws, 0);
+  HIMG_LAUNCH(k_tree, dim3(1, 1), dim3(kTreeThreads), ws, 0);
+  HIMG_LAUNCH(k_span_bits, dim3((g.lres_spans + 3) / 4, 1), b256, g, ws, 0, g.lres_spans, (uint32_t *)nullptr);
+  HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0, 0, g.rows);
+  hipLaunchKernelGGL(k_shard_head_info, dim3(1), dim3(1), 0, stream, g, ws, d_size, d_head);
+  launch_emit(g, ws, d_out, out_cap, d_size, 0, g.lres_spans, 1, stream, prof);
+  if (r1 > r0) launch_emit(g, ws, d_out, out_cap, d_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
+}
+
+void launch_shard_finish(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_cap, const uint32_t *d_size,
+                         hipStream_t stream, Profiler *prof) {
+  HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, 1), dim3(256), g, ws, d_out, out_cap, d_size);
+}
+
 }  // namespace himg_dev

@@ -10,9 +10,11 @@ collectives of SURVEY.md 8(e) between the device phases of the C ABI
                -> low-res rows to rank 0, point to point         (1/64 of the pixels)
     row_bits   -> all-gather payload bits of every block row     (rows x u32)
     emit       -> the packed rows to rank 0, point to point,     (the only large message;
-                  exact sizes, received in place                  each peer -> rank 0 over
-                                                                   its own xGMI link)
-    assemble   (rank 0) LRES stream, container, FRES tree, rows, stale pad bits
+                  exact sizes, received at their FINAL offsets    each peer -> rank 0 over
+                  in rank 0's stream buffer                       its own xGMI link)
+    head       (rank 0, WHILE the peers pack and send) LRES stream, container, FRES tree,
+               every row's size header, its own rows -- straight into the stream buffer
+    finish     (rank 0) stale pad bits, once every row has arrived
 
 The result on rank 0 is byte-identical to encoding the whole frame on one GPU.
 `backend` hides the device: EngineBackend drives the HIP engine; the tests use a
@@ -76,6 +78,9 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=T
         row_bits(hist_global)  -> int32[r1-r0]
         emit(all_bits int32[rows], start, end) -> uint8[end-start]   (the local byte range)
         assemble(low_full uint8[C*rows*cols], all_bits, rel_full uint8[total], host) -> numpy uint8 / tensor
+      or, final-placement form (used when the backend has it):
+        head(low_full, all_bits, own_start, own_end) -> (stream buffer uint8[>= size], offset of the first row header)
+        finish(buffer, host) -> numpy uint8 / tensor
     All tensors live where the process group can move them (CUDA for nccl/RCCL,
     CPU for gloo)."""
     import torch
@@ -118,6 +123,38 @@ def encode_sharded(backend, rows, cols, channels, use_blocks, group=None, host=T
     total = layout[3]
 
     start, end = ranges[rank]
+    if hasattr(backend, "head"):
+        # Final-placement form.  Rank 0 does not pack into a relative buffer and assemble
+        # afterwards: as soon as the row sizes are known it builds everything that does not
+        # come from a peer -- LRES stream, container, tree, every row header, its own rows --
+        # in the stream buffer itself, learns where the first row header lies (one 8-byte
+        # read-back), and receives every peer's byte range AT ITS FINAL OFFSET, each over
+        # that peer's own link.  Its LRES branch and its own packing run while the peers
+        # pack and send; behind the last receive only the pad-bit fix-up is left.
+        if rank != 0:
+            piece = backend.emit(all_bits, start, end)
+            reqs = list(low_reqs)
+            if end > start:
+                reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, piece.contiguous(), 0, group)])
+            for req in reqs:
+                req.wait()
+            return None
+        for req in low_reqs:
+            req.wait()
+        if world > 1:
+            low_full = torch.empty(channels * rows * cols, dtype=torch.uint8, device=low.device)
+            lf = low_full.view(channels, rows, cols)
+            for ll, (p0, p1) in zip(low_list, parts):
+                if p1 > p0:
+                    lf[:, p0:p1, :] = ll[: channels * (p1 - p0) * cols].view(channels, p1 - p0, cols)
+        else:
+            low_full = low
+        out, base = backend.head(low_full, all_bits, start, end)   # `out`: the stream buffer as the process group sees it
+        ops = [dist.P2POp(dist.irecv, out[base + s: base + e], peer, group)
+               for peer, (s, e) in enumerate(ranges) if peer and e > s]
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        return backend.finish(out, host)
     piece = backend.emit(all_bits, start, end)
     if world == 1:
         # One rank holds everything already: no copies (a 16384x16384 frame's packed rows
@@ -222,6 +259,44 @@ class EngineBackend:
         self._all_bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
         self.eng.shard_emit(self._all_bits_dev, self._rel, self._rel_cap, self._size, self._s())
         return self._to_comm(self._rel[start:end])
+
+    def head(self, low_full, all_bits, own_start, own_end):
+        """Rank 0, final-placement form: everything but the peers' rows into the stream buffer
+        ([own_start, own_end): the byte range of this rank's own rows behind the first row
+        header).  Returns (buffer as the process group sees it, offset of the first row header)."""
+        self._own_range = (own_start, own_end)
+        import torch
+        import himg_amd
+        if self._out is None:
+            self._out = torch.empty(self._out_cap, dtype=torch.uint8, device=self.dev)
+            self._head = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        bits_dev = all_bits.to(self.dev).to(torch.int32).contiguous()
+        self.eng.shard_head(low_full.to(self.dev).contiguous(), bits_dev, self._out, self._out_cap, self._size,
+                            self._head, self._status, self._s())
+        h = torch.cat([self._head[:2], self._status[:1]]).cpu()      # the one wait of this phase (12 bytes)
+        if int(h[2]) != 0 or int(h[1]) == 0:
+            raise himg_amd.HimgError(-int(h[2]) if int(h[2]) else himg_amd.HIMG_ERR_UNSUPPORTED, "sharded head failed")
+        self._total = int(h[1])
+        if self.comm == self.dev:
+            return self._out, int(h[0])
+        self._stage = torch.empty(self._total, dtype=torch.uint8, device=self.comm)   # (tests: gloo with CPU staging)
+        return self._stage, int(h[0])
+
+    def finish(self, out, host=True):
+        import torch
+        if self.comm != self.dev:
+            # The peers' ranges arrived in the staging tensor: move what lies behind the
+            # first row header, except this rank's own rows, which head() packed in place.
+            s0, e0 = self._own_range
+            base = int(self._head[0].item())
+            n = self._total
+            if s0 > 0:
+                self._out[base:base + s0] = out[base:base + s0].to(self.dev)
+            if base + e0 < n:
+                self._out[base + e0:n] = out[base + e0:n].to(self.dev)
+        self.eng.shard_finish(self._out, self._out_cap, self._size, self._s())
+        res = self._out[: self._total]
+        return res.cpu().numpy() if host else res
 
     def assemble(self, low_full, all_bits, rel_full, host=True):
         import torch

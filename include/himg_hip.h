@@ -200,6 +200,20 @@ int himg_hip_shard_assemble(himg_hip_ctx *ctx, const uint8_t *d_low_full,
                             const uint32_t *d_all_row_bits, const void *d_rel, size_t rel_bytes,
                             void *d_out, size_t out_cap, uint32_t *d_size, int32_t *d_status,
                             void *stream);
+/* The assembling rank in its final-placement form (instead of shard_emit + shard_assemble
+ * there): once the row bit counts are known, shard_head builds everything that does not come
+ * from another rank straight in the stream buffer d_out -- container, LRES stream from the
+ * gathered low-res plane, FRES tree, every row's size header, the payloads of the rank's own
+ * rows -- while the peers still pack and send; d_head receives [0] the byte offset of the
+ * first row header in d_out and [1] the stream's size, so that the peers' byte ranges
+ * (relative to the first row header, himg_amd.sharded.fres_layout) are received in place at
+ * d_out + d_head[0] + start.  shard_finish, once every range has arrived: the stale pad bits
+ * (trap T1).  d_out: out_cap >= himg_hip_max_packed_size, a multiple of 256, 16-byte aligned. */
+int himg_hip_shard_head(himg_hip_ctx *ctx, const uint8_t *d_low_full, const uint32_t *d_all_row_bits,
+                        void *d_out, size_t out_cap, uint32_t *d_size, uint32_t *d_head,
+                        int32_t *d_status, void *stream);
+int himg_hip_shard_finish(himg_hip_ctx *ctx, void *d_out, size_t out_cap, const uint32_t *d_size,
+                          void *stream);
 
 /* ---- row-sharded decode of ONE frame over several GPUs -------------------- */
 /*

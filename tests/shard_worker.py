@@ -91,6 +91,22 @@ class StubBackend:
         rel = self.stream[off + self.tr["fres_tree_bytes"]: off + sz]
         return torch.from_numpy(rel[start:end].copy())
 
+    def head(self, low_full, all_bits, own_start, own_end):
+        """Final-placement form: the stream buffer with everything in it that rank 0 makes
+        itself; what the peers send is poisoned until it arrives."""
+        assert np.array_equal(low_full.numpy(), self.tr["lowres"]), "gathered low-res plane is wrong"
+        off, sz = self.chunks["FRES"]
+        base = off + self.tr["fres_tree_bytes"]
+        buf = np.full(self.stream.size + 64, 0xAA, np.uint8)
+        buf[:base] = self.stream[:base]
+        buf[base + own_start: base + own_end] = self.stream[base + own_start: base + own_end]
+        self._buf = torch.from_numpy(buf)
+        return self._buf, base
+
+    def finish(self, out, host=True):
+        assert out.data_ptr() == self._buf.data_ptr()
+        return out.numpy()[: self.stream.size].copy()
+
     def assemble(self, low_full, all_bits, rel_full, host=True):
         assert np.array_equal(low_full.numpy(), self.tr["lowres"]), "gathered low-res plane is wrong"
         off, sz = self.chunks["FRES"]

@@ -80,18 +80,23 @@ def test_config4_16384_rows_sharded_over_8_ranks():
     bits = [b.row_bits(hist) for b in backs]
     all_bits = torch.cat(bits)                                # = all-gather
     layout = sharded.fres_layout(all_bits.cpu().numpy(), True)
-    rel_full = torch.empty(layout[3], dtype=torch.uint8, device=dev)
-    for b, (r0, r1) in zip(backs, ranges):                    # = gather of the packed rows
-        s, e = sharded.piece_range(layout, r0, r1)
-        rel_full[s:e] = b.emit(all_bits, s, e)
     low_full = torch.empty(4 * rows * cols, dtype=torch.uint8, device=dev)
     lf = low_full.view(4, rows, cols)
     for (r0, r1), s in zip(ranges, stats):                    # = gather of the low-res rows
         lf[:, r0:r1, :] = s[1].view(4, r1 - r0, cols)
-    stream = backs[0].assemble(low_full, all_bits, rel_full, host=False)
+    # Rank 0 in its final-placement form (what encode_sharded runs): LRES stream, container,
+    # tree, all row headers and its own rows straight into the stream buffer; the peers'
+    # byte ranges land at their final offsets (the receive of sharded.py, by hand), then
+    # the pad bits.
+    s0, e0 = sharded.piece_range(layout, *ranges[0])
+    buf, base = backs[0].head(low_full, all_bits, s0, e0)
+    for b, (r0, r1) in list(zip(backs, ranges))[1:]:          # = the peers' sends, received in place
+        s, e = sharded.piece_range(layout, r0, r1)
+        buf[base + s: base + e] = b.emit(all_bits, s, e)
+    stream = backs[0].finish(buf, host=False)
     for b in backs:
         b.eng.close()
-    del backs, rel_full, stats
+    del backs, stats
     assert stream.numel() == rec["packed_size"] == 275620945
     assert himg_amd.fnv1a64(stream.cpu().numpy()) == rec["stream_fnv"] == "5bdcdb7a140df481"
 

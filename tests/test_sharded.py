@@ -82,13 +82,17 @@ def test_sharded_orchestration_gloo_cpu(tmp_path, world, w, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["assemble", "head"])
 @pytest.mark.parametrize("kind,w,h,q,parts", [
     ("randtile", 256, 512, 50, 2), ("randtile", 512, 1024, 50, 4), ("gradn", 256, 264, 90, 3),
     ("rand", 128, 512, 50, 2), ("randtile", 2048, 2048, 50, 8),
     ("randtile", 256, 800, 50, 8), ("gradn", 128, 128, 50, 2)])   # more ranks than macro rows: empty shares
-def test_sharded_device_phases_simulated_ranks(kind, w, h, q, parts):
+def test_sharded_device_phases_simulated_ranks(kind, w, h, q, parts, form):
     """All ranks simulated in one process (one engine context per rank): the
-    exchanges are done by hand exactly as encode_sharded does them."""
+    exchanges are done by hand exactly as encode_sharded does them -- in the
+    final-placement form it runs (rank 0: shard_head, the peers' ranges received at their
+    final offsets, shard_finish) and in the gather-then-assemble form of the C ABI's
+    multi-device handle."""
     import torch
     img = himg_amd.synth(kind, 1, w, h)
     rows, cols = h // 8, w // 8
@@ -105,16 +109,26 @@ def test_sharded_device_phases_simulated_ranks(kind, w, h, q, parts):
     bits = [b.row_bits(hist) for b in backs]
     all_bits = torch.cat(bits)
     layout = sharded.fres_layout(all_bits.cpu().numpy(), rows > 1)
-    rel_full = torch.empty(layout[3], dtype=torch.uint8, device="cuda:0")
-    for b, (r0, r1) in zip(backs, ranges):
-        s, e = sharded.piece_range(layout, r0, r1)
-        rel_full[s:e] = b.emit(all_bits, s, e)
     low_full = torch.empty(4 * rows * cols, dtype=torch.uint8, device="cuda:0")
     lf = low_full.view(4, rows, cols)
     for (r0, r1), s in zip(ranges, stats):
         if r1 > r0:
             lf[:, r0:r1, :] = s[1].view(4, r1 - r0, cols)
-    out = backs[0].assemble(low_full, all_bits, rel_full)
+    if form == "head":
+        s0, e0 = sharded.piece_range(layout, *ranges[0])
+        buf, base = backs[0].head(low_full, all_bits, s0, e0)
+        buf[base + e0: base + layout[3]] = 0xAA            # whatever is not a peer's to send stays rank 0's
+        for b, (r0, r1) in list(zip(backs, ranges))[1:]:
+            s, e = sharded.piece_range(layout, r0, r1)
+            if e > s:
+                buf[base + s: base + e] = b.emit(all_bits, s, e)
+        out = backs[0].finish(buf)
+    else:
+        rel_full = torch.empty(layout[3], dtype=torch.uint8, device="cuda:0")
+        for b, (r0, r1) in zip(backs, ranges):
+            s, e = sharded.piece_range(layout, r0, r1)
+            rel_full[s:e] = b.emit(all_bits, s, e)
+        out = backs[0].assemble(low_full, all_bits, rel_full)
     want = ol.oracle_encode(img, q, True)
     assert out.size == want.size
     d = np.nonzero(out != want)[0]

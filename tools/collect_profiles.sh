@@ -16,7 +16,7 @@ out = [{"workload": r["config"]["workload"], "bit_exact": r["config"]["bit_exact
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 PY
 cp "$SRC"/stats_default/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_default.csv"
-cp "$SRC"/stats_streams1/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_streams1.csv"
+cp "$SRC"/stats_b64/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_b64.csv"
 cp "$SRC/pmc/summary.json" "profiles/${TAG}_pmc_summary.json"
 cp "$SRC/traffic.json" profiles/traffic.json
 ls -la profiles/${TAG}_* profiles/traffic.json

@@ -50,6 +50,10 @@ for k, v in d.items():
                    "issue_frac_measured_mix": round(cost * v["SQ_INSTS_VALU"] / simd_cycles, 3) if cost else None,
                    "lds_conflict_frac": (round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 3)
                                          if v.get("SQ_LDS_IDX_ACTIVE") else None),
+                   # dynamic: thread-cycles in VALU instructions per executed instruction and 64 lanes
+                   # (a lower bound of the cycles per instruction: lanes masked off count as idle)
+                   "thread_cycles_per_valu_div64": (round(v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 64.0, 3)
+                                                    if v.get("SQ_THREAD_CYCLES_VALU") else None),
                    "dur_us": round(v["dur_us"], 1)}
 json.dump({"note": "HBM bytes per 4096x4096 RGBA q50 randtile frame per kernel launch: rocprofv3 --pmc FETCH_SIZE "
                    "(x2 only for the 16-byte-per-lane streaming kernels, the gfx950 correction of MI355X_MICROARCH.md; "
@@ -57,5 +61,7 @@ json.dump({"note": "HBM bytes per 4096x4096 RGBA q50 randtile frame per kernel l
                    "tools/profile_pmc.sh.  valu: SQ_INSTS_VALU per symbol; issue_frac_* = the SIMD issue time of that count "
                    "(at the guide's 2 cycles per instruction / at the kernel's class-weighted measured cost, "
                    "profiles/r03_isa_mix.json) over the kernel's duration on 1024 SIMDs." % frames_per_launch,
-           "git_sha": sha, "bytes_per_frame": t, "bytes_per_frame_fetch_raw": raw, "bytes_per_frame_fetch_x2": x2,
+           "git_sha": sha, "frames_per_launch": frames_per_launch,
+           "bytes_per_launch": {k: round((v.get("hbm_read_MB_corrected", 0) + v.get("hbm_write_MB", 0)) * 1e6) for k, v in d.items()},
+           "bytes_per_frame": t, "bytes_per_frame_fetch_raw": raw, "bytes_per_frame_fetch_x2": x2,
            "valu": valu}, open(out, "w"), indent=1)

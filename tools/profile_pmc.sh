@@ -17,6 +17,9 @@ run() {
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAIT_INST_LDS
+# Dynamic evidence for the issue model: thread-cycles spent in VALU instructions (per
+# executed instruction and active lane), the integer instruction classes, LDS traffic by kind.
+run sq3 SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_IOPS SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INST_CYCLES_SALU
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
 python3 "$ROOT/tools/summarize_pmc.py" "$ROOT/$OUT" > "$ROOT/$OUT/summary.txt" 2>&1

@@ -10,8 +10,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 # The PMC passes first: bench.py quotes profiles/traffic.json (HBM bytes per launch, issue
 # fractions) next to its live timings, so the file it reads must be this commit's.
-(cd "$ROOT" && BENCH_ARGS="--streams 1 --batch 16 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
- python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 16 "$OUT/traffic.json" "$SHA" && cp "$OUT/traffic.json" profiles/traffic.json)
+# (At the DEFAULT batch, 128 frames per launch: what bench.py's line quotes is then read from
+# these passes, not scaled from a smaller launch.)
+(cd "$ROOT" && BENCH_ARGS="--streams 1 --no-rows" bash tools/profile_pmc.sh "$OUT/pmc" > "$ROOT/$OUT/pmc.log" 2>&1
+ python3 tools/make_traffic_json.py "$OUT/pmc/summary.json" 128 "$OUT/traffic.json" "$SHA" && cp "$OUT/traffic.json" profiles/traffic.json)
 python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench.json" 2> "$ROOT/$OUT/bench.err"
 # The same with 64 frames per launch: the batch DESIGN.md's per-kernel discussion is written for.
 python3 "$ROOT/bench.py" --batch 64 --no-rows --no-extras --no-cpu-baseline > "$ROOT/$OUT/bench_b64.json" 2> "$ROOT/$OUT/bench_b64.err"
@@ -28,9 +30,10 @@ for wh in "2048 2048" "1024 1024" "1920 1080"; do
   python3 "$ROOT/bench.py" --width $1 --height $2 --batch 256 --no-rows --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 >> "$ROOT/$OUT/configs.jsonl"
 done
 cd /tmp && export TMPDIR=/tmp
+# The driver's command (default batch), then the 64-frame launch DESIGN.md's per-kernel tables are written for.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_default" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --batch 64 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_streams1" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --streams 1 --batch 16 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_streams1.log" 2>&1
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_default.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_b64" -- \
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --batch 64 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_b64.log" 2>&1
 cd "$ROOT"
 ls "$ROOT/$OUT"
