@@ -86,6 +86,11 @@ def lib():
     L.himg_hip_decode_rows_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_decode_index_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp, vp]
     L.himg_hip_decode_rows_indexed_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.himg_hip_decode_rows_after_head_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.himg_hip_decode_head_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp]
+    L.himg_hip_decode_first_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp]
+    L.himg_hip_decode_walk_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp, vp]
+    L.himg_hip_decode_walk_wait.argtypes = [vp]
     L.himg_hip_index_host.argtypes = [vp, sz, i32, P(i32), P(i32), P(i32), vp, sz, P(C.c_uint32)]
     L.himg_hip_create_multi.argtypes = [vp, i32, P(vp)]
     L.himg_hip_destroy_multi.argtypes = [vp]
@@ -318,6 +323,39 @@ class Engine:
                                                        height, channels, row0, row1, _ptr(d_row_index),
                                                        _ptr(d_out_rows), _ptr(d_status), C.c_void_p(stream))
         self._check(rc, "decode_rows_indexed_device")
+
+    def decode_head_device(self, d_packed, packed_size, width, height, channels, stream=0):
+        """What needs only the head of the stream (container parse, LRES chain, predictor
+        inverse); decode_rows_after_head_device follows on the same stream."""
+        rc = lib().himg_hip_decode_head_device(self._ctx, _ptr(d_packed), int(packed_size), width, height,
+                                               channels, C.c_void_p(stream))
+        self._check(rc, "decode_head_device")
+
+    def decode_rows_after_head_device(self, d_packed, packed_size, width, height, channels, row0, row1,
+                                      d_row_index, d_out_rows, d_status, stream=0):
+        rc = lib().himg_hip_decode_rows_after_head_device(self._ctx, _ptr(d_packed), int(packed_size), width,
+                                                          height, channels, row0, row1, _ptr(d_row_index),
+                                                          _ptr(d_out_rows), _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "decode_rows_after_head_device")
+
+    def decode_first_device(self, d_packed, packed_size, width, height, channels, d_rows_first, d_status,
+                            stream=0):
+        """Offset of the first FRES row header of a stream in HBM, without the header walk."""
+        rc = lib().himg_hip_decode_first_device(self._ctx, _ptr(d_packed), int(packed_size), width, height,
+                                                channels, _ptr(d_rows_first), _ptr(d_status), C.c_void_p(stream))
+        self._check(rc, "decode_first_device")
+
+    def decode_walk_device(self, d_packed, packed_size, width, height, channels, d_row_index, d_rows_first,
+                           d_status, stream=0):
+        """The row index by the header walk alone, on the context's side stream (beside a head
+        phase launched after this call); results valid after decode_walk_wait()."""
+        rc = lib().himg_hip_decode_walk_device(self._ctx, _ptr(d_packed), int(packed_size), width, height, channels,
+                                               _ptr(d_row_index), _ptr(d_rows_first), _ptr(d_status),
+                                               C.c_void_p(stream))
+        self._check(rc, "decode_walk_device")
+
+    def decode_walk_wait(self):
+        self._check(lib().himg_hip_decode_walk_wait(self._ctx), "decode_walk_wait")
 
     # row-sharded encode (see himg_amd/sharded.py) --------------------------------------
     def shard_stats(self, d_frame_base, width, height, pixel_stride, channels, quality, use_ycbcr,

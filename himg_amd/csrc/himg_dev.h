@@ -177,7 +177,11 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
                    const DecStreams *ds, int r0, int r1,
-                   const uint32_t *d_row_index = nullptr, bool index_only = false);
+                   const uint32_t *d_row_index = nullptr, bool index_only = false, int phase = 3);
+constexpr int kDecHead = 1, kDecRows = 2;   // launch_decode's phases
+// The row-header walk of one frame alone (row-sharded decode: beside the head phase).
+void launch_rowwalk_only(const Geom &g, const DecWs &ws, const uint8_t *d_packed, size_t in_stride,
+                         const uint32_t *d_sizes, hipStream_t stream);
 
 // Row-sharded encode of one frame (multi-GPU): phases between the collectives.
 void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,

@@ -699,13 +699,10 @@ extern "C" int himg_hip_decode_index_device(himg_hip_ctx *ctx, const void *d_pac
 
 // Block rows [row0, row1) with the row index supplied (no header walk: the buffer
 // only has to hold the bytes in front of the first row header and the payloads of
-// these rows, each at its offset in the stream).
-extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void *d_packed,
-                                                   uint32_t packed_size, int width, int height,
-                                                   int num_channels, int row0, int row1,
-                                                   const uint32_t *d_row_index, void *d_out_rows,
-                                                   int32_t *d_status, void *stream) {
-  if (!ctx || !d_packed || !d_out_rows || !d_status || !d_row_index) return HIMG_ERR_ARG;
+// these rows, each at its offset in the stream).  phase: kDecHead | kDecRows.
+static int decode_rows_indexed(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size, int width,
+                               int height, int num_channels, int row0, int row1, const uint32_t *d_row_index,
+                               void *d_out_rows, int32_t *d_status, void *stream, int phase) {
   Geom g;
   if (!make_geom(width, height, num_channels, num_channels, 1, &g))
     return fail(ctx, HIMG_ERR_ARG, "bad geometry");
@@ -725,10 +722,116 @@ extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void
   ctx->last_stream = s;
   rc = stage_sizes(ctx, &packed_size, 1, s);
   if (rc) return rc;
-  uint8_t *base = (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C;
+  uint8_t *base = d_out_rows ? (uint8_t *)d_out_rows - (size_t)8 * row0 * g.W * g.C : nullptr;
   launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
                 (const uint32_t *)ctx->d_sizes.p, base, d_status, s, &ctx->prof, ctx->allow_fused,
-                ctx->use_side ? &ctx->dstr : nullptr, row0, row1, d_row_index);
+                ctx->use_side ? &ctx->dstr : nullptr, row0, row1, d_row_index, false, phase);
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void *d_packed,
+                                                   uint32_t packed_size, int width, int height,
+                                                   int num_channels, int row0, int row1,
+                                                   const uint32_t *d_row_index, void *d_out_rows,
+                                                   int32_t *d_status, void *stream) {
+  if (!ctx || !d_packed || !d_out_rows || !d_status || !d_row_index) return HIMG_ERR_ARG;
+  return decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, row0, row1, d_row_index,
+                             d_out_rows, d_status, stream, himg_dev::kDecHead | himg_dev::kDecRows);
+}
+
+// The same in two launches, for a rank whose rows' bytes arrive later than the head of
+// the stream: decode_head_device needs only the bytes in front of the first row header
+// (container parse, LRES chain, predictor inverse: the low-res plane of the whole frame),
+// decode_rows_after_head_device -- same context, same stream, same geometry -- the row
+// index and the rows' bytes.
+extern "C" int himg_hip_decode_head_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                           int width, int height, int num_channels, void *stream) {
+  if (!ctx || !d_packed) return HIMG_ERR_ARG;
+  return decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, 0, 0, nullptr, nullptr,
+                             nullptr, stream, himg_dev::kDecHead);
+}
+
+extern "C" int himg_hip_decode_rows_after_head_device(himg_hip_ctx *ctx, const void *d_packed,
+                                                      uint32_t packed_size, int width, int height,
+                                                      int num_channels, int row0, int row1,
+                                                      const uint32_t *d_row_index, void *d_out_rows,
+                                                      int32_t *d_status, void *stream) {
+  if (!ctx || !d_packed || !d_out_rows || !d_status || !d_row_index) return HIMG_ERR_ARG;
+  if (!ctx->dec_valid) return fail(ctx, HIMG_ERR_ARG, "decode_head_device has not run");
+  return decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, row0, row1, d_row_index,
+                             d_out_rows, d_status, stream, himg_dev::kDecRows);
+}
+
+// The row index of a stream in HBM by the header walk ALONE (k_dec_rowwalk finds the FRES
+// payload itself), on the context's side stream behind whatever `stream` holds at the time of
+// the call: launched in front of decode_head_device it runs BESIDE the head phase (they
+// touch disjoint fields, as in every decode).  Results arrive with
+// himg_hip_decode_walk_wait: d_row_index ([rows] offsets, [rows] lengths), d_rows_first,
+// d_status (the walk's verdict only; the container's is the head phase's).
+extern "C" int himg_hip_decode_walk_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                           int width, int height, int num_channels, uint32_t *d_row_index,
+                                           uint32_t *d_rows_first, int32_t *d_status, void *stream) {
+  if (!ctx || !d_packed || !d_row_index || !d_rows_first || !d_status) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
+  if (g.rows + 1 > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if ((uintptr_t)d_packed & 15) return fail(ctx, HIMG_ERR_ARG, "buffers must be 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, 1);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  rc = stage_sizes(ctx, &packed_size, 1, s);
+  if (rc) return rc;
+  hipStream_t w = ctx->use_side ? ctx->dstr.side : s;
+  if (w != s) {
+    HIP_TRY(ctx, hipEventRecord(ctx->dstr.ev_fork, s));
+    HIP_TRY(ctx, hipStreamWaitEvent(w, ctx->dstr.ev_fork, 0));
+  }
+  himg_dev::launch_rowwalk_only(g, ctx->dec_ws, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
+                                (const uint32_t *)ctx->d_sizes.p, w);
+  HIP_TRY(ctx, hipMemcpyAsync(d_row_index, ctx->dec_ws.row_off, (size_t)g.rows * 4, hipMemcpyDeviceToDevice, w));
+  HIP_TRY(ctx, hipMemcpyAsync(d_row_index + g.rows, ctx->dec_ws.row_len, (size_t)g.rows * 4, hipMemcpyDeviceToDevice, w));
+  HIP_TRY(ctx, hipMemcpyAsync(d_rows_first, &ctx->dec_ws.frames[0].rows_first, 4, hipMemcpyDeviceToDevice, w));
+  HIP_TRY(ctx, hipMemcpyAsync(d_status, &ctx->dec_ws.frames[0].walk_status, 4, hipMemcpyDeviceToDevice, w));
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_walk_wait(himg_hip_ctx *ctx) {
+  if (!ctx) return HIMG_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->use_side) HIP_TRY(ctx, hipStreamSynchronize(ctx->dstr.side));
+  else if (ctx->last_stream || true) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  return HIMG_OK;
+}
+
+// Where the first FRES row header lies (container parse + the length of the serialised
+// tree, no header walk): what the rank that holds a stream in HBM needs to send the head
+// of the stream on its way before it indexes the rows.
+extern "C" int himg_hip_decode_first_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                            int width, int height, int num_channels, uint32_t *d_rows_first,
+                                            int32_t *d_status, void *stream) {
+  if (!ctx || !d_packed || !d_rows_first || !d_status) return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
+  if (g.rows + 1 > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if ((uintptr_t)d_packed & 15) return fail(ctx, HIMG_ERR_ARG, "buffers must be 16-byte aligned");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, 1);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  rc = stage_sizes(ctx, &packed_size, 1, s);
+  if (rc) return rc;
+  launch_decode(g, ctx->dec_ws, 1, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
+                (const uint32_t *)ctx->d_sizes.p, nullptr, d_status, s, &ctx->prof, ctx->allow_fused,
+                nullptr, 0, 0, nullptr, true);
+  HIP_TRY(ctx, hipMemcpyAsync(d_rows_first, &ctx->dec_ws.frames[0].rows_first, 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(ctx, hipGetLastError());
   return HIMG_OK;
 }

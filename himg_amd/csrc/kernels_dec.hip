@@ -3353,19 +3353,29 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
 
 bool dec_rows_fit_lds(const Geom &g) { return fused_layout(g.row_block).total <= 160u * 1024u; }
 
+void launch_rowwalk_only(const Geom &g, const DecWs &ws, const uint8_t *d_packed, size_t in_stride,
+                         const uint32_t *d_sizes, hipStream_t stream) {
+  hipLaunchKernelGGL(k_dec_rowwalk, dim3(1), dim3(64), 0, stream, g, ws, d_packed, in_stride, d_sizes, 0x7fffffff, 0);
+}
+
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,
                    const DecStreams *ds, int r0, int r1,
-                   const uint32_t *d_row_index, bool index_only) {
+                   const uint32_t *d_row_index, bool index_only, int phase) {
   // d_row_index: the FRES row index is given (k_dec_set_index instead of the serial
   // header walk; one frame).  index_only: container parse and row-header walk only --
   // the caller reads ws.row_off / ws.row_len / DecFrame::rows_first (rank 0 of a
-  // row-sharded decode).
+  // row-sharded decode); with r1 == 0 the walk stops in front of the first row header
+  // (rows_first alone: what a rank needs to send the head of the stream on its way).
+  // phase: kDecHead = what needs only the head of the stream (container parse, LRES chain,
+  // predictor inverse), kDecRows = the FRES rows (index, counts, row kernels, verdict);
+  // a row-sharded decode launches them one by one, the rows once their bytes have arrived.
   constexpr int kWalkAll = 0x7fffffff;
+  const bool do_head = (phase & kDecHead) != 0, do_rows = (phase & kDecRows) != 0;
   if (index_only) {
     HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
-    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes, kWalkAll, 0);
+    HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes, r1 == 0 ? 0 : kWalkAll, 0);
     HIMG_LAUNCH(k_dec_status, dim3((batch + 63) / 64), dim3(64), ws, d_status, batch);
     return;
   }
@@ -3397,7 +3407,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   auto seg_lo = [&](int k) { return r0 + (int)((long long)nrows * k / nseg); };
   // Diagnostics and the LRES symbols (k_lres_write stores the non-zero ones only) are
   // cleared up front: k_row_count may start as soon as the parse and the walk are done.
-  {
+  if (do_head) {
     const uint32_t n16 = (uint32_t)(((size_t)batch * ws.lres_stride + 15) / 16);   // (the stride is a multiple of 256)
     const uint32_t ns = (uint32_t)((size_t)batch * (g.rows + 1) * 8), nr = ws.rc_stats ? (uint32_t)((size_t)batch * g.rows * 8) : 0u;
     prof_begin(prof, "memset", stream);
@@ -3406,7 +3416,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     prof_end(prof, stream);
   }
   // Fork: the serial FRES row-header walk runs on the side stream beside k_dec_parse.
-  if (ds) {
+  if (ds && do_rows) {
     (void)hipEventRecord(ds->ev_fork, stream);
     (void)hipStreamWaitEvent(side, ds->ev_fork, 0);
     if (d_row_index) {
@@ -3424,7 +3434,7 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       }
     }
   }
-  HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
+  if (do_head) HIMG_LAUNCH(k_dec_parse, dim3(batch), dim3(kParseThreads), g, ws, d_packed, in_stride, d_sizes);
   // The FRES counts need the decode tables (parse) and the row index (walk); their
   // stream joins this one again before the FRES row kernels.
   // (ds == nullptr: everything in line.)
@@ -3445,7 +3455,9 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
                          d_packed, in_stride, d_sizes, a, b, rpc);
     prof_end(prof, s);
   };
-  if (ds) {
+  if (!do_rows) {
+    // (nothing of the rows in this launch)
+  } else if (ds) {
     (void)hipEventRecord(ds->ev_fork, stream);
     (void)hipStreamWaitEvent(cnt_stream, ds->ev_fork, 0);
     // They fill the CUs the latency-bound LRES kernels leave idle.
@@ -3459,24 +3471,27 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   } else {
     HIMG_LAUNCH(k_dec_rowwalk, dim3(batch), dim3(64), g, ws, d_packed, in_stride, d_sizes, kWalkAll, 0);
   }
-  // LRES: every chunk in parallel, chain verified, serial fallback if not.
-  static const int lres_stage = getenv("HIMG_LRES_STAGE") ? atoi(getenv("HIMG_LRES_STAGE")) : 3;
-  if (lres_stage & 1)
-    HIMG_LAUNCH(k_lres_spec<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
-                d_packed, in_stride, d_sizes);
-  else
-    HIMG_LAUNCH(k_lres_spec<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
-                d_packed, in_stride, d_sizes);
-  if (lres_stage & 2)
-    HIMG_LAUNCH(k_lres_fix<true>, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
-  else
-    HIMG_LAUNCH(k_lres_fix<false>, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
-  HIMG_LAUNCH(k_lres_write, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws, d_packed,
-              in_stride, d_sizes);
-  HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);
-  if (wps) {
+  if (do_head) {
+    // LRES: every chunk in parallel, chain verified, serial fallback if not.
+    static const int lres_stage = getenv("HIMG_LRES_STAGE") ? atoi(getenv("HIMG_LRES_STAGE")) : 3;
+    if (lres_stage & 1)
+      HIMG_LAUNCH(k_lres_spec<true>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+                  d_packed, in_stride, d_sizes);
+    else
+      HIMG_LAUNCH(k_lres_spec<false>, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws,
+                  d_packed, in_stride, d_sizes);
+    if (lres_stage & 2)
+      HIMG_LAUNCH(k_lres_fix<true>, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
+    else
+      HIMG_LAUNCH(k_lres_fix<false>, dim3(batch), dim3(kDecThreads), g, ws, d_packed, in_stride, d_sizes);
+    HIMG_LAUNCH(k_lres_write, dim3(ws.lres_chunks, batch), dim3(kDecThreads), g, ws, d_packed,
+                in_stride, d_sizes);
+    HIMG_LAUNCH(k_lres_finish, dim3((batch + 63) / 64), dim3(64), ws, batch);
     HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
                 dim3(64 * kUnpredWaves), g, ws);
+  }
+  if (!do_rows) return;
+  if (wps) {
     // Rows per workgroup: as many as the transform has lanes for and the LDS holds
     // (4096-pixel rows: one).
     const int per_row = ((g.cols + 31) / 32) * 64;
@@ -3512,8 +3527,6 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     // (k_row_window) and stored whole; rows whose block is not a multiple of 16 bytes
     // (ragged widths of 1-3 channel frames) take k_dec_huff's 32 KiB windows.
     const bool window = (g.row_block % 16) == 0;
-    HIMG_LAUNCH(k_lres_unpredict, dim3((g.mcols + 4 * kUnpredWaves - 1) / (4 * kUnpredWaves), g.mrows, batch * g.C),
-                dim3(64 * kUnpredWaves), g, ws);
     for (int k = 0; k < nseg; ++k) {
       const int a = seg_lo(k), b = seg_lo(k + 1);
       if (ds) (void)hipStreamWaitEvent(stream, ds->ev_cnt[k], 0);

@@ -341,17 +341,24 @@ class ShardedDecoder:
     """Row-sharded decode of frames of one geometry (reference
     decoder.cpp:292-326 hands block rows to worker threads the same way).
 
-    Rank 0 holds the stream.  It indexes the block rows ONCE (container parse + the
-    serial walk over the row size headers: on the host for a stream in host memory, on
-    its GPU otherwise), then
-        broadcast   a small record: stream size, verdict, first-row offset, row index
+    Rank 0 holds the stream.  The exchange is a pipeline of two stages:
+        broadcast   a small record: stream size, verdict so far, first-row offset
+                    (container chunk look-ups only: no header walk yet)
         broadcast   the head of the stream [0, first row header): container chunks,
                     LRES stream, FRES tree -- 1/20 of a 16384 x 16384 stream
+      -> EVERY rank starts what needs only the head (himg_hip_decode_head_device:
+         container parse, LRES chain, predictor inverse -- 1 ms of a 16384 x 16384 decode)
+         WHILE rank 0 indexes the block rows once (the serial walk over the row size
+         headers: microseconds on the host for a stream in host memory, 1.3 ms of
+         dependent loads on its GPU otherwise)
+        broadcast   the row index (offsets and lengths of all block rows)
         send/recv   to every other rank ONLY the bytes of its own block rows, each over
                     that peer's own link
-    and every rank decodes the LRES stream and its rows from a buffer that holds just
-    those two ranges at their stream offsets (himg_hip_decode_rows_indexed_device: no
-    rank repeats the header walk).  All buffers are allocated once.
+      -> every rank decodes its rows (himg_hip_decode_rows_after_head_device) from a
+         buffer that holds just the head and its own rows at their stream offsets; no
+         rank repeats the header walk.  All buffers are allocated once.
+    `trace` of the last call lists the steps in the order this rank took them (the tests
+    pin that the head phase is launched before the row index is known).
     `bytes_from_rank0` of the last call = what left rank 0 (the tests bound it by
     1.2 x the stream)."""
 
@@ -397,11 +404,11 @@ class ShardedDecoder:
         self.d_packed[int(size):cap].zero_()
         return self.d_packed
 
-    def _index_rank0(self, packed):
-        """-> (size, ok, rows_first, offsets, lengths, d_src or None)."""
+    def _first_rank0(self, packed):
+        """-> (size, ok, rows_first, d_src or None, host array or None): the stream's size and
+        where its first row header lies -- the chunk look-ups, not the header walk."""
         import torch
         import himg_amd
-        rows = self.rows
         if torch.is_tensor(packed) and packed.device.type != "cpu":
             size = int(packed.numel())
             src = packed
@@ -409,18 +416,34 @@ class ShardedDecoder:
                 buf = self._buffer(size)
                 buf[:size] = src
                 src = buf
-            self.eng.decode_index_device(src, size, self.W, self.H, self.C, self.d_index, self.d_index[2 * rows:],
+            self.eng.decode_first_device(src, size, self.W, self.H, self.C, self.d_index[2 * self.rows:],
                                          self.d_status[1:], self._s())
-            host = torch.cat([self.d_index, self.d_status[1:2]]).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-            ok = int(host[-1]) == 0
-            return size, ok, int(host[2 * rows]), host[:rows], host[rows:2 * rows], src
+            host = torch.cat([self.d_index[2 * self.rows: 2 * self.rows + 1], self.d_status[1:2]]).cpu().numpy()
+            first = int(np.int64(host[0]) & 0xFFFFFFFF)
+            return size, first != 0, first, src, None       # (a damaged container: k_dec_parse's verdict, below)
         a = packed.numpy() if torch.is_tensor(packed) else np.ascontiguousarray(packed, np.uint8)
         try:
             w, h, c, off, ln, first = himg_amd.index_host(a, self.fix_t2)
             ok = (w, h, c) == (self.W, self.H, self.C)
         except himg_amd.HimgError:
-            ok, off, ln, first = False, np.zeros(rows, np.uint32), np.zeros(rows, np.uint32), 0
-        return int(a.size), ok, int(first), off.astype(np.int64), ln.astype(np.int64), None
+            ok, off, ln, first = False, None, None, 0
+        self._host_index = (off, ln) if ok else None          # (microseconds: the whole index is there already)
+        return int(a.size), ok, int(first), None, a
+
+    def _walk_rank0(self, d_src, size):
+        """Start the header walk of a stream in HBM on the engine's side stream (it runs
+        beside the head phase launched after it)."""
+        rows = self.rows
+        self.eng.decode_walk_device(d_src, size, self.W, self.H, self.C, self.d_index, self.d_index[2 * rows:],
+                                    self.d_status[1:], self._s())
+
+    def _index_rank0(self):
+        """-> (ok, offsets, lengths) once the walk is through."""
+        import torch
+        rows = self.rows
+        self.eng.decode_walk_wait()
+        host = torch.cat([self.d_index, self.d_status[1:2]]).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        return int(host[-1]) == 0, host[:rows], host[rows:2 * rows]
 
     def decode(self, packed=None, gather=True):
         """packed: the stream on rank 0 (numpy array, CPU or CUDA tensor), ignored
@@ -429,6 +452,7 @@ class ShardedDecoder:
         import torch.distributed as dist
         world, rank, rows, group = self.world, self.rank, self.rows, self.group
         self.bytes_from_rank0 = 0
+        self.trace = []
         if world == 1 and hasattr(self.eng, "decode_rows_device"):
             # One rank: nothing to scatter -- the plain row-range decode, whose header walk
             # runs beside the container parse instead of in front of it.
@@ -446,35 +470,30 @@ class ShardedDecoder:
             if not gather:
                 return ok, (self.d_rows if ok else None)
             return ok, (self.d_rows.cpu().numpy() if ok else None)
-        d_src = None
+        pipelined = hasattr(self.eng, "decode_head_device")
+        # ---- stage 1: the head of the stream to everybody, and what needs only the head started
+        d_src = h_src = None
+        m0 = torch.zeros(4, dtype=torch.int64, device=self.comm)
         if rank == 0:
-            size, ok, first, off, ln, d_src = self._index_rank0(packed)
-            m = np.zeros(4 + 2 * rows, np.int64)
-            m[0], m[1], m[2] = size, 1 if ok else 0, first
-            m[4:4 + rows], m[4 + rows:] = off, ln
-            self.meta.copy_(torch.from_numpy(m))
+            size, ok, first, d_src, h_src = self._first_rank0(packed)
+            m0.copy_(torch.tensor([size, 1 if ok else 0, first, 0], dtype=torch.int64))
         if world > 1:
-            dist.broadcast(self.meta, src=0, group=group)
-            self.bytes_from_rank0 += (world - 1) * self.meta.numel() * 8
-        m = self.meta.cpu().numpy()
-        size, ok, first = int(m[0]), bool(m[1]), int(m[2])
+            dist.broadcast(m0, src=0, group=group)
+            self.bytes_from_rank0 += (world - 1) * m0.numel() * 8
+        size, ok, first = (int(x) for x in m0.cpu().numpy()[:3])
+        self.trace.append("first")
         if not ok:
-            return False, None          # the container or a row header is damaged: every rank agrees
-        off, ln = m[4:4 + rows], m[4 + rows:]
-        ranges = slice_ranges(off, ln, first, size, self.parts)
+            return False, None          # the container is damaged: every rank agrees
         head16 = min((first + 15) // 16 * 16, (size + 15) // 16 * 16)
-
         if world == 1 and d_src is not None:
             buf = d_src                  # one rank, stream already in HBM: decode in place
         else:
             buf = self._buffer(size)
             if rank == 0 and d_src is None:
-                src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
-                buf[:size] = src.to(self.dev)
+                buf[:size] = torch.from_numpy(h_src).to(self.dev)
             elif rank == 0 and d_src.data_ptr() != buf.data_ptr():
                 buf[:size] = d_src[:size]
         if world > 1:
-            # Head to everybody, then each peer's own rows to that peer only.
             head = buf[:head16]
             if self.comm != self.dev:
                 hc = head.to(self.comm)
@@ -484,6 +503,42 @@ class ShardedDecoder:
             else:
                 dist.broadcast(head, src=0, group=group)
             self.bytes_from_rank0 += (world - 1) * head16
+        self.trace.append("head")
+        self.d_status.zero_()
+        if rank == 0 and d_src is not None:
+            self._walk_rank0(buf, size)      # (in front of the head phase: they run side by side)
+            self.trace.append("walk_started")
+        if pipelined:
+            # Container parse, LRES chain, predictor inverse: launched now, running while rank 0
+            # walks the row headers and the rows' bytes travel.
+            self.eng.decode_head_device(buf, size, self.W, self.H, self.C, self._s())
+            self.trace.append("head_phase")
+        # ---- stage 2: the row index, every rank's own rows, the rows' decode
+        meta = self.meta
+        if rank == 0:
+            if d_src is not None:
+                iok, off, ln = self._index_rank0()
+            elif self._host_index is not None:
+                iok, (off, ln) = True, self._host_index
+            else:
+                iok, off, ln = False, np.zeros(rows, np.int64), np.zeros(rows, np.int64)
+            m = np.zeros(4 + 2 * rows, np.int64)
+            m[0], m[1] = size, 1 if iok else 0
+            m[4:4 + rows], m[4 + rows:] = np.asarray(off, np.int64), np.asarray(ln, np.int64)
+            meta.copy_(torch.from_numpy(m))
+        if world > 1:
+            dist.broadcast(meta, src=0, group=group)
+            self.bytes_from_rank0 += (world - 1) * meta.numel() * 8
+        m = meta.cpu().numpy()
+        self.trace.append("index")
+        if not bool(m[1]):
+            if pipelined:
+                torch.cuda.synchronize(self.dev) if self.dev.type == "cuda" else None
+            return False, None          # a row header is damaged: every rank agrees
+        off, ln = m[4:4 + rows], m[4 + rows:]
+        ranges = slice_ranges(off, ln, first, size, self.parts)
+        if world > 1:
+            # Each peer's own rows to that peer only.
             ops, staged = [], []
             if rank == 0:
                 for peer in range(1, world):
@@ -504,11 +559,16 @@ class ShardedDecoder:
             if self.comm != self.dev:
                 for lo, hi, t in staged:
                     buf[lo:hi] = t.to(self.dev)
+        self.trace.append("rows_arrived")
         idx32 = torch.from_numpy(np.concatenate([off, ln]).astype(np.uint32).view(np.int32))
         self.d_index[: 2 * rows] = idx32.to(self.dev)
-        self.d_status.zero_()
-        self.eng.decode_rows_indexed_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
-                                            self.d_rows, self.d_status, self._s())
+        if pipelined:
+            self.eng.decode_rows_after_head_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
+                                                   self.d_rows, self.d_status, self._s())
+        else:
+            self.eng.decode_rows_indexed_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
+                                                self.d_rows, self.d_status, self._s())
+        self.trace.append("rows_phase")
         bad = (self.d_status[:1] != 0).to(torch.int32).to(self.comm)    # (the transfer waits for the kernels)
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)

@@ -255,6 +255,29 @@ int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void *d_packed,
                                         int width, int height, int num_channels, int row0, int row1,
                                         const uint32_t *d_row_index, void *d_out_rows,
                                         int32_t *d_status, void *stream);
+/* The same in two launches, for a rank whose rows' bytes arrive later than the head of the
+ * stream (pipelined row-sharded decode): decode_head_device needs only the bytes in front of
+ * the first row header -- container parse, LRES chain, predictor inverse --, and
+ * decode_rows_after_head_device (same context, stream and geometry) the row index and the
+ * rows' bytes.  decode_first_device: where the first row header lies, without the header
+ * walk (the rank that holds a stream in HBM sends the head on its way before it indexes). */
+int himg_hip_decode_head_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                int width, int height, int num_channels, void *stream);
+int himg_hip_decode_rows_after_head_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                           int width, int height, int num_channels, int row0, int row1,
+                                           const uint32_t *d_row_index, void *d_out_rows,
+                                           int32_t *d_status, void *stream);
+int himg_hip_decode_first_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                 int width, int height, int num_channels, uint32_t *d_rows_first,
+                                 int32_t *d_status, void *stream);
+/* The row index by the header walk alone, on the context's side stream behind what `stream`
+ * holds at the call: launched in FRONT of decode_head_device it runs beside the head phase.
+ * d_row_index / d_rows_first as himg_hip_decode_index_device, d_status: the walk's verdict
+ * (the container's is the head phase's); all valid after himg_hip_decode_walk_wait. */
+int himg_hip_decode_walk_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                int width, int height, int num_channels, uint32_t *d_row_index,
+                                uint32_t *d_rows_first, int32_t *d_status, void *stream);
+int himg_hip_decode_walk_wait(himg_hip_ctx *ctx);
 
 /* ---- multi-device: several GPUs of one node behind this ABI ------------------- */
 /*

@@ -124,6 +124,22 @@ class StubDecodeEngine:
 
     def __init__(self, full_stream):
         self.full = np.ascontiguousarray(full_stream, np.uint8)
+        self.head_done = False
+
+    def decode_head_device(self, d_packed, size, w, h, c, stream=0):
+        """The head phase: only the bytes in front of the first row header may be looked at
+        (the rows' bytes have not arrived yet: the decoder poisons nothing, so check the head)."""
+        full = self.full
+        assert size == full.size
+        first = himg_amd.index_host(full)[5] if ol.oracle_decode(full)[0] == 0 else 0
+        if first:
+            assert np.array_equal(d_packed.numpy()[:first], full[:first]), "head of the stream differs"
+        self.head_done = True
+
+    def decode_rows_after_head_device(self, d_packed, size, w, h, c, r0, r1, d_index, d_rows, d_status, stream=0):
+        assert self.head_done, "the rows phase needs the head phase"
+        self.head_done = False
+        return self.decode_rows_indexed_device(d_packed, size, w, h, c, r0, r1, d_index, d_rows, d_status, stream)
 
     def decode_rows_indexed_device(self, d_packed, size, w, h, c, r0, r1, d_index, d_rows, d_status, stream=0):
         full, rows = self.full, (h + 7) // 8
@@ -167,15 +183,28 @@ def main_decode(mode, kind, seed, W, H, q, outfile):
         ok, pix = sharded.decode_sharded(eng, d_packed, W, H, 4, device=dev)
         if ok and rank == 0 and torch.is_tensor(pix):
             pix = pix.cpu().numpy()
+    elif mode == "dgpu_dev":
+        # The stream in rank 0's HBM (the header walk on its GPU, beside the head phase); both
+        # ranks on the one GPU of the test box, collectives over gloo with CPU staging.
+        eng = himg_amd.Engine(0)
+        d_packed = torch.from_numpy(full).to("cuda:0") if rank == 0 else None
+        ok, pix = sharded.decode_sharded(eng, d_packed, W, H, 4, device="cuda:0", comm_device="cpu")
+        if rank == 0:
+            assert "walk_started" in list(eng._sharded_decoders.values())[0].trace
     else:
         eng = himg_amd.Engine(0)
         ok, pix = sharded.decode_sharded(eng, packed, W, H, 4, device="cuda:0", comm_device="cpu")
+    dec = list(eng._sharded_decoders.values())[0]
+    if "rows_phase" in dec.trace:
+        # The pipeline's order on EVERY rank: what needs only the head is launched before the
+        # row index is known, the rows' decode when their bytes have arrived.
+        t = dec.trace
+        assert t.index("head") < t.index("head_phase") < t.index("index") < t.index("rows_arrived") < t.index("rows_phase"), t
     if rank == 0:
         if ok:
             np.asarray(pix, np.uint8).tofile(outfile)
         else:
             open(outfile, "w").write("REJECTED")
-        dec = list(eng._sharded_decoders.values())[0]
         open(str(outfile) + ".stats", "w").write("%d %d" % (dec.bytes_from_rank0, full.size))
     dist.barrier()
     dist.destroy_process_group()
@@ -184,7 +213,7 @@ def main_decode(mode, kind, seed, W, H, q, outfile):
 def main():
     mode, kind, seed, W, H, q, outfile = sys.argv[1:8]
     seed, W, H, q = int(seed), int(W), int(H), int(q)
-    if mode in ("dstub", "dgpu", "dgpu_nccl"):
+    if mode in ("dstub", "dgpu", "dgpu_dev", "dgpu_nccl"):
         return main_decode(mode, kind, seed, W, H, q, outfile)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     nccl = mode == "gpu_nccl"   # one GPU per rank, RCCL

@@ -284,6 +284,23 @@ def test_sharded_decode_two_processes(tmp_path):
     assert open(out).read() == "REJECTED"
 
 
+@pytest.mark.gpu
+def test_sharded_decode_stream_in_rank0_hbm(tmp_path):
+    """The stream lives in rank 0's HBM: rank 0 learns where the first row header lies
+    (himg_hip_decode_first_device), the head goes out, the header walk runs on its GPU's side
+    stream BESIDE the head phase (himg_hip_decode_walk_device), then the rows' bytes travel --
+    same pixels, same verdicts (a damaged row header; a stream the reference rejects)."""
+    out = tmp_path / "out.bin"
+    _run_ranks(2, ["dgpu_dev", "randtile", 2, 512, 1024, 70, out])
+    rc, pix = ol.oracle_decode(ol.oracle_encode(himg_amd.synth("randtile", 2, 512, 1024), 70, True))
+    assert rc == 0 and np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
+    _run_ranks(3, ["dgpu_dev", "gradn", 5, 256, 520, 90, out])
+    rc, pix = ol.oracle_decode(ol.oracle_encode(himg_amd.synth("gradn", 5, 256, 520), 90, True))
+    assert rc == 0 and np.array_equal(np.fromfile(out, np.uint8), pix.ravel())
+    _run_ranks(2, ["dgpu_dev", "grad", 0, 512, 512, 50, out])
+    assert open(out).read() == "REJECTED"
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()   # (does not initialise the GPU)
