@@ -1436,6 +1436,65 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
   rd.init(bp);
   const int limk = (int)lim - kLutBits;
   bool bad = false;
+  if (!exact) {
+    // Every lane but the one in which the block completes: lean_write's loop (whole groups,
+    // a long code as two steps whose table is lane state) with the store below instead of
+    // the OR into LDS; the general step further down costs twice the instructions and was
+    // k_lres_write's whole time (0.74 -> 0.55 ms per 128 frames, in front of the row kernel).
+    const uint32_t TM = ((1u << kLutBits) - 1u) << 3, TB = lds_addr(tb.grp);
+    uint32_t tm = TM, tbase = TB;
+    uint32_t o = (uint32_t)op;                       // (the output of one stream is below 2^32 symbols)
+    const uint32_t o_end = (uint32_t)op_end;
+    auto put = [&](uint32_t by) {
+      if (by) {
+        if (o + 4u <= o_end) {
+          asm volatile("global_store_dword %0, %1, %2" :: "v"(o), "v"(by), "s"(gout) : "memory");
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t b = (by >> (8 * j)) & 255u;
+            if (b) gout[o + j] = (uint8_t)b;
+          }
+        }
+      }
+    };
+    auto step = [&]() {
+      rd.refill();
+      const uint2 e = lds_ld64(((((uint32_t)rd.win) << 3) & tm) + tbase);
+      uint32_t y = e.y, by = e.x, ntm = TM, ntb = TB, adv = 0;
+      if (__builtin_expect(y == 0, 0)) {
+        if ((by >> 31) && tm == TM) {
+          ntm = ((1u << (by & 255u)) - 1u) << 3;
+          ntb = TB + (((1u << kLutBits) + ((by >> 8) & 0xffffu)) << 3);
+          y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
+          by = 0;
+        } else {
+          const int base = tm == TM ? 0 : kLutBits;
+          uint32_t len;
+          y = walk_token(rd, tb, by, base, &len, &by, &bad);
+          adv = len - (uint32_t)base;
+        }
+      }
+      tm = ntm; tbase = ntb;
+      const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
+      const uint32_t n = y >> 27;
+      rd.consume((int)n);
+      put(by);
+      o += ((y >> 10) & 511u) + extra;
+      bp += adv + n;
+    };
+    while ((int)bp <= limk) step();
+    if (tm != TM) step();
+    while (bp < lim) {
+      uint32_t nbits, cnt, by;
+      lean_step<true>(rd, tb, true, &nbits, &cnt, &by, &bad);
+      put(by);
+      o += cnt;
+      bp += nbits;
+    }
+    if (bad) sh->err = 1;
+    return;
+  }
   for (;;) {
     uint32_t nbits, cnt, by;
     lean_step<true>(rd, tb, exact || (int)bp > limk, &nbits, &cnt, &by, &bad);

@@ -2023,15 +2023,18 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
               (const uint32_t *)nullptr, 0, 0, g.rows);
   // The LRES spans' bit packing (1/64 of the symbols, 20 us of a single frame's 130) beside
   // the FRES rows': forked to the side stream again, joined behind the pad-bit fix-up.
-  if (side) {
+  // (A single frame only: in a batch the LRES spans are thousands of workgroups of their own
+  // and the two launches side by side just slow each other down -- encode 141.7 -> 138.9 Gpx/s.)
+  hipStream_t lres_side = (side && (long long)g.rows * batch <= kWideRows) ? side : nullptr;
+  if (lres_side) {
     (void)hipEventRecord(ev_fork, stream);
-    (void)hipStreamWaitEvent(side, ev_fork, 0);
+    (void)hipStreamWaitEvent(lres_side, ev_fork, 0);
   }
-  launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof, side);
-  if (side) (void)hipEventRecord(ev_join, side);
+  launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof, lres_side);
+  if (lres_side) (void)hipEventRecord(ev_join, lres_side);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);
-  if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
+  if (lres_side) (void)hipStreamWaitEvent(stream, ev_join, 0);
 }
 
 // ---- row-sharded encode of ONE frame (see himg_hip.h, "row-sharded encode") ----
