@@ -1568,7 +1568,8 @@ struct PreLane {
 // beforehand by k_row_count (pre_off[kDecThreads + 2] != 0 says it is usable).
 // GLOBAL (with FUSED false): the output goes straight to `gout`, PRE-ZEROED global
 // memory, without the LDS window (win may be nullptr) -- the LRES serial fallback.
-template <bool FUSED, bool GLOBAL = false>
+// PRIMED: the caller has set sh->err / sh->endbit in front of a barrier of its own.
+template <bool FUSED, bool GLOBAL = false, bool PRIMED = false>
 __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
@@ -1576,16 +1577,48 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
                              const uint32_t *pre_start = nullptr, const uint32_t *pre_off = nullptr,
                              const PreLane *pl = nullptr) {
   const int tid = threadIdx.x;
-  if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
-  __syncthreads();
+  if (!PRIMED) {
+    if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
+    __syncthreads();
+  }
 
   const unsigned long long P1 = 8ull * pay_len;  // payload end, in bits from pay_off
   unsigned long long cur = 0;                    // exact bit position of the next token
   unsigned long long O0 = 0;                     // symbols produced so far
   uint32_t st_chunks = 0, st_rounds = 0;
   long long c_sync = 0, c_write = 0, c_r1 = 0, c_t0 = clock64();
+  bool synced = false;   // (uniform) a barrier stands between the last write pass and here
+
+  // The row kernel's normal case: ONE chunk whose lanes k_row_count has recorded, the
+  // record in registers.  Nothing of the sub-sequence grid is needed (a lane walks from
+  // its recorded start to its right neighbour's), and where the chunk ends is in the
+  // record as well: one barrier, behind the write pass.
+  if (FUSED && pl && pl->valid != 0 && P1 != 0 && out_size != 0) {
+    GReader rd;
+    const uint32_t rel0 = rd.attach(p, stream_size, 8ull * pay_off);
+    const uint32_t rel_end = rel0 + (uint32_t)P1;   // (a recorded row is one chunk: k_row_count)
+    const uint32_t start = rel0 + pl->start, opl = pl->off, cnt = pl->nxt - pl->off;
+    const uint32_t wlim = pl->nstart < (uint32_t)P1 ? rel0 + pl->nstart : rel_end;
+    st_chunks = 1; st_rounds = pl->rounds;
+    { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
+    const bool inside = opl + cnt < out_size, exact = !inside && opl < out_size;
+    uint32_t end_bp = ~0u;
+    if (inside) {
+      if (!lean_write(rd, tb, start, wlim, opl, lds_out, 0u, pl->valid == 3u)) sh->err = 1;
+    } else if (exact) {
+      if (!exact_write(rd, tb, start, wlim, opl, out_size, lds_out, &end_bp)) sh->err = 1;
+    }
+    if (end_bp != ~0u) sh->endbit = (unsigned long long)(end_bp - rel0);
+    __syncthreads();
+    { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
+    cur = pl->endrel;
+    O0 = pl->tot;
+    if (pl->endrel == 0) cur = P1;   // no progress (cannot happen on a valid stream): stop, like the loop below
+    synced = true;
+  }
 
   while (cur < P1 && O0 < out_size) {
+    synced = false;
     GReader rd;
     const uint32_t rel0 = rd.attach(p, stream_size, 8ull * pay_off + cur);
     ++st_chunks;
@@ -1669,7 +1702,7 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     if (last_end == rel0) break;  // no progress (cannot happen on a valid stream)
     __syncthreads();
   }
-  __syncthreads();
+  if (!synced) __syncthreads();
 
   // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
   int bad = sh->err;
@@ -2665,15 +2698,23 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     pre_off0 = ws.row_off[ri]; pre_len0 = ws.row_len[ri];
     const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + (int)blockIdx.x;
     const int u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
+    // (32-bit offsets from the frame's plane: a low-res plane set is C * rows * cols bytes)
+    const uint32_t pstride = (uint32_t)g.rows * COLS, o1 = (uint32_t)v * COLS, o2 = (uint32_t)v2 * COLS;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-      const uint8_t *m = low + (size_t)(2 * hs + cc) * g.rows * COLS;
-      pre_lr[2 * cc] = (uint32_t)m[(size_t)v * COLS + u] | ((uint32_t)m[(size_t)v * COLS + u2] << 8);
-      pre_lr[2 * cc + 1] = (uint32_t)m[(size_t)v2 * COLS + u] | ((uint32_t)m[(size_t)v2 * COLS + u2] << 8);
+      const uint32_t m = (uint32_t)(2 * hs + cc) * pstride;
+      pre_lr[2 * cc] = (uint32_t)low[m + o1 + u] | ((uint32_t)low[m + o1 + u2] << 8);
+      pre_lr[2 * cc + 1] = (uint32_t)low[m + o2 + u] | ((uint32_t)low[m + o2 + u2] << 8);
     }
   }
-  if (tid == 0) sh->flag = df->status;
+  // The frame's verdict: ONE read for the workgroup (other workgroups flag the frame
+  // concurrently).  4096-pixel rows: requested here, stored with the tables below -- a
+  // store right here would make wave 0 wait for every load above before it requests
+  // its share of the tables, two round trips in front of the first barrier.
+  uint32_t st0 = 0;
+  if (tid == 0) st0 = df->status;
   if constexpr (COLS != 512) {
+    if (tid == 0) sh->flag = st0;
     __syncthreads();
     if (sh->flag) return;
   }
@@ -2713,6 +2754,9 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   reinterpret_cast<uint4 *>(T.grp)[tid] = t_grp;
   if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(T.grp + (1 << kLutBits))[tid] = t_sub;
   if (tid < kMaxNodes + 1) T.nd[tid] = t_nd;
+  if constexpr (COLS == 512) {
+    if (tid == 0) { sh->flag = st0; sh->err = 0; sh->endbit = ~0ull; }   // (decode_stream<.., PRIMED>)
+  }
   __syncthreads();
   if constexpr (COLS == 512) {
     if (sh->flag) return;   // (uniform: one read, in front of the barrier above)
@@ -2725,7 +2769,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
     }
     if constexpr (COLS == 512)
-      return decode_stream<true>(
+      return decode_stream<true, false, true>(
           p, sizes[f], pre_off0, pre_len0, (uint32_t)g.row_block, tb, sh, sym0, nullptr, nullptr,
           ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
           nullptr, nullptr, &pl);
