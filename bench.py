@@ -646,13 +646,23 @@ def main():
                     traffic_src = "profiles/traffic.json (PMC passes at commit %s with %s frames per launch, scaled; not this run)" % (
                         tj.get("git_sha", "?"), tj.get("frames_per_launch", "?"))
                 pmc = tj.get("valu", {})
+                # The three kernels whose hot loops carry trip counters (tools/dynamic_mix.py): the
+                # class-weighted cost taken over what they EXECUTE instead of over their static mix.
+                dpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_dynamic_mix.json")
+                if os.path.exists(dpath):
+                    for k, v in json.load(open(dpath)).get("kernels", {}).items():
+                        if k in pmc:
+                            pmc[k]["mean_cost_per_valu_dynamic"] = v["mean_cost_per_valu_dynamic"]
+                            pmc[k]["issue_frac_dynamic_mix"] = v["issue_frac_dynamic_mix"]
+                            pmc[k]["executed_valu_shares"] = {p_["part"].split(" (")[0].split(":")[0]: p_["share_of_executed_valu"]
+                                                             for p_ in v["parts"]}
             # VALU issue of that kernel from the same PMC passes: the SIMD issue time of its
             # instruction count at the kernel's class-weighted measured cost
-            # (profiles/r03_isa_mix.json over profiles/r03_valu_rate.txt) over its duration.
+            # (profiles/r04_isa_mix.json over profiles/r03_valu_rate.txt) over its duration.
             valu_busy = None
             for k, v in pmc.items():
                 if k.split("<")[0] == key:
-                    valu_busy = v.get("issue_frac_measured_mix", v.get("issue_frac"))
+                    valu_busy = v.get("issue_frac_dynamic_mix", v.get("issue_frac_measured_mix", v.get("issue_frac")))
             roofline = {"bound": "hbm", "kernel": dom, "side": "encode" if dom.strip("()").split("<")[0] in enc_stages else "decode",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -689,7 +699,10 @@ def main():
                                        "1024 SIMDs need to ISSUE that count -- at the guide's 2 cycles per wave64 "
                                        "instruction (SIMD-32) and at the kernel's class-weighted measured cost "
                                        "(plain VOP1/VOP2 ~2.2, VOP3 / packed / DPP / compares ~4.1 cycles: "
-                                       "profiles/r03_valu_rate.txt, profiles/r03_isa_mix.json)",
+                                       "profiles/r03_valu_rate.txt, profiles/r04_isa_mix.json); "
+                                       "issue_frac_dynamic_mix where the kernel's hot loops carry trip counters: "
+                                       "the cost weighted by what is EXECUTED (measured trip counts x each loop's "
+                                       "hot path, profiles/r04_dynamic_mix.json) instead of by the static mix",
                                "source": traffic_src, "kernels": pmc} if pmc else None),
             "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
         }

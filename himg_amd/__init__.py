@@ -28,7 +28,7 @@ SYNTH = {"grad": 0, "gradn": 1, "rand": 2, "randtile": 3}
 DBG = {
     "avg": 0, "lowres": 1, "lres_sym": 2, "fres_sym": 3, "lres_hist": 4, "fres_hist": 5,
     "lres_len": 6, "fres_len": 7, "lres_code": 8, "fres_code": 9, "fres_row_bytes": 10,
-    "dec_stats": 11, "parse_stats": 12, "rowcount_stats": 13,
+    "dec_stats": 11, "parse_stats": 12, "rowcount_stats": 13, "loop_counts": 14,
 }
 DBG_DECODER = 0x100
 

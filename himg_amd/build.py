@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libhimg_hip.so")
 HIP_SOURCES = ["kernels_enc.hip", "kernels_dec.hip", "himg_hip.hip", "himg_multi.hip"]
 CXX_SOURCES = ["encoder.cpp", "decoder.cpp"]
 C_SOURCES = ["himg_tables.c", "himg_synth.c"]
-HEADERS = ["himg_dev.h", "himg_tables.h", "ctx_pool.h", "../../include/himg_hip.h",
+HEADERS = ["himg_dev.h", "loop_counts.h", "himg_tables.h", "ctx_pool.h", "../../include/himg_hip.h",
            "../../include/encoder.h", "../../include/decoder.h"]
 
 

@@ -172,6 +172,10 @@ struct DecStreams {
 // The fused row kernel serves this geometry (a block row's symbols and the decode tables fit
 // the LDS of one CU); otherwise the rows go through 128 KiB windows (k_row_window).
 bool dec_rows_fit_lds(const Geom &g);
+constexpr int kLoopCounters = 8;
+// Loop trip counters of a -DHIMG_LOOP_COUNTS build (loop_counts.h): read and reset; -1 when not compiled in.
+int loop_counts_read_enc(unsigned long long *out);
+int loop_counts_read_dec(unsigned long long *out);
 
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,

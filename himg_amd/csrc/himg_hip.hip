@@ -1378,6 +1378,14 @@ extern "C" int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void 
   size_t n = 0;
   const bool dec = (what & 0x100) != 0;  // 0x100 | what: decoder-side buffers
   what &= 0xff;
+  if (what == HIMG_DBG_LOOP_COUNTS) {
+    unsigned long long c[2 * himg_dev::kLoopCounters];
+    if (dst_bytes < sizeof(c)) return HIMG_ERR_CAPACITY;
+    if ((dec ? himg_dev::loop_counts_read_dec(c) : himg_dev::loop_counts_read_enc(c)) != 0) return HIMG_ERR_ARG;
+    memcpy(dst, c, sizeof(c));
+    if (written) *written = sizeof(c);
+    return HIMG_OK;
+  }
   if (!dec) {
     if (!ctx->enc_valid || frame < 0 || frame >= ctx->enc_batch) return HIMG_ERR_ARG;
     const Geom &g = ctx->enc_geom;

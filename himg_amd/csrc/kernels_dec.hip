@@ -17,6 +17,7 @@
 //                     the serial LRES fallback
 // One entropy-decode engine serves all of them: see "Entropy decoding" below.
 #include "himg_dev.h"
+#include "loop_counts.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -1291,8 +1292,10 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       op += ((y >> 10) & 511u) + extra;
       bp += adv + n;
     };
+    LoopCount lc;
     if (chain) {   // (uniform per row)
-      while (bp < lim) step();
+      while (bp < lim) { HIMG_REGION_BEGIN("dec.write"); step(); lc.step(); HIMG_REGION_END("dec.write"); }
+      lc.done(0);
       if (tm != TM) step();
       return !bad;
     }
@@ -2800,6 +2803,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   // stay read-only in LDS: no barrier, no second pass over them.
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
   const int per_row = ((cols + 31) >> 5) * 64;   // whole wavefronts: a lane pair never straddles rows
+  HIMG_REGION_BEGIN("dec.transform");
 #pragma unroll 1
   for (int it = tid; it < per_row * nr; it += kDecThreads) {
     const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
@@ -2808,6 +2812,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
                                               pair_tile(il), pair_half(il), rb + i, img,
                                               COLS == 512 ? pre_lr : nullptr);
   }
+  HIMG_REGION_END("dec.transform");
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
   if ((tid & 63) == 0) {
@@ -3109,7 +3114,9 @@ __device__ __forceinline__ void grp_count_lds(const LdsBits &bits, const GrpTabl
       pos += y >> 27;
       c += ((y >> 10) & 511u) + extra;
     };
-    while (pos < lim) step();
+    LoopCount lc;
+    while (pos < lim) { HIMG_REGION_BEGIN("dec.count"); step(); lc.step(); HIMG_REGION_END("dec.count"); }
+    lc.done(1);
     if (tm != TM) step();   // the loop ended between the two steps of a long code
   }
   *endpos = pos;
@@ -3453,6 +3460,8 @@ __global__ void k_dec_status(DecWs ws, int32_t *status, int batch) {
     hipLaunchKernelGGL(name, grid, block, 0, stream, __VA_ARGS__); \
     prof_end(prof, stream);                                    \
   } while (0)
+
+int loop_counts_read_dec(unsigned long long *out) { return loop_counts_read(out); }
 
 bool dec_rows_fit_lds(const Geom &g) { return fused_layout(g.row_block).total <= 160u * 1024u; }
 

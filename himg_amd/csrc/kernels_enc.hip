@@ -16,6 +16,7 @@
 //
 // Wavefront = 64 lanes everywhere; no MFMA (there is no dense contraction).
 #include "himg_dev.h"
+#include "loop_counts.h"
 
 #include <cstdlib>
 #include <utility>
@@ -816,7 +817,10 @@ __device__ __forceinline__ void walk16(const uint32_t w[4], uint32_t mask, int n
                                        bool flush, F &&f) {
   int prev = -1 - run_in;   // the zeros in front of the chunk count as positions before it
   uint32_t m = mask;
+  LoopCount lc;
   while (m) {
+    HIMG_REGION_BEGIN("enc.walk");
+    lc.step();
     const int k = __ffs(m) - 1;
     m &= m - 1;
     const int run = k - prev - 1;
@@ -842,7 +846,10 @@ __device__ __forceinline__ void walk16_pairs(const uint32_t w[4], uint32_t mask,
                                              const uint32_t *run_tab, FP &&fp, F &&f) {
   int prev = -1 - run_in;   // the zeros in front of the chunk count as positions before it
   uint32_t m = mask;
+  LoopCount lc;
   while (m) {
+    HIMG_REGION_BEGIN("enc.walk");
+    lc.step();
     const int k = __ffs(m) - 1;
     m &= m - 1;
     const int run = k - prev - 1;
@@ -877,7 +884,10 @@ __device__ __forceinline__ void walk16_emit(const uint32_t w[4], uint32_t mask, 
                                             const unsigned long long *code_len, PUT &&put, F &&f) {
   int prev = -1 - run_in;   // the zeros in front of the chunk count as positions before it
   uint32_t m = mask;
+  LoopCount lc;
   while (m) {
+    HIMG_REGION_BEGIN("enc.walk");
+    lc.step();
     const int k = __ffs(m) - 1;
     m &= m - 1;
     const int run = k - prev - 1;
@@ -893,7 +903,9 @@ __device__ __forceinline__ void walk16_emit(const uint32_t w[4], uint32_t mask, 
       const unsigned long long cl = code_len[sym];
       put((uint32_t)cl, (int)(cl >> 32));
     }
+    HIMG_REGION_END("enc.walk");
   }
+  lc.done(1);
   if (flush) {
     const int run = nvalid - 1 - prev;
     if (run) emit_run(run, f);
@@ -1585,7 +1597,10 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : (WIDE ? 1024 : 256)) void k_
   uint32_t w[4], wn[4];
   load16(s.sym + tid * 16, s.len - tid * 16, w);
   int par = 0;
+  LoopCount lci;
   for (int base = 0; base < s.len; base += kIter, par ^= 1) {
+    HIMG_REGION_BEGIN("enc.iter");
+    lci.step();
     const int off = base + tid * 16;
     const int nvalid = max(0, min(16, s.len - off));
     // Prefetch the next iteration's symbols.
@@ -1673,13 +1688,18 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : (WIDE ? 1024 : 256)) void k_
       // (Not unrolled: fully unrolled to kPrivWords it is 103 instructions every iteration,
       // whatever the lanes hold -- and a third of the iterations, in the sparse
       // high-frequency rows, have one word per lane at most.)
+      LoopCount lcs;
 #pragma unroll 1
       for (uint32_t j = 0; j < nwords; ++j) {
+        HIMG_REGION_BEGIN("enc.stage");
+        lcs.step();
         const unsigned long long v = (unsigned long long)s_priv[j * NT + tid] << sh;
         atomicOr(&stage[widx], (uint32_t)v | carry);
         carry = (uint32_t)(v >> 32);
         widx = (widx + 1) & (kStage - 1);
+        HIMG_REGION_END("enc.stage");
       }
+      lcs.done(2);
       if (carry) atomicOr(&stage[widx], carry);
       gsync();   // (C)
       const uint32_t nw = iter_end >> 5;
@@ -1692,6 +1712,7 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : (WIDE ? 1024 : 256)) void k_
       fw = nw;
       sbit = iter_end;
       w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
+      HIMG_REGION_END("enc.iter");   // (the fast path's end: the fallback below is not part of the hot iteration)
       continue;
     }
 
@@ -1757,6 +1778,7 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : (WIDE ? 1024 : 256)) void k_
     sbit = iter_end;
     w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
   }
+  lci.done(0);
   gsync();
   if (tid == 0 && (sbit & 31)) store_word(gw0 + (sbit >> 5), stage[(sbit >> 5) & (kStage - 1)]);
 }
@@ -1958,6 +1980,8 @@ static void launch_emit(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t o
     prof_end(prof, stream);
   }
 }
+
+int loop_counts_read_enc(unsigned long long *out) { return loop_counts_read(out); }
 
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
                    uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,

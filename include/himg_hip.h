@@ -340,7 +340,10 @@ enum {
   HIMG_DBG_FRES_ROW_BYTES = 10, /* u32 [rows] payload bytes per block row      */
   HIMG_DBG_DEC_STATS = 11, /* decoder only: u32 [rows+1][8] entropy-decode counters   */
   HIMG_DBG_PARSE_STATS = 12, /* decoder only: u32 [4] container-parse phase cycles / 16 */
-  HIMG_DBG_ROWCOUNT_STATS = 13 /* decoder only: u32 [rows][8] k_row_count phase cycles / 16 */
+  HIMG_DBG_ROWCOUNT_STATS = 13, /* decoder only: u32 [rows][8] k_row_count phase cycles / 16 */
+  HIMG_DBG_LOOP_COUNTS = 14 /* u64 [8][2] trip counts of the marked hot loops since the last read (wavefront
+                               iterations, lane iterations), encoder or decoder kernels; only in a library
+                               built with -DHIMG_LOOP_COUNTS (tools/dynamic_mix.py), HIMG_ERR_ARG otherwise */
 };
 int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void *host_dst,
                         size_t dst_bytes, size_t *bytes_written);

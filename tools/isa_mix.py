@@ -105,8 +105,46 @@ def analyse(body, fast_c, slow_c):
     labels = {}
     loop_at = {}    # label -> depth
     pending_depth = None
+    # Which loop a basic block belongs to comes from the compiler's own annotations ("in
+    # Loop: Header=BBn_m", "This (Inner) Loop Header", "Parent Loop BBn_k"), which hold
+    # whatever the layout (rotated loops, latches in front of their headers, cold blocks
+    # moved away).  own[h] = instructions of the blocks whose INNERMOST loop is h.
+    own = collections.defaultdict(list)
+    parent, depth_of, names = {}, {}, collections.defaultdict(set)
+    regions = {}    # straight-line regions: name -> [begin, end) in insts (HIMG_REGION_BEGIN / _END outside loops)
+    cur = None      # innermost loop of the current block
+    inst_loop = []  # innermost loop of every instruction
+    begin_at, end_at = collections.defaultdict(list), collections.defaultdict(list)   # marker name -> positions in insts
     for i, l in enumerate(lines):
         s = l.strip()
+        blk = re.match(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)", s)
+        if blk:
+            ann = " ".join(lines[i:i + 8 if blk.group(1) else i + 1])
+            ann = ann.split("\n")[0]
+            # only the comment lines that directly follow the label belong to it
+            k, ann = i + 1, lines[i]
+            while k < len(lines) and lines[k].strip().startswith(";") and not lines[k].strip().startswith("; %bb.") and "HIMG_" not in lines[k] and "#ASM" not in lines[k]:
+                ann += " " + lines[k]
+                k += 1
+            if blk.group(1) and "Loop Header: Depth=" in ann:
+                cur = blk.group(1)
+                depth_of[cur] = int(re.search(r"Loop Header: Depth=(\d+)", ann).group(1))
+                ps = re.findall(r"Parent Loop (BB\d+_\d+) Depth=(\d+)", ann)
+                parent[cur] = max(ps, key=lambda t: int(t[1]))[0] if ps else None
+            else:
+                h = re.search(r"in Loop: Header=(BB\d+_\d+)", ann)
+                cur = h.group(1) if h else None
+        mk = re.match(r"^;\s*HIMG_REGION_(BEGIN|END)\s+(\S+)", s)
+        if mk:
+            (begin_at if mk.group(1) == "BEGIN" else end_at)[mk.group(2)].append(len(insts))
+            if cur is not None:
+                if mk.group(1) == "BEGIN":
+                    names[cur].add(mk.group(2))
+            elif mk.group(1) == "BEGIN":
+                regions.setdefault(mk.group(2), [len(insts), None])
+            elif mk.group(2) in regions:
+                regions[mk.group(2)][1] = len(insts)
+            continue
         m = re.match(r"^(\.LBB\d+_\d+):", s)
         if m:
             labels[m.group(1)] = len(insts)
@@ -121,11 +159,14 @@ def analyse(body, fast_c, slow_c):
             continue
         kind, op = classify(s)
         insts.append((kind, op, s))
+        inst_loop.append(cur)
+        if cur is not None:
+            own[cur].append(insts[-1])
     # loops: a backward branch to a loop header label
     loops = []
     for pos, (kind, op, s) in enumerate(insts):
         m = re.search(r"(\.LBB\d+_\d+)$", s)
-        if kind == "salu" and op.startswith("s_cbranch") and m and m.group(1) in labels and labels[m.group(1)] <= pos \
+        if kind == "salu" and op.startswith(("s_cbranch", "s_branch")) and m and m.group(1) in labels and labels[m.group(1)] <= pos \
                 and m.group(1) in loop_at:
             loops.append((m.group(1), labels[m.group(1)], pos + 1))
     def mix(seq):
@@ -138,16 +179,65 @@ def analyse(body, fast_c, slow_c):
                 "valu_cycles_measured": round(c["fast"] * fast_c + c["slow"] * slow_c, 1),
                 "mean_cost_per_valu": round((c["fast"] * fast_c + c["slow"] * slow_c) / valu, 3) if valu else None,
                 "top_slow": slow_ops.most_common(5)}
-    res = {"kernel": mix(insts), "loops": []}
+    res = {"kernel": mix(insts), "loops": [], "regions": {}}
     seen = set()
+    uniq = []
     for lab, a, b in sorted(loops, key=lambda t: (t[1], -t[2])):
         if (lab, a) in seen:
             continue
         seen.add((lab, a))
+        uniq.append((lab, a, b))
+    for lab, a, b in uniq:
         m_ = mix(insts[a:b])
         if m_["instructions"] >= 12:
             m_.update({"header": lab, "depth": loop_at[lab]})
             res["loops"].append(m_)
+    # Named loops (HIMG_REGION_BEGIN inside a loop body names that loop): the mix of the
+    # loop's OWN blocks -- its nested loops are listed on their own -- for
+    # tools/dynamic_mix.py, which weights them with measured trip counts.
+    # The HOT PATH of a named loop: from its BEGIN comment along the layout -- an
+    # unconditional branch is followed; `s_cbranch_execz` to a block of the same loop nest
+    # is TAKEN (it skips a side path no lane needs: the path is the one every iteration
+    # executes at least); every other conditional branch falls through -- to its END comment.
+    def inside(lp, h):   # is loop lp == h or nested in h
+        while lp is not None:
+            if lp == h:
+                return True
+            lp = parent.get(lp)
+        return False
+    def hot_path(name, start, h):
+        ends = set(end_at.get(name, []))
+        seq, pos, steps = [], start, 0
+        while pos < len(insts) and steps < 4000:
+            if pos in ends and seq:
+                return seq
+            kind, op, txt = insts[pos]
+            seq.append(insts[pos])
+            steps += 1
+            tgt = re.search(r"\.L(BB\d+_\d+)$", txt)
+            if kind == "salu" and tgt and ("." + "L" + tgt.group(1)) in labels:
+                tpos = labels[".L" + tgt.group(1)]
+                tin = tpos < len(inst_loop) and inside(inst_loop[tpos], h)
+                if op.startswith("s_branch") or (op.startswith("s_cbranch_execz") and tin):
+                    pos = tpos
+                    continue
+            pos += 1
+        return None
+    res["named_loops"] = []
+    for h, nm in names.items():
+        kids = [c for c, p_ in parent.items() if p_ == h]
+        entry = dict(mix(own[h]), names=sorted(nm), header=h, depth=depth_of.get(h), children=kids, parent=parent.get(h))
+        for n in nm:
+            for b in begin_at[n]:
+                if b < len(inst_loop) and inst_loop[b] == h:
+                    hp = hot_path(n, b, h)
+                    if hp:
+                        entry["hot_path"] = mix(hp)
+        res["named_loops"].append(entry)
+    res["all_loops_own"] = {h: dict(mix(v), depth=depth_of.get(h), parent=parent.get(h)) for h, v in own.items()}
+    for name, (a, b) in regions.items():
+        if b is not None and b > a:
+            res["regions"][name] = mix(insts[a:b])
     return res
 
 
