@@ -114,7 +114,7 @@ struct himg_hip_ctx {
   size_t host_bytes = 0;   // bytes of the last host-API result still resident in h_out
   int fix_t2 = 0;          // HIMG_OPT_FIX_T2 (or HIMG_FIX_T2=1 in the environment)
   int max_sub = 4096;      // HIMG_MAX_SUB_BITS: test knob, see Geom::max_sub
-  int lead_bits = 96;      // HIMG_LEAD_BITS: tuning knob, see Geom::lead_bits
+  int lead_bits = 128;     // HIMG_LEAD_BITS: tuning knob, see Geom::lead_bits
   int lres_serial = 0;     // HIMG_FORCE_LRES_SERIAL=1: test knob, see Geom::lres_serial
   int count_wave = -1, emit_rows = -1;   // HIMG_OPT_COUNT_WAVE / _EMIT_ROWS (-1: by launch size)
   // Batched host API: H2D of frame i+1, kernels of frame i and D2H of frame i-1 overlap
@@ -202,7 +202,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->use_blocks = g->rows > 1 ? 1 : 0;                   // block_size < in_size
   g->fix_t2 = 0;
   g->max_sub = 4096;
-  g->lead_bits = 96;
+  g->lead_bits = 128;
   g->lres_serial = 0;
   g->count_wave = g->emit_rows = -1;
   g->frame_bytes = (long long)width * height * pixel_stride;
