@@ -184,6 +184,20 @@ def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, 
                                                       d_sizes[:1], d_st_e[:1], 0)), 3),
         "decode": round(lat(lambda: eng.decode_device(d_out[:1], cap, h_sizes[:1], 1, W, H, 4, d_pix[:1],
                                                       d_st_d[:1], 0)), 3)}
+    # The same decode with the block rows indexed by the caller (himg_hip_index_host on the host's
+    # copy of the stream, as himg_hip_decode / Decoder::Decode do for every stream that comes from
+    # host memory): the serial header walk -- 246 of the 410 us above -- does not run on the GPU.
+    size0 = int(h_sizes[0])
+    host0 = d_out[0, :size0].cpu().numpy()
+    t = time.perf_counter()
+    _, _, _, off, ln, _ = himg_amd.index_host(host0)
+    t_index = time.perf_counter() - t
+    d_idx = torch.from_numpy(np.concatenate([off, ln]).astype(np.uint32).view(np.int32)).to(dev)
+    out["single_frame_latency_ms"]["decode_rows_indexed"] = round(lat(
+        lambda: eng.decode_rows_indexed_device(d_out[0], size0, W, H, 4, 0, (H + 7) // 8, d_idx, d_pix[0],
+                                               d_st_d[:1], 0)), 3)
+    out["single_frame_latency_ms"]["index_host_ms"] = round(t_index * 1e3, 3)
+    assert int(d_st_d[0].item()) == 0
     # Host-buffer API (himg_hip_encode / himg_hip_decode): H2D + kernels + D2H.
     # The output array is reused, like the reference benchmark reuses one Decoder
     # (benchmark.cpp:122-125): a fresh 64 MiB buffer per call would page-fault

@@ -273,6 +273,62 @@ def test_sharded_decode_scattered_stream(kind, w, h, q, parts):
 
 
 @pytest.mark.gpu
+def test_damaged_rows_from_a_poisoned_scattered_buffer():
+    """Streams with a flipped bit in a block row's payload (half of them in the row's last
+    bytes, where a token may run into the bytes behind the row), decoded by row ranges from
+    buffers that hold only the head and the range's own bytes -- everything else poisoned,
+    the tail behind the stream zeroed as ShardedDecoder leaves it: the verdict and the
+    pixels are the oracle's, i.e. nothing depends on bytes a rank does not own."""
+    import torch
+    w, h, q, parts = 512, 256, 70, 2
+    packed = ol.oracle_encode(himg_amd.synth("randtile", 3, w, h), q, True)
+    rows = (h + 7) // 8
+    _, _, _, off, ln, first = himg_amd.index_host(packed)
+    cap = (packed.size + 15) // 16 * 16 + 64
+    eng = himg_amd.Engine(0)
+    ranges = sharded.shard_rows(rows, parts)
+    slices = sharded.slice_ranges(off, ln, first, packed.size, ranges)
+    d_idx = torch.from_numpy(np.concatenate([off, ln]).astype(np.uint32).view(np.int32)).to("cuda:0")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    rng = np.random.default_rng(11)
+    accepted = rejected = 0
+    for trial in range(32):
+        m = packed.copy()
+        r = int(rng.integers(rows))
+        if trial % 2:
+            pos = int(off[r]) + int(ln[r]) - 1 - int(rng.integers(min(3, int(ln[r]))))
+        else:
+            pos = int(off[r]) + int(rng.integers(int(ln[r])))
+        m[pos] ^= np.uint8(1 << int(rng.integers(8)))
+        rc, pix = ol.oracle_decode(m)
+        d_full = torch.zeros(cap, dtype=torch.uint8, device="cuda:0")
+        d_full[: m.size] = torch.from_numpy(m).to("cuda:0")
+        bad = False
+        got = np.zeros((h, w, 4), np.uint8)
+        for (r0, r1), (lo, hi) in zip(ranges, slices):
+            d_part = torch.full((cap,), 0xAA, dtype=torch.uint8, device="cuda:0")
+            head = (first + 15) // 16 * 16
+            d_part[:head] = d_full[:head]
+            d_part[lo:hi] = d_full[lo:hi]
+            d_part[m.size:] = 0
+            y0, y1 = min(8 * r0, h), min(8 * r1, h)
+            d_rows = torch.zeros((max(y1 - y0, 1), w, 4), dtype=torch.uint8, device="cuda:0")
+            st.zero_()
+            eng.decode_rows_indexed_device(d_part, m.size, w, h, 4, r0, r1, d_idx, d_rows, st)
+            torch.cuda.synchronize()
+            bad = bad or int(st.item()) != 0
+            got[y0:y1] = d_rows[: y1 - y0].cpu().numpy()
+        assert bad == (rc != 0), (trial, r, pos)
+        if rc == 0:
+            assert np.array_equal(got, pix.reshape(h, w, 4)), (trial, r, pos)
+            accepted += 1
+        else:
+            rejected += 1
+    assert accepted and rejected   # both outcomes occur among the mutations
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_sharded_decode_two_processes(tmp_path):
     """Two ranks, two processes, real collectives (gloo with CPU staging: one GPU on
     the test box), real kernels on both ranks; and a stream both ranks reject."""
