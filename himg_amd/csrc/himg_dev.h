@@ -101,7 +101,14 @@ struct DecFrame {            // written by k_dec_parse, read by later kernels
   int16_t lmap[128];         // decoder-side companding tables (positive halves)
   int16_t fmap[128];
   uint8_t shift[2][64];
+  // The row kernels' small tables, the same for every block row of the frame -- built once by
+  // k_dec_parse, copied (kRowTabWords / 4 x 16 bytes) by every row workgroup: the code byte ->
+  // dequantised magnitude (int16 [256]), the shifts (u8 [2][64]), the shifts as packed pairs in
+  // tile_plane's register order (u32 [2][32]) and the identity-test words (u32 [4]).
+  alignas(16) uint32_t row_tabs[128 + 32 + 64 + 4];
 };
+constexpr int kRowTabWords = 128 + 32 + 64 + 4;
+static_assert(kRowTabWords % 4 == 0, "whole 16-byte words");
 
 constexpr int kLresMemoWords = 6;
 // Header words behind a row's kDecThreads lane offsets (lane_off): [0] symbols of the row,

@@ -783,6 +783,7 @@ extern "C" int himg_hip_decode_walk_device(himg_hip_ctx *ctx, const void *d_pack
   int rc = ensure_dec_ws(ctx, g, 1);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
   rc = stage_sizes(ctx, &packed_size, 1, s);
   if (rc) return rc;
   hipStream_t w = ctx->use_side ? ctx->dstr.side : s;
@@ -803,8 +804,8 @@ extern "C" int himg_hip_decode_walk_device(himg_hip_ctx *ctx, const void *d_pack
 extern "C" int himg_hip_decode_walk_wait(himg_hip_ctx *ctx) {
   if (!ctx) return HIMG_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->use_side) HIP_TRY(ctx, hipStreamSynchronize(ctx->dstr.side));
-  else if (ctx->last_stream || true) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  // (without a side stream the walk went to the caller's stream)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->use_side ? ctx->dstr.side : ctx->last_stream));
   return HIMG_OK;
 }
 

@@ -153,6 +153,8 @@ __device__ __forceinline__ uint32_t sub_leaf(int sym, uint32_t rest_bits) {
 // ---------------------------------------------------------------------------
 constexpr int kParseThreads = 1024;
 constexpr int kParseHalf = kParseThreads / 2;   // lanes per stream in step 5
+__device__ __forceinline__ void identity_test_words(const DecFrame *df, int l, uint32_t *dst);
+
 __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, const uint8_t *packed,
                                                              size_t in_stride, const uint32_t *sizes) {
   __shared__ TreeAux aux[2][kMaxNodes + 1];
@@ -428,6 +430,25 @@ __global__ __launch_bounds__(kParseThreads) void k_dec_parse(Geom g, DecWs ws, c
   }
   __syncthreads();
   if (s_status) return;
+  // The row kernels' tables (DecFrame::row_tabs).  df->fmap / df->shift were written by other
+  // lanes of this workgroup in front of the two barriers above.
+  {
+    int16_t *um = reinterpret_cast<int16_t *>(df->row_tabs);
+    uint8_t *sh = reinterpret_cast<uint8_t *>(df->row_tabs + 128);
+    uint32_t *sp = df->row_tabs + 160;
+    if (lane < 256) {
+      const int sc = (int8_t)lane;
+      um[lane] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
+    } else if (lane < 384) {
+      sh[lane - 256] = df->shift[(lane - 256) >> 6][(lane - 256) & 63];
+    } else if (lane < 448) {
+      // The same shifts as packed pairs in tile_plane's register order.
+      const int t = lane - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
+      sp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
+    } else if (lane < 512) {
+      identity_test_words(df, lane - 448, sp + 64);
+    }
+  }
   const long long c_serial = clock64();
 
   // ---- 5: both streams side by side
@@ -1267,6 +1288,9 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       rd.refill();
       const uint2 e = lds_ld64(((((uint32_t)rd.win) << 3) & tm) + tb);
       uint32_t y = e.y, by = e.x, ntm = TM, ntb = TB, adv = 0;
+      // (Unconditional: resetting the table state only on the rare paths -- an else-branch on
+      // tm != TM -- trades three v_mov for four scalar instructions and a branch per step and
+      // measured 12 % slower in the count kernel, 2 % in the row kernel.)
       if (__builtin_expect(y == 0, 0)) {
         if ((by >> 31) && tm == TM) {
           ntm = ((1u << (by & 255u)) - 1u) << 3;
@@ -2733,18 +2757,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   if (tid < kSubEntries / 2) t_sub = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries)[tid];
   uint32_t t_nd = 0;
   if (tid < kMaxNodes + 1) t_nd = (ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1))[tid];
-  if (tid < 256) {
-    const int sc = (int8_t)tid;
-    s_unmap[tid] = (int16_t)(sc >= 0 ? df->fmap[sc] : (sc == -128 ? -df->fmap[127] : -df->fmap[-sc]));
-  } else if (tid < 384) {
-    s_shift[tid - 256] = df->shift[(tid - 256) >> 6][(tid - 256) & 63];
-  } else if (tid < 448) {
-    // The same shifts as packed pairs in tile_plane's register order.
-    const int t = tid - 384, ch = t >> 5, e = t & 31, x = e >> 2, j = e & 3;
-    s_shiftp[t] = (uint32_t)df->shift[ch][(2 * j) * 8 + x] | ((uint32_t)df->shift[ch][(2 * j + 1) * 8 + x] << 16);
-  } else if (tid < 512) {
-    identity_test_words(df, tid - 448, s_shiftp + 64);
-  }
+  // The transform's tables: one 16-byte word per lane of wave 0 from the frame's copy (k_dec_parse).
+  static_assert(kRowTabWords / 4 <= 64, "one wavefront copies them");
+  uint4 t_row = make_uint4(0, 0, 0, 0);
+  if (tid < kRowTabWords / 4) t_row = reinterpret_cast<const uint4 *>(df->row_tabs)[tid];
   const GrpTables tb = tables_of(&T);
   const int rb = r0 + (int)blockIdx.x * rpw;
   const int nr = COLS == 512 ? 1 : min(rpw, r1 - rb);
@@ -2755,6 +2771,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym0)[k] = z;
   }
   reinterpret_cast<uint4 *>(T.grp)[tid] = t_grp;
+  if (tid < kRowTabWords / 4) reinterpret_cast<uint4 *>(smem + L.unmap)[tid] = t_row;   // unmap, shift, shiftp: contiguous
   if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(T.grp + (1 << kLutBits))[tid] = t_sub;
   if (tid < kMaxNodes + 1) T.nd[tid] = t_nd;
   if constexpr (COLS == 512) {
