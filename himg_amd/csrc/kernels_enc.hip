@@ -740,7 +740,10 @@ __device__ __forceinline__ uint32_t wave_prev(uint32_t identity, uint32_t v) {
 // Exclusive block scan (256 threads) of zero-run summaries; `carry` is the state
 // before this block of symbols.  Returns the exclusive prefix; *total receives
 // the state after the block.  `sm` needs NW entries (NW wavefronts in the workgroup).
-template <int NW = 4>
+// ALT: the caller alternates between two `sm` buffers from call to call, so the barrier
+// that protects sm against the next call's stores is not needed (a wavefront can only be
+// two calls ahead of another once that one has passed the barrier of the call between).
+template <int NW = 4, bool ALT = false>
 __device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total) {
   const int lane = lane_id(), wave = wave_id();
   const uint32_t inclp = wave_scan_zrp(zr_pack(mine));
@@ -752,7 +755,7 @@ __device__ __forceinline__ ZR block_scan_zr(ZR mine, ZR carry, ZR *sm, ZR *total
     if (w < wave) pre = zr_combine(pre, sm[w]);
     tot = zr_combine(tot, sm[w]);
   }
-  __syncthreads();
+  if (!ALT) __syncthreads();
   *total = tot;
   return zr_combine(pre, ex);
 }
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   __shared__ uint32_t hist2[kPairRuns + 1][257];
   __shared__ uint32_t hrun[kRunTab + 1];   // runs of kPairRuns..278 zeros, by exact length
   __shared__ uint32_t s_sym[8 * NT];      // [word][lane]: the lane's 32 symbols of this iteration
-  __shared__ ZR sm[NT / 64];
+  __shared__ ZR sm[2][NT / 64];           // (alternating: one barrier per iteration, see block_scan_zr)
   const int sp = blockIdx.x + sp0, f = blockIdx.y;
   const Span s = get_span(g, ws, sp, f);
   for (int k = threadIdx.x; k < kHistStride; k += NT) hist[k] = 0;
@@ -1026,7 +1029,8 @@ __global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
   // with 32 symbols the busiest lane is 1.6x the mean instead of 1.9x with 16; the
   // scans and the barrier are paid half as often per symbol.  The lane's symbols sit
   // in LDS (transposed), where the walk fetches them by position.
-  for (int base = 0; base < s.len; base += 32 * NT) {
+  int par = 0;
+  for (int base = 0; base < s.len; base += 32 * NT, par ^= 1) {
     const int off = base + threadIdx.x * 32;
     const int nvalid = max(0, min(32, s.len - off));
     uint32_t w[8];
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
     mine.tz = mask ? nvalid - (32 - __clz(mask)) : nvalid;
     mine.az = mask ? 0 : 1;
     ZR total;
-    const ZR ex = block_scan_zr<NT / 64>(mine, carry, sm, &total);
+    const ZR ex = block_scan_zr<NT / 64, true>(mine, carry, sm[par], &total);
     carry = total;
     carry.az = 0;
     const bool flush = s.last_of_block && nvalid > 0 && off + nvalid == s.len;
