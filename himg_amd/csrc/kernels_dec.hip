@@ -2264,6 +2264,21 @@ __device__ __forceinline__ uint32_t sat_pk_u8(uint32_t x) {
   return r;   // byte 0 = sat(lo half), byte 1 = sat(hi half)
 }
 
+// The same into the HIGH half of `lo` (whose low half holds an earlier pair's two bytes): SDWA
+// writes the result word there and keeps the other, which saves the v_perm that would merge
+// two results.
+__device__ __forceinline__ uint32_t sat_pk_u8_hi(uint32_t lo, uint32_t x) {
+  asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(lo) : "v"(x));
+  return lo;
+}
+
+// 2 * a + c on packed int16 pairs, one instruction.
+__device__ __forceinline__ uint32_t pk_mad2(dpk16 a, dpk16 c) {
+  uint32_t r;
+  asm("v_pk_mad_i16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, c)));
+  return r;
+}
+
 __device__ __forceinline__ void iwht8_pk(dpk16 &x0, dpk16 &x1, dpk16 &x2, dpk16 &x3, dpk16 &x4,
                                          dpk16 &x5, dpk16 &x6, dpk16 &x7) {
   const dpk16 three = {3, 3};
@@ -2485,16 +2500,16 @@ __device__ __forceinline__ void tile_plane(const uint8_t *slot, int cols_rt, con
   lowres_quads(lr0, lr8, LQ);
 #pragma unroll
   for (int y = 0; y < 8; ++y) {
-    uint32_t sb[4];
+    uint32_t sum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t sel = 0x0c000c00u | (uint32_t)(y & 3) | ((uint32_t)(4 + (y & 3)) << 16);
       const dpk16 lo = __builtin_bit_cast(
           dpk16, __builtin_amdgcn_perm(LQ[y >> 2][2 * i + 1], LQ[y >> 2][2 * i], sel));
-      sb[i] = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(T[y * 4 + i] + lo)));
+      sum[i] = __builtin_bit_cast(uint32_t, (dpk16)(T[y * 4 + i] + lo));
     }
-    O[y * 2] = __builtin_amdgcn_perm(sb[1], sb[0], 0x05040100u);
-    O[y * 2 + 1] = __builtin_amdgcn_perm(sb[3], sb[2], 0x05040100u);
+    O[y * 2] = sat_pk_u8_hi(sat_pk_u8(sum[0]), sum[1]);
+    O[y * 2 + 1] = sat_pk_u8_hi(sat_pk_u8(sum[2]), sum[3]);
   }
   (void)shift;
 }
@@ -2582,12 +2597,14 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
             const dpk16 cbq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q1, sel));
             const dpk16 crq = __builtin_bit_cast(dpk16, __builtin_amdgcn_perm(0u, q2, sel));
             const dpk16 c255 = {255, 255}, c254 = {254, 254}, one = {1, 1};
-            const dpk16 cbv = cbq + cbq - c255, crv = crq + crq - c255;
-            // (cbv + crv + 2) >> 2 == (cb + cr - 254) >> 1 exactly.
+            // cbv = 2 cb - 255, crv = 2 cr - 255;  (cbv + crv + 2) >> 2 == (cb + cr - 254) >> 1 exactly.
             const dpk16 gg = yy - ((cbq + crq - c254) >> one);
-            const uint32_t rs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + crv)));
+            // r = g + crv, b = g + cbv as ONE multiply-add each on top of g - 255 (v_pk_mad_i16:
+            // three packed operations for the pair instead of six; everything stays far inside int16).
+            const dpk16 g255 = gg - c255;
+            const uint32_t rs = sat_pk_u8(pk_mad2(crq, g255));
             const uint32_t gs = sat_pk_u8(__builtin_bit_cast(uint32_t, gg));
-            const uint32_t bs = sat_pk_u8(__builtin_bit_cast(uint32_t, (dpk16)(gg + cbv)));
+            const uint32_t bs = sat_pk_u8(pk_mad2(cbq, g255));
             const uint32_t rg = __builtin_amdgcn_perm(gs, rs, 0x05010400u);            // r0 g0 r1 g1
             const uint32_t ba = __builtin_amdgcn_perm(q3, bs, k ? 0x07010600u : 0x05010400u);  // b0 a0 b1 a1
             px[4 * h + 2 * k] = __builtin_amdgcn_perm(ba, rg, 0x05040100u);
