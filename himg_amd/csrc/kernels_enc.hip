@@ -902,9 +902,19 @@ __device__ __forceinline__ void walk16_emit(const uint32_t w[4], uint32_t mask, 
     } else {
       const uint32_t rt = run_tab[min(run, kRunTab)];
       if (__builtin_expect(rt == 0 && run != 0, 0)) emit_run(run, f);   // 279 zeros or more, or a token beyond 24 bits
-      put(rt & 0xffffffu, (int)(rt >> 24));
+      // The run token and the literal as ONE put where they fit 32 bits together -- they do
+      // whenever the literal is short, and a literal behind seven zeros or more is (|s| <= 4 in
+      // every such token of the benchmark frames; 86 % of a wavefront's 1024-symbol iterations
+      // hold such a token: the sparse high-frequency rows).  -3 % VALU instructions, -6 % LDS
+      // (PMC); the kernel's time does not move (5.63 ms per 128 frames either way).
       const unsigned long long cl = code_len[sym];
-      put((uint32_t)cl, (int)(cl >> 32));
+      const int nr = (int)(rt >> 24), nl = (int)(cl >> 32);
+      if (__builtin_expect(nr + nl <= 32, 1)) {
+        put((rt & 0xffffffu) | ((uint32_t)cl << nr), nr + nl);
+      } else {
+        put(rt & 0xffffffu, nr);
+        put((uint32_t)cl, nl);
+      }
     }
     HIMG_REGION_END("enc.walk");
   }
