@@ -3077,6 +3077,26 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count(Geom g, DecWs ws, 
 // ---------------------------------------------------------------------------
 constexpr int kCountRowsW = kDecThreads / 64;   // rows per workgroup (one per wavefront)
 
+// Wavefront scan / shift on the DPP path (one VALU operation per step where __shfl_up is a
+// ds_bpermute with its address arithmetic, a wait and a select).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_from_d(uint32_t identity, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add_dpp(uint32_t v) {   // inclusive; lane 63: the total
+  v += dpp_from_d<0x111, 0xf>(0, v);   // row_shr:1
+  v += dpp_from_d<0x112, 0xf>(0, v);   // row_shr:2
+  v += dpp_from_d<0x114, 0xf>(0, v);   // row_shr:4
+  v += dpp_from_d<0x118, 0xf>(0, v);   // row_shr:8
+  v += dpp_from_d<0x142, 0xa>(0, v);   // row_bcast:15
+  v += dpp_from_d<0x143, 0xc>(0, v);   // row_bcast:31
+  return v;
+}
+// Lane l gets lane l - 1's v, lane 0 gets `first` (wave_shr:1).
+__device__ __forceinline__ uint32_t wave_shr1_dpp(uint32_t first, uint32_t v) {
+  return dpp_from_d<0x138, 0xf>(first, v);
+}
+
 // A piece of the payload staged in LDS, read ON DEMAND: a step fetches the 32 stream bits
 // at its position with one ds_read2_b32 and one v_alignbit instead of keeping a 64-bit
 // register window alive (the refill of ReaderT -- ten instructions with a 64-bit shift
@@ -3306,9 +3326,8 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
         cT = c1;
         at_start = false;
       }
-      // The chain: a lane starts where its left neighbour ended.
-      const uint32_t left = __shfl_up(endpos, 1);
-      const uint32_t ns = lane == 0 ? fst : left;
+      // The chain: a lane starts where its left neighbour ended (one DPP move).
+      const uint32_t ns = wave_shr1_dpp(fst, endpos);
       dirty = active && ns != start;
       if (active) start = ns;
       ++rounds;
@@ -3316,12 +3335,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
     }
     // Exclusive prefix of the counts (k_row_count's clamp: see row_count_one).
     const uint32_t c = min(cnt, 0x3fffffu);
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
+    const uint32_t incl = wave_scan_add_dpp(c);
     l_start[v] = start + shift - rel0;
     l_off[v] = base + incl - c;
     if (v == q.last_active) l_off[kDecThreads + 1] = endpos + shift - rel0;
