@@ -111,15 +111,43 @@ __global__ __launch_bounds__(256) void k_lowres_avg(Geom g, const uint8_t *frame
 }
 
 // k_lowres_blend: m = blend of the averages at (v-1,v) x (u-1,u) (downsampled.cpp:98-113).
-constexpr int kBlendRows = 8;   // block rows per k_lowres_blend workgroup (the kernel is launch-bound)
+constexpr int kBlendRows = 8;    // block rows per k_lowres_blend workgroup (the kernel is launch-bound)
+// QUAD: four columns per lane (cols a multiple of 4, planes dword aligned): one dword load
+// per row and one byte for the column in front, a dword store -- the byte-per-lane form
+// is bound by its instruction count, not by the 2 MiB it moves per frame.
+template <bool QUAD>
 __global__ __launch_bounds__(256) void k_lowres_blend(Geom g, const uint8_t *avg, uint8_t *low,
                                                       size_t plane_stride, int v0, int v1) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
-  if (u >= g.cols) return;
   const uint8_t *a = avg + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
-  const int c1 = max(0, u - 1);
   const int vb = v0 + (int)blockIdx.y * kBlendRows;
+  if (QUAD) {
+    const int u = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (u >= g.cols) return;
+    uint8_t *o = low + (size_t)f * plane_stride + (size_t)c * g.rows * g.cols;
+    auto row = [&](int r, uint32_t *w, uint32_t *left) {
+      *w = *reinterpret_cast<const uint32_t *>(a + (size_t)r * g.cols + u);
+      *left = u ? a[(size_t)r * g.cols + u - 1] : (*w & 255u);
+    };
+    for (int v = vb; v < min(vb + kBlendRows, v1); ++v) {
+      uint32_t w1, l1, w2, l2;
+      row(max(0, v - 1), &w1, &l1);
+      row(v, &w2, &l2);
+      uint32_t out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x12 = (w1 >> (8 * k)) & 255, x22 = (w2 >> (8 * k)) & 255;
+        const int x11 = k ? (int)((w1 >> (8 * (k - 1))) & 255) : (int)l1, x21 = k ? (int)((w2 >> (8 * (k - 1))) & 255) : (int)l2;
+        const int a1 = (x11 + 15 * x12 + 8) >> 4, a2 = (x21 + 15 * x22 + 8) >> 4;
+        out |= (uint32_t)((a1 + 15 * a2 + 8) >> 4) << (8 * k);
+      }
+      *reinterpret_cast<uint32_t *>(o + (size_t)v * g.cols + u) = out;
+    }
+    return;
+  }
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= g.cols) return;
+  const int c1 = max(0, u - 1);
   for (int v = vb; v < min(vb + kBlendRows, v1); ++v) {
     const int r1 = max(0, v - 1);
     const int x11 = a[r1 * g.cols + c1], x12 = a[r1 * g.cols + u];
@@ -2024,8 +2052,12 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   prof_end(prof, stream);
 
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride, 0);
-  HIMG_LAUNCH(k_lowres_blend, dim3(gx, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256, g, ws.avg, ws.low,
-              ws.plane_stride, 0, g.rows);
+  if ((g.cols & 3) == 0 && (ws.plane_stride & 3) == 0)
+    HIMG_LAUNCH(k_lowres_blend<true>, dim3((g.cols / 4 + 255) / 256, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256,
+                g, ws.avg, ws.low, ws.plane_stride, 0, g.rows);
+  else
+    HIMG_LAUNCH(k_lowres_blend<false>, dim3(gx, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256, g, ws.avg, ws.low,
+                ws.plane_stride, 0, g.rows);
   // The LRES branch (predictor selection + delta chain, zero-run summaries, token
   // histogram of the LRES spans: 1/64 of the data, latency-bound kernels) forks to the
   // side stream and runs beside the pixel stage and the FRES histogram; the two
@@ -2100,7 +2132,7 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
   const int a0 = r0 > 0 ? r0 - 1 : 0, a1 = r1 < g.rows ? r1 + 1 : g.rows;
   const int l1 = r1 < g.rows ? r1 + 1 : g.rows;
   HIMG_LAUNCH(k_lowres_avg, dim3(gx, a1 - a0, 1), b256, g, d_frame_base, ws.avg, ws.plane_stride, a0);
-  HIMG_LAUNCH(k_lowres_blend, dim3(gx, (l1 - r0 + kBlendRows - 1) / kBlendRows, g.C), b256, g, ws.avg, ws.low,
+  HIMG_LAUNCH(k_lowres_blend<false>, dim3(gx, (l1 - r0 + kBlendRows - 1) / kBlendRows, g.C), b256, g, ws.avg, ws.low,
               ws.plane_stride, r0, l1);
   launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
   launch_tok_hist_rows(g, ws, r0, r1, 1, stream, prof);
