@@ -234,7 +234,10 @@ def analyse(body, fast_c, slow_c):
                     if hp:
                         entry["hot_path"] = mix(hp)
         res["named_loops"].append(entry)
-    res["all_loops_own"] = {h: dict(mix(v), depth=depth_of.get(h), parent=parent.get(h)) for h, v in own.items()}
+    # (compact: only what has instructions worth a line)
+    res["all_loops_own"] = {h: {"instructions": len(v), "valu": sum(1 for k, _, _ in v if k in ("fast", "slow")),
+                                "depth": depth_of.get(h), "parent": parent.get(h)}
+                            for h, v in own.items() if len(v) >= 40}
     for name, (a, b) in regions.items():
         if b is not None and b > a:
             res["regions"][name] = mix(insts[a:b])
