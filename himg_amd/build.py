@@ -100,6 +100,33 @@ def build_cli(verbose=False):
     return out
 
 
+REF_SRC = "/root/reference/src"
+
+
+def build_ref_benchmark(verbose=False):
+    """The reference's OWN benchmark main (src/benchmark.cpp), compiled where it lies and
+    unchanged, linked against this library -- FreeImage, which that main only needs for
+    non-HIMG files, is a test-only link stub whose loaders fail (tests/cpp/fi_stub).  Built
+    in the container that has /root/reference; the binary (git-ignored, like the .so)
+    travels to the GPU box, where tests/test_reference_benchmark.py runs it.  Returns the
+    path, or None when neither the sources nor a prebuilt binary are there."""
+    exe = os.path.join(BINDIR, "ref_benchmark")
+    src = os.path.join(REF_SRC, "benchmark.cpp")
+    if not os.path.exists(src):
+        return exe if os.path.exists(exe) else None
+    lib = build_lib(verbose=verbose)
+    os.makedirs(BINDIR, exist_ok=True)
+    stub_dir = os.path.join(ROOT, "tests", "cpp", "fi_stub")
+    stub = os.path.join(stub_dir, "freeimage_link_stub.cpp")
+    if _stale(exe, [src, stub, os.path.join(stub_dir, "FreeImage.h"), lib]):
+        cmd = ["g++", "-std=c++11", "-O2", "-I" + os.path.join(ROOT, "include"), "-I" + stub_dir, src, stub,
+               "-L" + LIBDIR, "-lhimg_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../lib", "-o", exe]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return exe
+
+
 def build_unit_checks(verbose=False):
     """Device-side unit checks (tests/ run them on the GPU box): tile_plane_check
     compares the packed inverse transform with a scalar host model."""

@@ -926,6 +926,15 @@ struct ReaderT {
     }
   }
   __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
+  // End of a walk: the last prefetch is never used, and a load that is still in flight when
+  // the walk's code is left stays "pending" on its register for the compiler's s_waitcnt
+  // placement in whatever code follows -- including, through the structurised control flow,
+  // loops of OTHER walks that can never run after this one: their ds_read into that register
+  // then carries an s_waitcnt vmcnt(0) on every iteration (round 5: the chain loop of the row
+  // kernel's write pass waited for its own prefetch on every step because the token-tail
+  // loop's prefetch register was still pending on a static path into it).  Using the word
+  // here makes the wait happen once, where the walk ends.
+  __device__ __forceinline__ void retire() { asm volatile("" :: "v"(pre)); }
 };
 typedef ReaderT<const uint32_t *> GReader;                                        // payload in place (L2)
 typedef ReaderT<const __attribute__((address_space(3))) uint32_t *> LReader;      // payload staged in LDS
@@ -1116,6 +1125,7 @@ __device__ __forceinline__ void lean_count(RD &rd, const GrpTables &t, uint32_t 
       }
     }
   }
+  rd.retire();
   *endpos = pos;
   *count = c;
 }
@@ -1321,6 +1331,7 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       while (bp < lim) { HIMG_REGION_BEGIN("dec.write"); step(); lc.step(); HIMG_REGION_END("dec.write"); }
       lc.done(0);
       if (tm != TM) step();
+      rd.retire();
       return !bad;
     }
     while ((int)bp <= limk) step();
@@ -1332,6 +1343,7 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       op += cnt;
       bp += nbits;
     }
+    rd.retire();
   }
   return !bad;
 }
@@ -1342,9 +1354,9 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
 // complete (~0u if it did not).
 // CLIP: as in lean_write; op and out_size then both count from the window's guard.
 template <bool CLIP = false>
-__device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uint32_t bp,
-                                            uint32_t lim, uint32_t op, uint32_t out_size,
-                                            uint8_t *lds_out, uint32_t *end_bp, uint32_t win_span = 0) {
+__device__ __forceinline__ bool exact_write_body(GReader &rd, const GrpTables &t, uint32_t bp,
+                                                 uint32_t lim, uint32_t op, uint32_t out_size,
+                                                 uint8_t *lds_out, uint32_t *end_bp, uint32_t win_span) {
   *end_bp = ~0u;
   // Positions are compared as SIGNED numbers: in a window (CLIP) a lane may start in
   // front of it, its position then lies below zero (everything is far below 2^31).
@@ -1387,6 +1399,15 @@ __device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uin
     if (!before(op, out_size)) { *end_bp = bp; return true; }
     if (!(bp < lim)) return true;
   }
+}
+
+template <bool CLIP = false>
+__device__ __forceinline__ bool exact_write(GReader &rd, const GrpTables &t, uint32_t bp,
+                                            uint32_t lim, uint32_t op, uint32_t out_size,
+                                            uint8_t *lds_out, uint32_t *end_bp, uint32_t win_span = 0) {
+  const bool ok = exact_write_body<CLIP>(rd, t, bp, lim, op, out_size, lds_out, end_bp, win_span);
+  rd.retire();   // (whichever way the walk ended: see ReaderT::retire)
+  return ok;
 }
 
 // Write pass to HBM through 32 KiB LDS windows (zero runs are the window's zero
@@ -1445,6 +1466,7 @@ __device__ __forceinline__ void lean_write_windows(GReader &rd, const GrpTables 
     }
     __syncthreads();
   }
+  rd.retire();
 }
 
 // Write pass straight to PRE-ZEROED global memory (the LRES symbols: 1/64 of the
@@ -1519,6 +1541,7 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
       o += cnt;
       bp += nbits;
     }
+    rd.retire();
     if (bad) sh->err = 1;
     return;
   }
@@ -1547,6 +1570,7 @@ __device__ __forceinline__ void lean_write_global(GReader &rd, const GrpTables &
     if (exact && op >= out_size) { sh->endbit = endbit_base + (bp - rel0); break; }
     if (!(bp < lim)) break;
   }
+  rd.retire();
   if (bad) sh->err = 1;
 }
 
@@ -3677,6 +3701,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       prof_begin(prof, "k_dec_row_fused", stream);
       const bool whole4 = g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0;   // FULL4
       if (g.W == 4096 && whole4) HIMG_FUSED_LAUNCH(512, a, b);
+      else if (g.W == 2048 && whole4) HIMG_FUSED_LAUNCH(256, a, b);   // compile-time strides for the other
+      else if (g.W == 1920 && whole4) HIMG_FUSED_LAUNCH(240, a, b);   // BASELINE widths (config 3: 1920)
       else if (whole4) HIMG_FUSED_LAUNCH(-1, a, b);
       else HIMG_FUSED_LAUNCH(0, a, b);
       prof_end(prof, stream);
