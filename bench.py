@@ -73,6 +73,9 @@ def parse_args():
                     help="seconds the config-4 rows leg may take before the frames line is printed without it")
     ap.add_argument("--no-rows", action="store_true",
                     help="skip the row-sharded 16384x16384 leg (the `rows` object of the frames line)")
+    ap.add_argument("--rows-size", default=None,
+                    help="TEST ONLY: WxH of the frame of the `rows` object of a frames line (default: config 4, "
+                         "16384x16384 -- anything else is checked against the oracle instead of the golden table)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY (1-GPU box): every rank uses cuda:0 and the collectives run over gloo with "
                          "CPU staging, to exercise the launcher and the N > 1 orchestration; not a measurement")
@@ -273,6 +276,8 @@ def rows_leg(args, rank, local_rank, world, dev, steps, warmup):
         W, H, Q, kind = args.width or 16384, args.height or 16384, args.quality, args.kind
     else:                     # as the `rows` object of the frames line: config 4 as BASELINE.json states it
         W, H, Q, kind = 16384, 16384, 50, "randtile"
+        if args.rows_size:    # (tests: the same leg on a frame that eight ranks sharing one GPU can afford)
+            W, H = (int(x) for x in args.rows_size.lower().split("x"))
     rows, cols = (H + 7) // 8, (W + 7) // 8
     img = himg_amd.synth(kind, 0, W, H)               # every rank generates, then keeps its shard
     r0, r1 = sharded.shard_rows(rows, world)[rank]

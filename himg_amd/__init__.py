@@ -73,6 +73,7 @@ def lib():
     L.himg_hip_fetch_last.argtypes = [vp, vp, sz, P(sz)]
     L.himg_hip_peek.argtypes = [vp, sz, P(i32), P(i32), P(i32)]
     L.himg_hip_set_option.argtypes = [vp, i32, i32]
+    L.himg_hip_get_option.argtypes = [vp, i32, C.POINTER(C.c_int)]
     L.himg_hip_encode_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_decode_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.himg_hip_free.argtypes = [vp]
@@ -183,6 +184,9 @@ class Engine:
         if rc:
             raise HimgError(rc, "himg_hip_create (no usable GPU? there is no CPU fallback)")
         self.device = device
+        # What the context took from the environment (HIMG_FIX_T2=1) counts too: the row-sharded
+        # decoder's host index must follow the engine's own rule (sharded.py).
+        self.fix_t2 = bool(self.get_option("fix_t2"))
 
     def close(self):
         if self._ctx:
@@ -272,6 +276,13 @@ class Engine:
         rc = lib().himg_hip_decode_batch(self._ctx, src, szs, n, dst, caps, ws, hs, cs)
         self._check(rc, "decode_batch")
         return [o.ravel()[: ws[i] * hs[i] * cs[i]].reshape(hs[i], ws[i], cs[i]) for i, o in enumerate(outs)]
+
+    def get_option(self, option):
+        """himg_hip_get_option: the option as the context holds it (names as in set_option)."""
+        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3}[option] if isinstance(option, str) else int(option)
+        v = C.c_int(0)
+        self._check(lib().himg_hip_get_option(self._ctx, opt, C.byref(v)), "get_option")
+        return v.value
 
     def set_option(self, option, value):
         """himg_hip_set_option; option names: "fix_t2", and the kernel-variant selectors

@@ -140,6 +140,17 @@ struct himg_hip_ctx {
   DecWs dec_ws{};
   int dec_batch = 0;
   bool dec_valid = false;
+  // What the last himg_hip_decode_head_device prepared (the frame tables and the low-res plane in
+  // the decoder workspace): himg_hip_decode_rows_after_head_device must be handed the same
+  // stream, geometry and HIP stream, with no other decode on this context in between (every
+  // decode entry point goes through ensure_dec_ws, which drops the token).
+  struct HeadToken {
+    bool valid = false;
+    int w = 0, h = 0, c = 0;
+    const void *packed = nullptr;
+    uint32_t size = 0;
+    void *stream = nullptr;
+  } head;
 
   // Staging for the host-buffer API.
   DevBuf h_in, h_out, h_sizes, h_status, h_index;
@@ -328,6 +339,14 @@ extern "C" void himg_hip_host_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
 
+extern "C" int himg_hip_get_option(himg_hip_ctx *ctx, int option, int *value) {
+  if (!ctx || !value) return HIMG_ERR_ARG;
+  if (option == HIMG_OPT_FIX_T2) { *value = ctx->fix_t2; return HIMG_OK; }
+  if (option == HIMG_OPT_COUNT_WAVE) { *value = ctx->count_wave; return HIMG_OK; }
+  if (option == HIMG_OPT_EMIT_ROWS) { *value = ctx->emit_rows; return HIMG_OK; }
+  return fail(ctx, HIMG_ERR_ARG, "unknown option");
+}
+
 extern "C" int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value) {
   if (!ctx) return HIMG_ERR_ARG;
   if (option == HIMG_OPT_FIX_T2) { ctx->fix_t2 = value ? 1 : 0; return HIMG_OK; }
@@ -464,6 +483,7 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
 
 static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   DecWs &w = ctx->dec_ws;
+  ctx->head.valid = false;   // whatever decode this is, it overwrites what a head phase left
   const size_t plane = round_up((size_t)g.C * g.rows * g.cols, 256);
   const size_t lres = round_up((size_t)g.lres_size + 16, 256);
   const size_t fres = round_up((size_t)g.fres_size + 16, 256);
@@ -748,8 +768,14 @@ extern "C" int himg_hip_decode_rows_indexed_device(himg_hip_ctx *ctx, const void
 extern "C" int himg_hip_decode_head_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
                                            int width, int height, int num_channels, void *stream) {
   if (!ctx || !d_packed) return HIMG_ERR_ARG;
-  return decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, 0, 0, nullptr, nullptr,
-                             nullptr, stream, himg_dev::kDecHead);
+  const int rc = decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, 0, 0, nullptr, nullptr,
+                                     nullptr, stream, himg_dev::kDecHead);
+  if (rc == HIMG_OK) {
+    ctx->head.valid = true;
+    ctx->head.w = width; ctx->head.h = height; ctx->head.c = num_channels;
+    ctx->head.packed = d_packed; ctx->head.size = packed_size; ctx->head.stream = stream;
+  }
+  return rc;
 }
 
 extern "C" int himg_hip_decode_rows_after_head_device(himg_hip_ctx *ctx, const void *d_packed,
@@ -758,9 +784,16 @@ extern "C" int himg_hip_decode_rows_after_head_device(himg_hip_ctx *ctx, const v
                                                       const uint32_t *d_row_index, void *d_out_rows,
                                                       int32_t *d_status, void *stream) {
   if (!ctx || !d_packed || !d_out_rows || !d_status || !d_row_index) return HIMG_ERR_ARG;
-  if (!ctx->dec_valid) return fail(ctx, HIMG_ERR_ARG, "decode_head_device has not run");
-  return decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, row0, row1, d_row_index,
-                             d_out_rows, d_status, stream, himg_dev::kDecRows);
+  const himg_hip_ctx::HeadToken t = ctx->head;
+  if (!t.valid)
+    return fail(ctx, HIMG_ERR_ARG, "decode_rows_after_head_device: no decode_head_device in front of it (or another decode since)");
+  if (t.w != width || t.h != height || t.c != num_channels || t.packed != d_packed || t.size != packed_size ||
+      t.stream != stream)
+    return fail(ctx, HIMG_ERR_ARG, "decode_rows_after_head_device: not the stream / geometry / HIP stream of decode_head_device");
+  const int rc = decode_rows_indexed(ctx, d_packed, packed_size, width, height, num_channels, row0, row1, d_row_index,
+                                     d_out_rows, d_status, stream, himg_dev::kDecRows);
+  if (rc == HIMG_OK) ctx->head = t;   // (another row range of the same frame may follow)
+  return rc;
 }
 
 // The row index of a stream in HBM by the header walk ALONE (k_dec_rowwalk finds the FRES

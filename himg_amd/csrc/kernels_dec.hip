@@ -1607,6 +1607,27 @@ struct PreLane {
   uint32_t nstart;   // the right neighbour's start (~0u: none, the lane walks to the end of the chunk)
 };
 
+// The fixpoint of a chunk that no count kernel has recorded, out of line: the row kernels reach
+// it only for rows of several chunks or with an unusable record, and inlined its loops (and the
+// 1024-lane scan behind them) were where most of those kernels' scalar registers went -- 47 to
+// 118 SGPRs spilled to VGPR lanes, some reloaded inside the write loops.  Everything crosses
+// the call by value (a reader passed by reference would live in scratch).
+struct ColdFix { uint32_t start, endpos, cnt, rounds; unsigned long long off, tot; long long c_first; };
+__device__ __attribute__((noinline)) ColdFix cold_fixpoint(const uint8_t *p, uint32_t stream_size,
+                                                           unsigned long long abs_bit, const uint32_t *grp_lds,
+                                                           const uint32_t *nd_lds, StreamShared *sh, bool active,
+                                                           uint32_t lim, uint32_t start, uint32_t lead_bits) {
+  GrpTables tb;
+  tb.grp = reinterpret_cast<const uint2 *>(grp_lds); tb.gx = nullptr; tb.gy = nullptr; tb.nd = nd_lds;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(p, stream_size, abs_bit);
+  ColdFix r;
+  r.start = start; r.endpos = start; r.cnt = 0; r.rounds = 0; r.c_first = 0;
+  lean_fixpoint(rd, tb, sh, rel0, active, lim, &r.start, &r.endpos, &r.cnt, &r.rounds, false, lead_bits, &r.c_first);
+  r.off = block_scan_u64(r.cnt, sh->sm64, &r.tot);
+  return r;
+}
+
 // Decode one whole stream with one workgroup, chunk after chunk (each chunk's
 // first token position is exact because the previous chunk has finished).  The
 // sub-sequence length is chosen so that the 1024 lanes cover the remaining payload
@@ -1625,8 +1646,7 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
                              uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
                              StreamShared *sh, uint8_t *lds_out, uint32_t *win, uint8_t *gout,
                              uint32_t *stats, uint32_t max_sub, uint32_t lead_bits,
-                             const uint32_t *pre_start = nullptr, const uint32_t *pre_off = nullptr,
-                             const PreLane *pl = nullptr) {
+                             const uint32_t *pre_start = nullptr, const uint32_t *pre_off = nullptr) {
   const int tid = threadIdx.x;
   if (!PRIMED) {
     if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
@@ -1639,34 +1659,6 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
   uint32_t st_chunks = 0, st_rounds = 0;
   long long c_sync = 0, c_write = 0, c_r1 = 0, c_t0 = clock64();
   bool synced = false;   // (uniform) a barrier stands between the last write pass and here
-
-  // The row kernel's normal case: ONE chunk whose lanes k_row_count has recorded, the
-  // record in registers.  Nothing of the sub-sequence grid is needed (a lane walks from
-  // its recorded start to its right neighbour's), and where the chunk ends is in the
-  // record as well: one barrier, behind the write pass.
-  if (FUSED && pl && pl->valid != 0 && P1 != 0 && out_size != 0) {
-    GReader rd;
-    const uint32_t rel0 = rd.attach(p, stream_size, 8ull * pay_off);
-    const uint32_t rel_end = rel0 + (uint32_t)P1;   // (a recorded row is one chunk: k_row_count)
-    const uint32_t start = rel0 + pl->start, opl = pl->off, cnt = pl->nxt - pl->off;
-    const uint32_t wlim = pl->nstart < (uint32_t)P1 ? rel0 + pl->nstart : rel_end;
-    st_chunks = 1; st_rounds = pl->rounds;
-    { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
-    const bool inside = opl + cnt < out_size, exact = !inside && opl < out_size;
-    uint32_t end_bp = ~0u;
-    if (inside) {
-      if (!lean_write(rd, tb, start, wlim, opl, lds_out, 0u, pl->valid == 3u)) sh->err = 1;
-    } else if (exact) {
-      if (!exact_write(rd, tb, start, wlim, opl, out_size, lds_out, &end_bp)) sh->err = 1;
-    }
-    if (end_bp != ~0u) sh->endbit = (unsigned long long)(end_bp - rel0);
-    __syncthreads();
-    { const long long t = clock64(); c_write += t - c_t0; c_t0 = t; }
-    cur = pl->endrel;
-    O0 = pl->tot;
-    if (pl->endrel == 0) cur = P1;   // no progress (cannot happen on a valid stream): stop, like the loop below
-    synced = true;
-  }
 
   while (cur < P1 && O0 < out_size) {
     synced = false;
@@ -1692,21 +1684,13 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     // (k_row_count_w: the first GROUP boundary at or past the nominal one), and a lane
     // owns exactly the tokens in front of its neighbour's first.
     uint32_t wlim = lim;
-    const uint32_t pre_valid = cur != 0 ? 0u : pl ? pl->valid : pre_off ? pre_off[kDecThreads + 2] : 0u;
+    const uint32_t pre_valid = cur != 0 ? 0u : pre_off ? pre_off[kDecThreads + 2] : 0u;
     const bool pre = pre_valid != 0, chain = pre_valid == 3u;
     if (pre) {
-      const uint32_t ns = pl ? pl->nstart : (tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u);
+      const uint32_t ns = tid + 1 < kDecThreads ? pre_start[tid + 1] : ~0u;
       wlim = ns < rel_end - rel0 ? rel0 + ns : rel_end;
     }
-    if (pre && pl) {
-      // The same record, loaded by the caller before its first barrier.
-      start = rel0 + pl->start;
-      off = pl->off;
-      cnt = pl->nxt - pl->off;
-      tot = pl->tot;
-      if (tid == last_active) endpos = rel0 + pl->endrel;
-      st_rounds += pl->rounds;
-    } else if (pre) {
+    if (pre) {
       // One chunk, fixpoint done by k_row_count at twice the occupancy.
       start = rel0 + pre_start[tid];
       off = pre_off[tid];
@@ -1716,10 +1700,10 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
       if (tid == last_active) endpos = rel0 + pre_off[kDecThreads + 1];
       st_rounds += pre_off[kDecThreads + 3];
     } else {
-      long long c_first = 0;
-      lean_fixpoint(rd, tb, sh, rel0, active, lim, &start, &endpos, &cnt, &st_rounds, false, lead_bits, &c_first);
-      c_r1 += c_first;
-      off = block_scan_u64(cnt, sh->sm64, &tot);
+      const ColdFix cf = cold_fixpoint(p, stream_size, 8ull * pay_off + cur, reinterpret_cast<const uint32_t *>(tb.grp),
+                                       tb.nd, sh, active, lim, start, lead_bits);
+      start = cf.start; endpos = cf.endpos; cnt = cf.cnt; st_rounds += cf.rounds;
+      c_r1 += cf.c_first; off = cf.off; tot = cf.tot;
     }
     { const long long t = clock64(); c_sync += t - c_t0; c_t0 = t; }
 
@@ -1768,6 +1752,64 @@ __device__ __forceinline__ int decode_stream(const uint8_t *p, uint32_t stream_s
     stats[6] = pay_len; stats[7] = out_size;
   }
   return bad;
+}
+
+// The row kernel's normal case (4096-pixel rows): ONE chunk whose lanes a count kernel has
+// recorded, the record in registers (PreLane).  Nothing of the sub-sequence grid is needed -- a
+// lane walks from its recorded start to its right neighbour's -- and where the chunk ends is in
+// the record as well: one barrier, behind the write pass.  Returns decode_stream's verdict, or
+// -1 (to every lane, before anything is written) when the record is not usable: the caller
+// then takes decode_stream_fused_cold.  The caller has set sh->err / sh->endbit in front of a
+// barrier of its own (decode_stream's PRIMED).
+__device__ __forceinline__ int decode_row_recorded(const uint8_t *p, uint32_t stream_size, uint32_t pay_off,
+                                                   uint32_t pay_len, uint32_t out_size, const GrpTables &tb,
+                                                   StreamShared *sh, uint8_t *lds_out, uint32_t *stats,
+                                                   const PreLane &pl) {
+  const int tid = threadIdx.x;
+  const unsigned long long P1 = 8ull * pay_len;
+  if (pl.valid == 0 || P1 == 0 || out_size == 0) return -1;
+  const long long c_t0 = clock64();
+  GReader rd;
+  const uint32_t rel0 = rd.attach(p, stream_size, 8ull * pay_off);
+  const uint32_t rel_end = rel0 + (uint32_t)P1;   // (a recorded row is one chunk: k_row_count)
+  const uint32_t start = rel0 + pl.start, opl = pl.off, cnt = pl.nxt - pl.off;
+  const uint32_t wlim = pl.nstart < (uint32_t)P1 ? rel0 + pl.nstart : rel_end;
+  const bool inside = opl + cnt < out_size, exact = !inside && opl < out_size;
+  uint32_t end_bp = ~0u;
+  if (inside) {
+    if (!lean_write(rd, tb, start, wlim, opl, lds_out, 0u, pl.valid == 3u)) sh->err = 1;
+  } else if (exact) {
+    if (!exact_write(rd, tb, start, wlim, opl, out_size, lds_out, &end_bp)) sh->err = 1;
+  }
+  if (end_bp != ~0u) sh->endbit = (unsigned long long)(end_bp - rel0);
+  __syncthreads();
+  const long long c_t1 = clock64();
+  // ---- accept / reject like UncompressStream (huffman_dec.cpp:361-417) ----
+  int bad = sh->err;
+  if (pl.tot < out_size) bad = 1;  // ran out of payload before the block was full
+  const unsigned long long E = sh->endbit;
+  // AtTheEnd (huffman_dec.cpp:140-145): inside the payload's last byte, or exactly at its end.
+  if (!bad && !(E <= P1 && E + 8 > P1 && E > 0)) bad = 1;
+  if (tid == 0 && stats) {
+    stats[0] = 1; stats[1] = pl.rounds;
+    stats[4] = 0; stats[5] = (uint32_t)((c_t1 - c_t0) >> 4);
+    stats[6] = pay_len; stats[7] = out_size;
+  }
+  return bad;
+}
+
+// A row without a usable record (several chunks, a count kernel that gave up): the general
+// decoder, OUT OF LINE -- inlined beside the fast path above it was most of the row kernel's
+// code and of its scalar register pressure.  Everything crosses the call by value.
+__device__ __attribute__((noinline)) int decode_stream_fused_cold(const uint8_t *p, uint32_t stream_size,
+                                                                  uint32_t pay_off, uint32_t pay_len, uint32_t out_size,
+                                                                  const uint32_t *grp_lds, const uint32_t *nd_lds,
+                                                                  StreamShared *sh, uint8_t *lds_out, uint32_t *stats,
+                                                                  uint32_t max_sub, uint32_t lead_bits) {
+  GrpTables tb;
+  tb.grp = reinterpret_cast<const uint2 *>(grp_lds); tb.gx = nullptr; tb.gy = nullptr; tb.nd = nd_lds;
+  return decode_stream<true, false, true>(p, stream_size, pay_off, pay_len, out_size, tb, sh, lds_out, nullptr, nullptr,
+                                          stats, max_sub, lead_bits);
 }
 
 // Tree nodes and decode tables of stream `strm` of frame f -> LDS.
@@ -2558,7 +2600,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
                                                      const uint8_t *low, const int16_t *s_unmap,
                                                      const uint8_t *s_shift, const uint32_t *s_shiftp,
                                                      int ycbcr, int u, int s, int v, uint8_t *img,
-                                                     const uint32_t *pre_lr = nullptr) {
+                                                     const uint32_t *pre_lr = nullptr, bool store_ok = true) {
   const int cols = COLS > 0 ? COLS : cols_rt;
   const int C = FULL4 ? 4 : g.C;
   const int v2 = min(v + 1, g.rows - 1);
@@ -2587,6 +2629,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
       if (cc == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) QA[i] = O[i];
+        __builtin_amdgcn_sched_barrier(0);
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) QB[i] = O[i];
@@ -2643,7 +2686,7 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
           px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
         }
       }
-      if (FULL4 || y < bh) {
+      if (store_ok && (FULL4 || y < bh)) {
         uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * C;
         if (FULL4 || (C == 4 && bw == 8)) {
           uint4 o0, o1;
@@ -2829,17 +2872,31 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
       st[2] = 0; st[3] = 0;   // atomicMax targets, see the end of the kernel
     }
-    if constexpr (COLS == 512)
-      return decode_stream<true, false, true>(
-          p, sizes[f], pre_off0, pre_len0, (uint32_t)g.row_block, tb, sh, sym0, nullptr, nullptr,
-          ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
-          nullptr, nullptr, &pl);
-    return decode_stream<true>(
-        p, sizes[f], ws.row_off[(size_t)f * g.rows + r], ws.row_len[(size_t)f * g.rows + r],
-        (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, nullptr, nullptr,
-        ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8, (uint32_t)g.max_sub, (uint32_t)g.lead_bits,
-        ws.lane_start + ((size_t)f * g.rows + r) * kDecThreads,
-        ws.lane_off + ((size_t)f * g.rows + r) * (kDecThreads + kRecHdr));
+    if constexpr (COLS == 512) {
+      uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
+      const int rc = decode_row_recorded(p, sizes[f], pre_off0, pre_len0, (uint32_t)g.row_block, tb, sh, sym0, st, pl);
+      if (rc >= 0) return rc;
+      return decode_stream_fused_cold(p, sizes[f], pre_off0, pre_len0, (uint32_t)g.row_block,
+                                      reinterpret_cast<const uint32_t *>(tb.grp), tb.nd, sh, sym0, st,
+                                      (uint32_t)g.max_sub, (uint32_t)g.lead_bits);
+    }
+    // Other widths: the same two paths, the lane's record read here (rows of a workgroup are
+    // decoded one after the other: the loads of row i + 1 cannot be in flight under the prologue).
+    const size_t ri = (size_t)f * g.rows + (size_t)r;
+    const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + kRecHdr);
+    PreLane q;
+    q.start = ps[tid]; q.off = po[tid]; q.nxt = po[tid + 1];
+    q.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
+    q.tot = po[kDecThreads]; q.endrel = po[kDecThreads + 1]; q.valid = po[kDecThreads + 2]; q.rounds = po[kDecThreads + 3];
+    const uint32_t off_r = ws.row_off[ri], len_r = ws.row_len[ri];
+    if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
+    __syncthreads();   // (also: the row before is done with sh)
+    uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
+    const int rc = decode_row_recorded(p, sizes[f], off_r, len_r, (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, st, q);
+    if (rc >= 0) return rc;
+    return decode_stream_fused_cold(p, sizes[f], off_r, len_r, (uint32_t)g.row_block,
+                                    reinterpret_cast<const uint32_t *>(tb.grp), tb.nd, sh, sym0 + (size_t)i * rb16, st,
+                                    (uint32_t)g.max_sub, (uint32_t)g.lead_bits);
   };
   int bad = 0;
   if constexpr (COLS == 512) {
@@ -2865,10 +2922,13 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
 #pragma unroll 1
   for (int it = tid; it < per_row * nr; it += kDecThreads) {
     const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
-    if (pair_tile(il) < cols)
-      transform_store_pair<COLS, COLS != 0>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
-                                              pair_tile(il), pair_half(il), rb + i, img,
-                                              COLS == 512 ? pre_lr : nullptr);
+    // A lane pair beyond the row's last tile (widths that are not a multiple of 256 pixels)
+    // transforms the last tile once more and stores nothing: no exec-masked region around
+    // the transform (with compile-time strides it cost 50 VGPR spills at 1920 pixels).
+    const bool in_row = pair_tile(il) < cols;
+    transform_store_pair<COLS, COLS != 0>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
+                                            in_row ? pair_tile(il) : cols - 1, pair_half(il), rb + i, img,
+                                            COLS == 512 ? pre_lr : nullptr, in_row);
   }
   HIMG_REGION_END("dec.transform");
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
@@ -3700,9 +3760,10 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
       if (b <= a) continue;
       prof_begin(prof, "k_dec_row_fused", stream);
       const bool whole4 = g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0;   // FULL4
+      static const bool no_cols = getenv("HIMG_NO_COLS") != nullptr;   // (A/B knob: the run-time-stride variant for every width but 4096)
       if (g.W == 4096 && whole4) HIMG_FUSED_LAUNCH(512, a, b);
-      else if (g.W == 2048 && whole4) HIMG_FUSED_LAUNCH(256, a, b);   // compile-time strides for the other
-      else if (g.W == 1920 && whole4) HIMG_FUSED_LAUNCH(240, a, b);   // BASELINE widths (config 3: 1920)
+      else if (g.W == 2048 && whole4 && !no_cols) HIMG_FUSED_LAUNCH(256, a, b);   // compile-time strides for the other
+      else if (g.W == 1920 && whole4 && !no_cols) HIMG_FUSED_LAUNCH(240, a, b);   // BASELINE widths (config 3: 1920)
       else if (whole4) HIMG_FUSED_LAUNCH(-1, a, b);
       else HIMG_FUSED_LAUNCH(0, a, b);
       prof_end(prof, stream);

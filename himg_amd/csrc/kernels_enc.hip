@@ -1967,12 +1967,13 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
   HIMG_LAUNCH_PAD((k_pix_fwd<Y, COLS, FULL>), grid, block, g, d_frames, ws.low, ws.plane_stride, ws.fres_sym, \
               ws.fres_stride, d_fmap_lut, pq, r0)
   const bool full = g.cols % 64 == 0;
+  static const bool no_cols = getenv("HIMG_NO_COLS") != nullptr;   // (A/B knob, see launch_decode)
   // Compile-time strides (immediate store offsets) for the widths of the BASELINE configurations:
   // 4096 (configs 2, 5), 2048, and 1920 (config 3: 240 tiles, the last wavefront of a row ragged).
   if (g.ycbcr) {
     if (g.cols == 512) HIMG_PIX(true, 512, true);
-    else if (g.cols == 256) HIMG_PIX(true, 256, true);
-    else if (g.cols == 240) HIMG_PIX(true, 240, false);
+    else if (g.cols == 256 && !no_cols) HIMG_PIX(true, 256, true);
+    else if (g.cols == 240 && !no_cols) HIMG_PIX(true, 240, false);
     else if (full) HIMG_PIX(true, 0, true);
     else HIMG_PIX(true, 0, false);
   }

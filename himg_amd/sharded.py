@@ -384,13 +384,43 @@ class ShardedDecoder:
         self.meta = torch.zeros(4 + 2 * self.rows, dtype=torch.int64, device=self.comm)
         self.d_packed = None      # grown on demand; the bytes behind the stream are zeroed per decode (_buffer)
         self.bytes_from_rank0 = 0
+        self._es = None           # the engine stream (_engine_stream)
+
+    def _engine_stream(self):
+        """The HIP stream the engine's kernels of a decode run on: a stream of this decoder's
+        own (or the one the caller gave), NOT torch's current stream -- the buffer fills, the
+        broadcasts and the point-to-point transfers are enqueued on the current stream
+        (ProcessGroupNCCL orders its own stream behind it), so a head phase launched there
+        would hold back the row index and every rank's row bytes until it has finished.
+        Ordering between the two is explicit: _fork() in front of a phase (the bytes it reads
+        have landed), _join() behind the last one (its results are read on the current
+        stream).  CPU tensors (the gloo stub tests): no streams, returns None."""
+        if self.dev.type != "cuda":
+            return None
+        if self._es is None:
+            import torch
+            self._es = (torch.cuda.ExternalStream(int(self.stream), device=self.dev) if self.stream is not None
+                        else torch.cuda.Stream(device=self.dev))
+        return self._es
 
     def _s(self):
-        """torch's current stream of the device unless one was given (see EngineBackend._s)."""
-        if self.stream is not None:
-            return self.stream
-        import torch
-        return torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
+        """Raw handle of the engine stream (0 without a GPU: the stub engines ignore it)."""
+        es = self._engine_stream()
+        return es.cuda_stream if es is not None else 0
+
+    def _fork(self):
+        """The engine stream waits for what torch's current stream holds now."""
+        es = self._engine_stream()
+        if es is not None:
+            import torch
+            es.wait_stream(torch.cuda.current_stream(self.dev))
+
+    def _join(self):
+        """torch's current stream waits for what the engine stream holds now."""
+        es = self._engine_stream()
+        if es is not None:
+            import torch
+            torch.cuda.current_stream(self.dev).wait_stream(es)
 
     def _buffer(self, size):
         """The stream buffer of this rank, with [size, size rounded up to 16, + 64) zeroed:
@@ -416,8 +446,10 @@ class ShardedDecoder:
                 buf = self._buffer(size)
                 buf[:size] = src
                 src = buf
+            self._fork()
             self.eng.decode_first_device(src, size, self.W, self.H, self.C, self.d_index[2 * self.rows:],
                                          self.d_status[1:], self._s())
+            self._join()
             host = torch.cat([self.d_index[2 * self.rows: 2 * self.rows + 1], self.d_status[1:2]]).cpu().numpy()
             first = int(np.int64(host[0]) & 0xFFFFFFFF)
             return size, first != 0, first, src, None       # (a damaged container: k_dec_parse's verdict, below)
@@ -465,7 +497,9 @@ class ShardedDecoder:
                 src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
                 buf[:size] = src.to(self.dev)
             self.d_status.zero_()
+            self._fork()
             self.eng.decode_rows_device(buf, size, self.W, self.H, self.C, 0, rows, self.d_rows, self.d_status, self._s())
+            self._join()
             ok = int(self.d_status[0].item()) == 0
             if not gather:
                 return ok, (self.d_rows if ok else None)
@@ -505,6 +539,10 @@ class ShardedDecoder:
             self.bytes_from_rank0 += (world - 1) * head16
         self.trace.append("head")
         self.d_status.zero_()
+        # The head of the stream is in `buf` once the current stream gets here: from this point
+        # the engine's kernels run on the engine stream, BESIDE what follows on the current one
+        # (the index broadcast, the rows' transfers).
+        self._fork()
         if rank == 0 and d_src is not None:
             self._walk_rank0(buf, size)      # (in front of the head phase: they run side by side)
             self.trace.append("walk_started")
@@ -534,6 +572,7 @@ class ShardedDecoder:
         if not bool(m[1]):
             if pipelined:
                 torch.cuda.synchronize(self.dev) if self.dev.type == "cuda" else None
+            self._join()
             return False, None          # a row header is damaged: every rank agrees
         off, ln = m[4:4 + rows], m[4 + rows:]
         ranges = slice_ranges(off, ln, first, size, self.parts)
@@ -550,6 +589,11 @@ class ShardedDecoder:
             else:
                 lo, hi = ranges[rank]
                 if hi > lo:
+                    # What lies right behind this rank's slice is a previous frame's: the row kernels
+                    # clamp their reads to the row, but the invariant is the one-process path's
+                    # (himg_multi.hip zeroes 64 bytes behind every slot's slice) -- no decode ever
+                    # sees bytes of another frame.
+                    buf[hi:min(hi + 64, buf.numel())].zero_()
                     t = buf[lo:hi] if self.comm == self.dev else torch.empty(hi - lo, dtype=torch.uint8, device=self.comm)
                     ops.append(dist.P2POp(dist.irecv, t, 0, group))
                     staged.append((lo, hi, t))
@@ -562,6 +606,9 @@ class ShardedDecoder:
         self.trace.append("rows_arrived")
         idx32 = torch.from_numpy(np.concatenate([off, ln]).astype(np.uint32).view(np.int32))
         self.d_index[: 2 * rows] = idx32.to(self.dev)
+        # The rows phase follows the head phase on the engine stream and must also see the row
+        # bytes and the index, which arrived on the current stream.
+        self._fork()
         if pipelined:
             self.eng.decode_rows_after_head_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
                                                    self.d_rows, self.d_status, self._s())
@@ -569,6 +616,7 @@ class ShardedDecoder:
             self.eng.decode_rows_indexed_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
                                                 self.d_rows, self.d_status, self._s())
         self.trace.append("rows_phase")
+        self._join()                         # status and pixel rows are read on the current stream
         bad = (self.d_status[:1] != 0).to(torch.int32).to(self.comm)    # (the transfer waits for the kernels)
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)

@@ -63,6 +63,10 @@ const char *himg_hip_last_error(const himg_hip_ctx *ctx);
 #define HIMG_OPT_COUNT_WAVE 2
 #define HIMG_OPT_EMIT_ROWS 3
 int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value);
+/* The option as the context holds it -- including what it took from the environment when it
+ * was created (HIMG_FIX_T2=1): a binding that mirrors an option (the row-sharded decoder's host
+ * index follows HIMG_OPT_FIX_T2) reads it here instead of tracking set_option calls. */
+int himg_hip_get_option(himg_hip_ctx *ctx, int option, int *value);
 
 /* Upper bound of the packed size of one frame (bytes), a multiple of 256.
  * Replaces HuffmanEnc::MaxCompressedSize (huffman_enc.cpp:242-244) plus the

@@ -64,3 +64,25 @@ def test_two_ranks_self_launched_rows():
     d = _run(["--gpus", "2", "--oversubscribe", "--mode", "rows", "--width", "1024", "--height", "1024",
               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_eight_ranks_self_launched_frames_and_rows():
+    """`python bench.py --gpus 8` as the driver's 8-GPU box will run it -- the launcher, eight
+    ranks, the seed split, the max-over-ranks reduction, then the `rows` leg (row-sharded encode
+    and decode of one frame over the same eight ranks) -- executed once before that box is its
+    first execution: all ranks share the one GPU here (--oversubscribe: gloo + CPU staging,
+    not a measurement), one frame per rank and a 2048 x 2048 frame for the rows leg (256 block
+    rows: sixteen-row shares for all eight ranks)."""
+    d = _run(["--gpus", "8", "--oversubscribe", "--batch", "1", "--steps", "1", "--warmup", "1",
+              "--no-cpu-baseline", "--no-extras", "--rows-size", "2048x2048", "--rows-timeout", "600"], timeout=1500)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 1
+    assert "8 rank" in d["config"]["parallelism"]
+    assert d["config"]["bit_exact"]          # every rank's frames checked against the golden table before timing
+    rows = d["rows"]
+    assert "error" not in rows, rows
+    assert "2048x2048" in rows["workload"].replace(" ", "")
+    assert rows["bit_exact"] == {"stream": "oracle", "pixels": "oracle"}, rows
+    assert rows["encode_ms"]["mean"] > 0 and rows["decode_ms"]["mean"] > 0

@@ -51,9 +51,8 @@ def test_reference_benchmark_decodes_a_himg_file(tmp_path):
     out = r.stdout
     assert "File size: %d" % packed.size in out
     assert "Unable to decode image." not in out
-    # 30 iterations, each through himg::Decoder::Decode (which prints the two chunk lines, T12)
+    # 30 iterations, each through himg::Decoder::Decode (src/benchmark.cpp:21,111-126)
     assert out.count("Iteration ") == 30 and "Iteration 30/30" in out
-    assert out.count("Full resolution data:") == 30
     vals = {}
     for key in ("Min", "Max", "Average"):
         m = re.search(r"^\s*%s: ([0-9.eE+-]+) ms$" % key, out, re.M)
