@@ -131,6 +131,11 @@ def build_unit_checks(verbose=False):
     """Device-side unit checks (tests/ run them on the GPU box): tile_plane_check
     compares the packed inverse transform with a scalar host model."""
     os.makedirs(BINDIR, exist_ok=True)
+    # (the HBM calibration kernels bench.py's extras and tools/calibrate_pmc.sh run)
+    cal_src = os.path.join(ROOT, "tools", "micro", "hbm_calib.hip")
+    cal_exe = os.path.join(ROOT, "tools", "micro", "hbm_calib")
+    if _stale(cal_exe, [cal_src]):
+        subprocess.run([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", cal_src, "-o", cal_exe], check=True)
     src = os.path.join(ROOT, "tools", "micro", "tile_plane_check.hip")
     exe = os.path.join(BINDIR, "tile_plane_check")
     deps = [src, os.path.join(CSRC, "kernels_dec.hip")] + [os.path.join(CSRC, h) for h in HEADERS]

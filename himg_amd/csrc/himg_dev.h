@@ -35,6 +35,8 @@ struct Geom {
   int lead_bits;             // decoder: lead-in before a lane's nominal start (lean_fixpoint; 0 = start blind)
   // Kernel variants (context options, see himg_hip.h HIMG_OPT_*): -1 = chosen by the launch size.
   int count_wave;            // decoder: k_row_count_w (a wavefront per row) instead of k_row_count
+  int wide_q;                // decoder, rows wider than the LDS: the host's estimate says a quarter sub-sequence of a row
+                             // (1/4096 of its payload) fits k_row_count_q's staging buffer -- that kernel counts
   int emit_rows;             // encoder: k_emit_t<8> (a wavefront per row) instead of a workgroup per row
   long long frame_bytes;     // W*H*stride
   long long fres_size;       // rows*row_block
@@ -171,8 +173,10 @@ constexpr int kWalkSegs = 4;   // single large frames: at most this many row ran
 struct DecStreams {
   hipStream_t side = nullptr;    // the serial row-header walk; k_row_count behind it (batches)
   hipStream_t side2 = nullptr;   // single frames: k_row_count of a row range while `side` walks the next one
+  hipStream_t side3 = nullptr;   // rows wider than the LDS: the entropy pass of a row range (k_row_window) while
+                                 // `side2` counts the next one and the caller's stream runs the LRES chain / transforms
   hipEvent_t ev_fork = nullptr;
-  hipEvent_t ev_walk[kWalkSegs] = {}, ev_cnt[kWalkSegs] = {};
+  hipEvent_t ev_walk[kWalkSegs] = {}, ev_cnt[kWalkSegs] = {}, ev_win[kWalkSegs] = {};
   int walk_segs = 0;             // HIMG_WALK_SEGS at context creation (0: by frame size)
 };
 

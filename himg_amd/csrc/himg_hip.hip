@@ -216,6 +216,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->lead_bits = 128;
   g->lres_serial = 0;
   g->count_wave = g->emit_rows = -1;
+  g->wide_q = 0;
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
   return true;
@@ -275,9 +276,11 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   bool ev_ok = true;
   for (int k = 0; k < kWalkSegs; ++k)
     ev_ok = ev_ok && hipEventCreateWithFlags(&ctx->dstr.ev_walk[k], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->dstr.ev_cnt[k], hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&ctx->dstr.ev_cnt[k], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ctx->dstr.ev_win[k], hipEventDisableTiming) == hipSuccess;
   if (!ev_ok || hipStreamCreateWithPriority(&ctx->dstr.side, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipStreamCreateWithPriority(&ctx->dstr.side2, hipStreamNonBlocking, prio_least) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->dstr.side3, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->dstr.ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->side_enc, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork_e, hipEventDisableTiming) != hipSuccess ||
@@ -297,9 +300,11 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
   for (int k = 0; k < kWalkSegs; ++k) {
     if (ctx->dstr.ev_walk[k]) hipEventDestroy(ctx->dstr.ev_walk[k]);
     if (ctx->dstr.ev_cnt[k]) hipEventDestroy(ctx->dstr.ev_cnt[k]);
+    if (ctx->dstr.ev_win[k]) hipEventDestroy(ctx->dstr.ev_win[k]);
   }
   if (ctx->dstr.side) hipStreamDestroy(ctx->dstr.side);
   if (ctx->dstr.side2) hipStreamDestroy(ctx->dstr.side2);
+  if (ctx->dstr.side3) hipStreamDestroy(ctx->dstr.side3);
   if (ctx->ev_fork_e) hipEventDestroy(ctx->ev_fork_e);
   if (ctx->ev_join_e) hipEventDestroy(ctx->ev_join_e);
   if (ctx->side_enc) hipStreamDestroy(ctx->side_enc);
@@ -481,6 +486,16 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   return HIMG_OK;
 }
 
+// Rows wider than the LDS: does a quarter sub-sequence (1 / 4096 of a row's payload) of the
+// LARGEST stream of the call fit k_row_count_q's staging buffer, with a margin for rows above
+// the frame's mean?  (An estimate from the stream's size; a row that exceeds it anyway is left
+// to k_dec_huff by the kernel itself.)
+static int wide_q_hint(const Geom &g, uint32_t max_packed_size) {
+  if (himg_dev::dec_rows_fit_lds(g) || g.rows < 1) return 0;
+  const double bits_per_quarter = 8.0 * (double)max_packed_size / ((double)g.rows * 4096.0);
+  return bits_per_quarter <= 272.0 ? 1 : 0;   // kStageSubBits = 320: rows up to 17 % above the mean
+}
+
 static int ensure_dec_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   DecWs &w = ctx->dec_ws;
   ctx->head.valid = false;   // whatever decode this is, it overwrites what a head phase left
@@ -629,6 +644,7 @@ extern "C" int himg_hip_decode_device(himg_hip_ctx *ctx, const void *d_packed, s
   g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   g.count_wave = ctx->count_wave;
+  { uint32_t mx = 0; for (int i = 0; i < batch; ++i) mx = h_sizes[i] > mx ? h_sizes[i] : mx; g.wide_q = wide_q_hint(g, mx); }
   if (g.rows + 1 > 65535 || batch * g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if ((in_stride & 3) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_out & 15))
     return fail(ctx, HIMG_ERR_ARG, "in_stride must be a multiple of 4; buffers 16-byte aligned");
@@ -663,6 +679,7 @@ extern "C" int himg_hip_decode_rows_device(himg_hip_ctx *ctx, const void *d_pack
   g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   g.count_wave = ctx->count_wave;
+  g.wide_q = wide_q_hint(g, packed_size);
   if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
   if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))
@@ -731,6 +748,7 @@ static int decode_rows_indexed(himg_hip_ctx *ctx, const void *d_packed, uint32_t
   g.lead_bits = ctx->lead_bits;
   g.lres_serial = ctx->lres_serial;
   g.count_wave = ctx->count_wave;
+  g.wide_q = wide_q_hint(g, packed_size);
   if (row0 < 0 || row1 < row0 || row1 > g.rows) return fail(ctx, HIMG_ERR_ARG, "bad row range");
   if (g.rows + 1 > 65535 || g.C > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
   if (((uintptr_t)d_packed & 15) || ((uintptr_t)d_out_rows & 15))

@@ -3439,6 +3439,249 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_row_count_w(Geom g, DecWs ws
 }
 
 // ---------------------------------------------------------------------------
+// k_row_count_q: the records of a WIDE row (one that goes through k_row_window: wider than the
+// LDS, e.g. the 16384-pixel rows of BASELINE config 4) -- FOUR per row-kernel lane, i.e. 4096
+// sub-sequences per row, at the cost per step of k_row_count_w: the payload staged in LDS in
+// blocks of 33 dwords and read on demand (15 VALU per step), where k_row_count<false> keeps a
+// register window over global memory (28+, and 100 us per 1-Mbit row whatever the number of
+// rows in flight: config-4 decode was bound by it).
+// One workgroup per row.  Wavefront w takes sub-sequences [256 w, 256 w + 256) as four phases
+// of 64 exactly like k_row_count_w takes a whole row (speculative lead-in, the chain inside a
+// phase by DPP, a phase's first lane exact from the phase before); what is speculative here is
+// where a WAVEFRONT's first sub-sequence starts.  The sixteen wavefronts then compare: wave w
+// is right if it started where wave w - 1 ended (wave 0 is exact, the rest by induction);
+// the lowest wave that is not walks its sub-sequences again from the exact position -- about
+// one row in ten has such a wave (a 128-bit lead-in misses in < 1 % of the boundaries).
+// Records: sub-sequence v is quarter v & 3 of lane v >> 2 in k_row_count<.., QTR>'s layout
+// (lane_start / lane_off for quarter 0, lane_q for the others), flag 3 (boundaries of the
+// write pass's chain of groups), and the index of the record that holds the first symbol of
+// every 128 KiB window.
+// ---------------------------------------------------------------------------
+constexpr int kQPhases = 4;   // phases of 64 sub-sequences per wavefront: 16 x 4 x 64 = 4 x kDecThreads
+// Where record q = 4 * lane + quarter lives (k_row_count<.., QTR>'s layout, k_row_window's rec_pos / rec_off).
+__device__ __forceinline__ uint32_t *qrec_pos(uint32_t *l_start, uint32_t *l_q, uint32_t q) {
+  const uint32_t t = q >> 2, k = q & 3u;
+  return k == 0 ? l_start + t : l_q + (k - 1u) * kDecThreads + t;
+}
+__device__ __forceinline__ uint32_t *qrec_off(uint32_t *l_off, uint32_t *l_q, uint32_t q) {
+  const uint32_t t = q >> 2, k = q & 3u;
+  return k == 0 ? l_off + t : l_q + (2u + k) * kDecThreads + t;
+}
+__global__ __launch_bounds__(kDecThreads, 8) void k_row_count_q(Geom g, DecWs ws, const uint8_t *packed,
+                                                               size_t in_stride, const uint32_t *sizes, int r0) {
+  __shared__ __attribute__((aligned(16))) uint32_t gyx[2 * kTabEntries];
+  __shared__ uint32_t nd[kMaxNodes + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stage[kCountRowsW * kStageAlloc];
+  __shared__ int s_flag;
+  __shared__ uint32_t s_ws[kCountRowsW], s_we[kCountRowsW], s_wc[kCountRowsW], s_wl[kCountRowsW], s_bad;
+  uint32_t *gy = gyx, *gx = gyx + kTabEntries;
+  const int f = blockIdx.y, r = r0 + (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  DecFrame *df = ws.frames + f;
+  if (tid == 0) {
+    const int w = df->parse_status == 0 ? df->walk_status : 0;   // (k_row_count's rule)
+    if (w && blockIdx.x == 0) atomicMax(&df->status, w);
+    s_flag = df->status | w;
+  }
+  __syncthreads();
+  const int failed = s_flag;
+  const size_t ri = (size_t)f * g.rows + (size_t)r;
+  uint32_t *l_start = ws.lane_start + ri * kDecThreads;
+  uint32_t *l_off = ws.lane_off + ri * (kDecThreads + kRecHdr);
+  uint32_t *l_q = ws.lane_q + ri * (6 * kDecThreads);
+  if (tid == 0) l_off[kDecThreads + 2] = 0;                                   // not usable until proven otherwise
+  if (tid >= kRecWin && tid < kRecHdr) l_off[kDecThreads + tid] = ~0u;        // no window index yet
+  const uint32_t pay_off = ws.row_off[ri], pay_len = ws.row_len[ri];
+  const unsigned long long rem64 = 8ull * pay_len;
+  uint32_t sb1 = (uint32_t)((rem64 + kDecThreads - 1) / kDecThreads);   // the row kernels' sub-sequence: one chunk?
+  sb1 = (sb1 + 31u) & ~31u;
+  sb1 = sb1 < kMinSubBits ? kMinSubBits : sb1;
+  constexpr uint32_t NSUB = 4u * (uint32_t)kDecThreads;
+  uint32_t sb = (uint32_t)((rem64 + NSUB - 1u) / NSUB);
+  sb = (sb + 31u) & ~31u;
+  sb = sb < kMinSubBits ? kMinSubBits : sb;
+  // Several chunks or nothing to do (k_row_count's rule), or sub-sequences beyond the staging
+  // buffer (more than ~2.4 bits per symbol of a 16384-pixel row): the record stays unusable
+  // and k_dec_huff decodes the row on its own.
+  if (failed || sb1 > (uint32_t)g.max_sub || rem64 == 0 || g.row_block >= (1 << 22) || sb > kStageSubBits) return;
+  {   // the write pass's step words next to the long-code descriptors (k_row_count_w)
+    const uint32_t *nodes = ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1);
+    const int nn = df->s[1].num_nodes;
+    for (int k = tid; k < nn; k += kDecThreads) nd[k] = nodes[k];
+    const uint4 *gg = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits));
+    for (int k = tid; k < (1 << kLutBits) / 2; k += kDecThreads) {
+      const uint4 q = gg[k];
+      reinterpret_cast<uint2 *>(gx)[k] = make_uint2(q.x, q.z);
+      reinterpret_cast<uint2 *>(gy)[k] = make_uint2(q.y, q.w);
+    }
+    const uint4 *gs = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries);
+    for (int k = tid; k < kSubEntries / 2; k += kDecThreads) {
+      const uint4 q = gs[k];
+      reinterpret_cast<uint2 *>(gx + (1 << kLutBits))[k] = make_uint2(q.x, q.z);
+      reinterpret_cast<uint2 *>(gy + (1 << kLutBits))[k] = make_uint2(q.y, q.w);
+    }
+  }
+  __syncthreads();
+  GrpTables tb;
+  tb.grp = nullptr; tb.gx = gx; tb.gy = gy; tb.nd = nd;
+  const uint32_t rem = (uint32_t)rem64;
+  GReader rd;
+  const uint32_t rel0 = rd.attach(packed + (size_t)f * in_stride, sizes[f], 8ull * pay_off);
+  const uint32_t rel_end = rel0 + rem;
+  const uint32_t lead = (uint32_t)g.lead_bits;
+  uint32_t *stage = s_stage + wave * kStageAlloc;
+  LdsBits bits;
+  bits.base = lds_addr(stage);
+  uint32_t w_start = rel_end, w_end = rel_end, w_last = rel_end, w_cnt = 0, rounds = 0;
+  // All four phases of this wavefront.  first0 / exact0: where its first sub-sequence starts,
+  // exactly -- or its nominal start, the real one to be found by a lead-in like any lane's.
+  // The records go out as they are found, offsets relative to the wavefront's first symbol.
+  auto run_wave = [&](uint32_t first0, bool exact0) {
+    uint32_t first = first0, base = 0;
+    bool have_start = false;
+#pragma unroll 1
+    for (int j = 0; j < kQPhases; ++j) {
+      const uint32_t v = 256u * (uint32_t)wave + 64u * (uint32_t)j + (uint32_t)lane;
+      const uint32_t nb0 = v ? rel0 + v * sb : rel0;              // nominal range of sub-sequence v
+      uint32_t nlim = rel0 + (v + 1u) * sb;
+      if (nlim > rel_end) nlim = rel_end;
+      const bool active = nb0 < rel_end;
+      const uint32_t pb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb0);
+      if (pb0 >= rel_end) {   // a phase beyond the payload: its sub-sequences own nothing
+        *qrec_pos(l_start, l_q, v) = rem;
+        *qrec_off(l_off, l_q, v) = base;
+        continue;
+      }
+      const bool spec0 = j == 0 && !exact0;   // the phase's first lane looks for its start as well
+      uint32_t sfrom = pb0;
+      if (spec0) sfrom = pb0 - rel0 > lead ? pb0 - lead : rel0;
+      if (first < sfrom) sfrom = first;         // (an exact start in front of the nominal one: the group before ran long)
+      const uint32_t w0 = sfrom >> 5;
+      const uint32_t shift = 32u * w0;          // positions below: relative to the first staged dword
+      wave_lds_sync();   // the walks of the phase before are done with the buffer
+      for (uint32_t k = (uint32_t)lane; 4u * k < kStageWords; k += 64u) {
+        const uint32_t w = w0 + 4u * k;
+        uint4 x;
+        if (w + 3u <= rd.jmax) {
+          const PackedU4 u = *reinterpret_cast<const PackedU4 *>(rd.w + w);
+          x.x = u.x; x.y = u.y; x.z = u.z; x.w = u.w;
+        } else {
+          x.x = rd.ld(w); x.y = rd.ld(w + 1u); x.z = rd.ld(w + 2u); x.w = rd.ld(w + 3u);
+        }
+        uint32_t *d = stage + 4u * k + (k >> 3);   // blocks of 33 (LdsBits)
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        if ((k & 7u) == 0u && k) d[-1] = x.x;
+      }
+      wave_lds_sync();
+      const uint32_t b0 = nb0 - shift, lim = nlim - shift, lo0 = rel0 - shift, fst = first - shift;
+      uint32_t start = active ? b0 : rel_end - shift;
+      if (lane == 0 && active && !spec0) start = fst;
+      if ((lane > 0 || spec0) && active && lead) {   // (lo0 may lie below zero in this frame of reference: differences only)
+        uint32_t from = start - lo0 > lead ? start - lead : lo0;
+        if (from < sfrom - shift) from = sfrom - shift;   // (not in front of what is staged)
+        uint32_t guess, none;
+        grp_count_lds(bits, tb, from, start, &guess, &none);
+        start = guess;
+      }
+      uint32_t endpos = start, cnt = 0;
+      bool dirty = active;
+      uint32_t T = (active ? b0 : rel_end - shift) + kJoinBits;
+      if (T > lim || T < b0) T = lim;
+      uint32_t posT = ~0u, cT = 0;
+      for (;;) {
+        if (dirty) {
+          uint32_t p1, c1;
+          grp_count_lds(bits, tb, start, T, &p1, &c1);
+          if (p1 == posT) {
+            cnt = c1 + (cnt - cT);
+          } else {
+            uint32_t c2;
+            grp_count_lds(bits, tb, p1, lim, &endpos, &c2);
+            cnt = c1 + c2;
+          }
+          posT = p1;
+          cT = c1;
+        }
+        // The chain: a lane starts where its left neighbour ended; the first lane of a
+        // speculative phase keeps the start its lead-in found.
+        const uint32_t lane0 = spec0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)start) : fst;
+        const uint32_t ns = wave_shr1_dpp(lane0, endpos);
+        dirty = active && ns != start;
+        if (active) start = ns;
+        ++rounds;
+        if (!__any(dirty ? 1 : 0)) break;
+      }
+      const uint32_t c = min(cnt, 0x3fffffu);
+      const uint32_t incl = wave_scan_add_dpp(c);
+      *qrec_pos(l_start, l_q, v) = active ? start + shift - rel0 : rem;
+      *qrec_off(l_off, l_q, v) = base + incl - c;
+      if (!have_start) { w_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)(start + shift)); have_start = true; }
+      base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      first = (uint32_t)__builtin_amdgcn_readlane((int)(active ? endpos + shift : rel_end), 63);
+      // where the chain of the row's LAST sub-sequence ends (the header's `endrel`)
+      const int la = 63 - __clzll((long long)__ballot(active ? 1 : 0));
+      w_last = (uint32_t)__builtin_amdgcn_readlane((int)(endpos + shift), la);
+    }
+    w_end = first;
+    w_cnt = base;
+    if (!have_start) w_start = rel_end;
+  };
+  const uint32_t nom0 = wave ? rel0 + 256u * (uint32_t)wave * sb : rel0;   // this wavefront's first nominal start
+  const bool w_active = nom0 < rel_end;
+  run_wave(nom0, wave == 0);
+  // ---- the wavefronts agree on the chain ----
+#pragma unroll 1
+  for (int it = 0; it < kCountRowsW + 1; ++it) {
+    if (lane == 0) { s_ws[wave] = w_start; s_we[wave] = w_end; s_wc[wave] = w_cnt; s_wl[wave] = w_last; }
+    if (tid == 0) s_bad = 0xffffu;
+    __syncthreads();
+    // (a wavefront beyond the payload has nothing to be wrong about)
+    const bool ok = wave == 0 || !w_active || s_ws[wave] == s_we[wave - 1];
+    if (!ok && lane == 0) atomicMin(&s_bad, (uint32_t)wave);
+    __syncthreads();
+    const uint32_t bad = s_bad;
+    if (bad == 0xffffu) break;
+    if ((uint32_t)wave == bad) run_wave(s_we[wave - 1], true);   // everything in front of it is final: again, exactly
+    __syncthreads();   // (s_ws / s_we / s_bad are rewritten at the top)
+  }
+  // ---- the offsets become the row's; the record that holds the first symbol of every window ----
+  uint32_t wbase = 0, total = 0, endrel = 0;
+  for (int w = 0; w < kCountRowsW; ++w) {
+    const uint32_t c = s_wc[w];
+    if (w < wave) wbase += c;
+    total += c;
+    if (w == 0 || rel0 + 256u * (uint32_t)w * sb < rel_end) endrel = s_wl[w] - rel0;
+  }
+  wave_lds_sync();   // (this wavefront's own stores above, before it reads them back)
+  __threadfence_block();
+  const uint32_t out_size = (uint32_t)g.row_block;
+#pragma unroll 1
+  for (int j = 0; j < kQPhases; ++j) {
+    const uint32_t v = 256u * (uint32_t)wave + 64u * (uint32_t)j + (uint32_t)lane;
+    uint32_t *po = qrec_off(l_off, l_q, v);
+    // (read back what this wavefront stored above: device-scope loads, past the vector L1)
+    const uint32_t rel = __hip_atomic_load(po, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the next record of this wavefront closes the range (its last one: the wavefront's total)
+    const uint32_t nrel = (j == kQPhases - 1 && lane == 63)
+                              ? w_cnt : __hip_atomic_load(qrec_off(l_off, l_q, v + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t off = wbase + rel, c = nrel - rel;
+    *po = off;
+    if (c) {
+      for (uint32_t w = (off + kRowWindow - 1u) / kRowWindow; w * kRowWindow < off + c && w * kRowWindow < out_size &&
+                                                                 w < (uint32_t)(kRecHdr - kRecWin); ++w)
+        if (w) l_off[kDecThreads + kRecWin + w] = v;
+    }
+    wave_lds_sync();   // (lane l + 1 has read record v + 1's relative offset before lane l + 1 rewrites it -- see below)
+  }
+  if (tid == 0) {
+    l_off[kDecThreads] = total;
+    l_off[kDecThreads + 1] = endrel;
+    l_off[kDecThreads + 3] = rounds;
+    l_off[kDecThreads + 4] = 1;   // four records per lane
+    l_off[kDecThreads + 2] = 3;   // boundaries of the write pass's chain of groups (no fence: the consumer is a later kernel)
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_row_window: write pass of rows whose symbols do not fit the LDS (wider than 4224
 // pixels), one workgroup per 128 KiB WINDOW of a row's symbols (a channel plane of a
 // 16384-pixel row).  Every lane looks at its own record from k_row_count and decodes its
@@ -3644,7 +3887,8 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
   // streams costs tens of microseconds, so frames of fewer than 1024 block rows (4096^2:
   // 0.40 ms either way, 1024^2: 0.23 -> 0.30 ms) stay in one piece.
   const int seg_env = ds ? ds->walk_segs : 0;
-  const int seg_want = seg_env ? (seg_env < 1 ? 1 : seg_env > kWalkSegs ? kWalkSegs : seg_env) : (nrows >= 1024 ? 2 : 1);
+  const int seg_want = seg_env ? (seg_env < 1 ? 1 : seg_env > kWalkSegs ? kWalkSegs : seg_env)
+                               : (nrows >= 1024 ? (wps ? 2 : kWalkSegs) : 1);   // (rows through windows: three kernels per range in a pipeline)
   const int nseg = (ds && batch == 1 && !d_row_index && r0 == 0 && r1 == g.rows && nrows >= 16 * kWalkSegs) ? seg_want : 1;
   hipStream_t side = ds ? ds->side : nullptr;
   hipStream_t cnt_stream = !ds ? stream : nseg > 1 ? ds->side2 : ds->side;
@@ -3694,9 +3938,36 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     else if (wps)
       hipLaunchKernelGGL(k_row_count<true>, dim3((b - a + rpc - 1) / rpc, batch), dim3(kDecThreads), 0, s, g, ws,
                          d_packed, in_stride, d_sizes, a, b, rpc);
+    else if (ws.lane_q && g.wide_q && g.count_wave < 0 && (g.row_block % 16) == 0)
+      // Rows that go through windows, at a bit rate the staged reader takes (the host's estimate
+      // from the stream's size; a row beyond it is left to k_dec_huff): four records per lane
+      // from 4096 sub-sequences.  HIMG_OPT_COUNT_WAVE = 0 / 1 force the other two forms.
+      hipLaunchKernelGGL(k_row_count_q, dim3(b - a, batch), dim3(kDecThreads), 0, s, g, ws, d_packed, in_stride, d_sizes, a);
     else
       hipLaunchKernelGGL(k_row_count<false>, dim3((b - a + rpc - 1) / rpc, batch), dim3(kDecThreads), 0, s, g, ws,
                          d_packed, in_stride, d_sizes, a, b, rpc);
+    prof_end(prof, s);
+  };
+  // The entropy pass of rows that do not fit the LDS, rows [a, b): every 128 KiB window of a
+  // row's symbols is assembled in LDS (k_row_window) and stored whole; rows whose block is not a
+  // multiple of 16 bytes (ragged widths of 1-3 channel frames) and rows without a usable
+  // record take k_dec_huff's 32 KiB windows (which skips the others).
+  const bool window = (g.row_block % 16) == 0;
+  auto window_pass = [&](hipStream_t s, int a, int b) {
+    if (b <= a) return;
+    if (window) {
+      const uint32_t lds = (uint32_t)sizeof(LdsTables) + 64u + kRowWindow + 2u * kWinGuard + 16u;
+      const unsigned nwin = (unsigned)(((uint32_t)g.row_block + kRowWindow - 1u) / kRowWindow);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_window),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      prof_begin(prof, "k_row_window", s);
+      hipLaunchKernelGGL(k_row_window, dim3(nwin, b - a, batch), dim3(kDecThreads), lds, s, g, ws, d_packed,
+                         in_stride, d_sizes, a);
+      prof_end(prof, s);
+    }
+    prof_begin(prof, "k_dec_huff", s);
+    hipLaunchKernelGGL(k_dec_huff, dim3(b - a, batch), dim3(kDecThreads), 0, s, g, ws, d_packed, in_stride,
+                       d_sizes, 1 + a, 1, window ? 2 : 1);
     prof_end(prof, s);
   };
   if (!do_rows) {
@@ -3708,7 +3979,21 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     for (int k = 0; k < nseg; ++k) {
       if (cnt_stream != side) (void)hipStreamWaitEvent(cnt_stream, ds->ev_walk[k], 0);
       row_count(cnt_stream, seg_lo(k), seg_lo(k + 1));
+      // Rows that go through HBM: their entropy pass (k_row_window, k_dec_huff) needs the
+      // stream's tables and the counts, NOT the low-res plane -- it follows the counts on
+      // their stream, beside the LRES chain on the caller's, and only the transform waits for
+      // both.  (Behind the LRES chain on the caller's stream these kernels were the critical
+      // path of a single large frame: LRES chain 1.1 ms, then 1.8 ms of window / transform
+      // launches one after the other -- 16384^2: 2.88 -> see DESIGN.md.)
       (void)hipEventRecord(ds->ev_cnt[k], cnt_stream);
+      if (!wps) {
+        // ... on a stream of its own where there are several row ranges: the counts of the next
+        // range start when its walk is done, not behind this range's windows.
+        hipStream_t ws_ = (nseg > 1 && ds->side3) ? ds->side3 : cnt_stream;
+        if (ws_ != cnt_stream) (void)hipStreamWaitEvent(ws_, ds->ev_cnt[k], 0);
+        window_pass(ws_, seg_lo(k), seg_lo(k + 1));
+        (void)hipEventRecord(ds->ev_win[k], ws_);
+      }
     }
   } else if (d_row_index) {
     HIMG_LAUNCH(k_dec_set_index, dim3(1), dim3(256), g, ws, d_row_index, d_sizes, r0, r1);
@@ -3770,29 +4055,13 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     }
 #undef HIMG_FUSED_LAUNCH
   } else {
-    // Symbols through HBM: every 128 KiB window of a row's symbols is assembled in LDS
-    // (k_row_window) and stored whole; rows whose block is not a multiple of 16 bytes
-    // (ragged widths of 1-3 channel frames) take k_dec_huff's 32 KiB windows.
-    const bool window = (g.row_block % 16) == 0;
+    // Symbols through HBM: the entropy pass (window_pass above; with side streams it ran on the
+    // counts' stream already), then the transform, which needs the low-res plane as well.
     for (int k = 0; k < nseg; ++k) {
       const int a = seg_lo(k), b = seg_lo(k + 1);
-      if (ds) (void)hipStreamWaitEvent(stream, ds->ev_cnt[k], 0);
-      else row_count(stream, a, b);
+      if (ds) (void)hipStreamWaitEvent(stream, ds->ev_win[k], 0);
+      else { row_count(stream, a, b); window_pass(stream, a, b); }
       if (b <= a) continue;
-      // Rows without a usable fixpoint (several chunks) take the window path of
-      // k_dec_huff, which skips the others.
-      if (window) {
-        const uint32_t lds = (uint32_t)sizeof(LdsTables) + 64u + kRowWindow + 2u * kWinGuard + 16u;
-        const unsigned nwin = (unsigned)(((uint32_t)g.row_block + kRowWindow - 1u) / kRowWindow);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_window),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        prof_begin(prof, "k_row_window", stream);
-        hipLaunchKernelGGL(k_row_window, dim3(nwin, b - a, batch), dim3(kDecThreads), lds, stream, g, ws, d_packed,
-                           in_stride, d_sizes, a);
-        prof_end(prof, stream);
-      }
-      HIMG_LAUNCH(k_dec_huff, dim3(b - a, batch), dim3(kDecThreads), g, ws, d_packed, in_stride,
-                  d_sizes, 1 + a, 1, window ? 2 : 1);
       if (g.C == 4 && (g.W & 7) == 0 && (g.H & 7) == 0) HIMG_LAUNCH(k_tile_inv<true>, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
       else HIMG_LAUNCH(k_tile_inv<false>, dim3(gx, b - a, batch), dim3(256), g, ws, d_out, a);
     }

@@ -337,6 +337,15 @@ def slice_ranges(offsets, lengths, rows_first, size, parts, margin=16):
     return out
 
 
+def _readable_bytes(t):
+    """Bytes of `t`'s storage from its first element on (the engine reads the stream in whole
+    dwords: a view of a padded buffer can be decoded in place, an exact-size tensor cannot)."""
+    try:
+        return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+    except (AttributeError, RuntimeError):
+        return t.numel() * t.element_size()
+
+
 class ShardedDecoder:
     """Row-sharded decode of frames of one geometry (reference
     decoder.cpp:292-326 hands block rows to worker threads the same way).
@@ -490,16 +499,18 @@ class ShardedDecoder:
             # runs beside the container parse instead of in front of it.
             size = int(packed.numel() if torch.is_tensor(packed) else len(packed))
             if torch.is_tensor(packed) and packed.device == self.dev and packed.data_ptr() % 16 == 0 \
-                    and packed.numel() % 4 == 0:
-                buf = packed
+                    and _readable_bytes(packed) >= (size + 3) // 4 * 4:
+                buf = packed             # in place: the engine reads whole dwords, the storage holds them
             else:
                 buf = self._buffer(size)
                 src = packed if torch.is_tensor(packed) else torch.from_numpy(np.ascontiguousarray(packed, np.uint8))
                 buf[:size] = src.to(self.dev)
             self.d_status.zero_()
-            self._fork()
-            self.eng.decode_rows_device(buf, size, self.W, self.H, self.C, 0, rows, self.d_rows, self.d_status, self._s())
-            self._join()
+            # (one rank: nothing travels while the engine works, so the engine stays on the caller's
+            # stream -- torch's current one unless one was given -- like every torch operation around it)
+            s1 = self.stream if self.stream is not None else (
+                torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0)
+            self.eng.decode_rows_device(buf, size, self.W, self.H, self.C, 0, rows, self.d_rows, self.d_status, s1)
             ok = int(self.d_status[0].item()) == 0
             if not gather:
                 return ok, (self.d_rows if ok else None)

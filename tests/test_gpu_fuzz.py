@@ -114,3 +114,62 @@ def test_kernel_forms_give_identical_results(emit_rows, count_wave):
             with pytest.raises(himg_amd.HimgError):
                 eng.decode(want)
     eng.close()
+
+
+WIDE_BASES = [("randtile", 4400, 40, 50), ("rand", 4608, 24, 30), ("randtile", 8192, 64, 50)]
+
+
+def test_fuzz_wide_rows_quarter_count_kernel():
+    """Rows wider than the LDS with the DEFAULT choice of the count kernel: k_row_count_q (4096
+    sub-sequences per row, staged reader, sixteen wavefronts that agree on the chain afterwards)
+    -- the forced forms above are the other two kernels.  Hostile streams must get the oracle's
+    verdict and pixels here as well."""
+    eng = himg_amd.Engine(0)
+    assert eng.get_option("count_wave") == -1
+    rng = np.random.default_rng(77)
+    accepted = rejected = 0
+    for kind, w, h, q in WIDE_BASES:
+        img = himg_amd.synth(kind, 5, w, h)
+        good = ol.oracle_encode(img, q, True)
+        rc, pix = ol.oracle_decode(good)
+        assert rc == 0
+        assert np.array_equal(eng.decode(good).ravel(), pix.ravel()), (kind, w, h, q)
+        ch = _chunks(good)
+        for t in range(120):
+            bad = _mutate(good, ch, rng, t)
+            rc, pix = ol.oracle_decode(bad)
+            try:
+                got = eng.decode(bad)
+            except himg_amd.HimgError:
+                got = None
+            assert (rc == 0) == (got is not None), "%s %dx%d q%d mutation %d: oracle rc %d, gpu %s" % (
+                kind, w, h, q, t, rc, "accepted" if got is not None else "rejected")
+            if rc == 0:
+                assert np.array_equal(got.ravel(), pix.ravel()), "%s %dx%d q%d mutation %d: pixels differ" % (kind, w, h, q, t)
+            accepted += rc == 0
+            rejected += rc != 0
+    eng.close()
+    assert accepted > 30 and rejected > 30
+
+
+def test_wide_rows_beyond_the_staged_reader_fall_back():
+    """A frame whose MEAN bit rate lets the host pick k_row_count_q while some of its rows do
+    not fit that kernel's staging buffer (a smooth gradient above, random tiles at q = 90 in the
+    last two block rows): the kernel leaves those rows' records unusable and the general
+    decoder takes them -- same pixels as the oracle.  (Full-swing noise at that quality is no
+    test input: the reference encoder itself overruns its output buffer on it.)"""
+    w, h = 16384, 128
+    img = himg_amd.synth("grad", 2, w, h).copy()
+    img[112:] = himg_amd.synth("randtile", 3, w, h)[112:]
+    good = ol.oracle_encode(img, 90, True)
+    rc, pix = ol.oracle_decode(good)
+    assert rc == 0
+    # the premise: the mean says "staged reader" (<= 272 bits per quarter sub-sequence), the
+    # busy rows do not fit it (> 320)
+    rows = h // 8
+    assert 8.0 * good.size / (rows * 4096.0) <= 272.0, good.size
+    _, _, _, off, ln, first = himg_amd.index_host(good)
+    assert (np.asarray(ln[-2:]) * 8 / 4096.0 > 320).all(), ln[-2:]
+    eng = himg_amd.Engine(0)
+    assert np.array_equal(eng.decode(good).ravel(), pix.ravel())
+    eng.close()

@@ -25,14 +25,45 @@ def kname(full):
             return n[:i]
     return n
 
-# Kernels that read their input as 16-byte-per-lane coalesced streams (matched on the
-# name in front of the template arguments; k_emit_t<8> / k_emit_t<1> are "k_emit_t").
-STREAMING = {"k_lowres_avg", "k_pix_fwd", "k_tok_hist", "k_emit", "k_emit_t", "k_emit_m", "k_lres_summary",
-             "k_place_fres", "k_tile_inv"}
+# FETCH_SIZE is not bytes: on gfx950 it reads 0.500 of the bytes of a 16-byte-per-lane coalesced
+# stream and 0.547 of a bit reader's (a dword per lane at a lane stride of ~36 bytes, the row
+# kernels' payload reads); WRITE_SIZE reads 1.000 either way.  Both factors are MEASURED on known
+# byte counts by tools/micro/hbm_calib under rocprofv3 (tools/calibrate_pmc.sh ->
+# profiles/r05_calibration.json, read below; the defaults are that file's values).  Every kernel of
+# the engine is one of the two patterns (matched on the name in front of the template arguments);
+# anything else is reported raw with both corrections beside it.
+_DEFAULT_FACTORS = {"stream16": {"fetch": 0.5000, "write": 1.0}, "rowlike": {"fetch": 0.5474, "write": 1.0}}
+
+
+def _load_factors():
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "..", "profiles", "r05_calibration.json")
+    try:
+        f = json.load(open(path))["factors"]
+        return {k: {"fetch": float(f[k]["fetch"]), "write": float(f[k]["write"])} for k in ("stream16", "rowlike")}
+    except (OSError, KeyError, TypeError, ValueError):
+        return _DEFAULT_FACTORS
+
+
+FACTORS = _load_factors()
+PATTERN = {
+    # 16 bytes per lane, coalesced
+    "k_lowres_avg": "stream16", "k_pix_fwd": "stream16", "k_tok_hist": "stream16", "k_emit": "stream16",
+    "k_emit_t": "stream16", "k_emit_m": "stream16", "k_lres_summary": "stream16", "k_place_fres": "stream16",
+    "k_tile_inv": "stream16", "k_tile_fwd": "stream16", "k_cal_read": "stream16", "k_cal_copy": "stream16",
+    # bit readers: a dword per lane along the lane's own sub-sequence of the payload
+    "k_dec_row_fused": "rowlike", "k_row_count": "rowlike", "k_row_count_w": "rowlike", "k_row_count_q": "rowlike",
+    "k_row_window": "rowlike", "k_dec_huff": "rowlike", "k_lres_spec": "rowlike", "k_lres_fix": "rowlike",
+    "k_lres_write": "rowlike", "k_cal_rowlike": "rowlike",
+}
+
+
+def pattern_of(key):
+    return PATTERN.get(key.split("<")[0].split("[")[0].strip().lstrip("("))
 
 
 def is_streaming(key):
-    return key.split("<")[0].split("[")[0].strip() in STREAMING
+    return pattern_of(key) == "stream16"
 
 # A kernel launched with several grid sizes per step (k_tok_hist: the LRES spans on the
 # side stream, then the FRES rows) is reported per grid: the largest under the kernel's
@@ -74,16 +105,14 @@ for k in sorted(acc, key=lambda k: -dur[k][0]):
         continue
     row = {c: v[0] / max(v[1], 1) for c, v in acc[k].items()}
     row["dur_us"] = dur[k][0] / max(dur[k][1], 1)
-    # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads HALF the bytes of wide coalesced
-    # streaming reads (16 B per lane); other access widths are uncalibrated.  So the x2
-    # is applied only to the kernels whose reads are 16-byte-per-lane streams
-    # (STREAMING below); for the others the raw figure is reported, with the x2 value
-    # beside it as an upper bound.
+    # FETCH_SIZE -> bytes by the measured factor of the kernel's access pattern (see FACTORS).
     if "FETCH_SIZE" in row:
         raw = row["FETCH_SIZE"] * 1024 / 1e6
+        pat = pattern_of(k)
         row["hbm_read_MB_raw"] = raw
         row["hbm_read_MB_x2"] = 2 * raw
-        row["hbm_read_MB_corrected"] = 2 * raw if is_streaming(k) else raw
+        row["hbm_read_MB_corrected"] = raw / FACTORS[pat]["fetch"] if pat else raw
+        row["fetch_pattern"] = {"stream16": 16, "rowlike": 4}.get(pat, 0)   # bytes per lane of the calibrated pattern (0: uncalibrated, raw)
     if "WRITE_SIZE" in row:
         row["hbm_write_MB"] = row["WRITE_SIZE"] * 1024 / 1e6
     out[k] = row
