@@ -92,6 +92,8 @@ def lib():
     L.himg_hip_decode_first_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp]
     L.himg_hip_decode_walk_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, vp, vp, vp, vp]
     L.himg_hip_decode_walk_wait.argtypes = [vp]
+    L.himg_hip_decode_walk_ranges_device.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, C.POINTER(C.c_int), i32, vp, vp, vp, vp]
+    L.himg_hip_decode_walk_wait_range.argtypes = [vp, i32]
     L.himg_hip_index_host.argtypes = [vp, sz, i32, P(i32), P(i32), P(i32), vp, sz, P(C.c_uint32)]
     L.himg_hip_create_multi.argtypes = [vp, i32, P(vp)]
     L.himg_hip_destroy_multi.argtypes = [vp]
@@ -364,6 +366,19 @@ class Engine:
                                                _ptr(d_row_index), _ptr(d_rows_first), _ptr(d_status),
                                                C.c_void_p(stream))
         self._check(rc, "decode_walk_device")
+
+    def decode_walk_ranges_device(self, d_packed, packed_size, width, height, channels, range_end, d_row_index,
+                                  d_rows_first, d_range_status, stream=0):
+        """himg_hip_decode_walk_ranges_device: the header walk in row ranges on the side stream;
+        range k's index entries and verdict are complete after decode_walk_wait_range(k)."""
+        ends = (C.c_int * len(range_end))(*[int(x) for x in range_end])
+        rc = lib().himg_hip_decode_walk_ranges_device(self._ctx, _ptr(d_packed), int(packed_size), width, height,
+                                                      channels, ends, len(range_end), _ptr(d_row_index),
+                                                      _ptr(d_rows_first), _ptr(d_range_status), C.c_void_p(stream))
+        self._check(rc, "decode_walk_ranges_device")
+
+    def decode_walk_wait_range(self, k):
+        self._check(lib().himg_hip_decode_walk_wait_range(self._ctx, int(k)), "decode_walk_wait_range")
 
     def decode_walk_wait(self):
         self._check(lib().himg_hip_decode_walk_wait(self._ctx), "decode_walk_wait")

@@ -197,6 +197,9 @@ constexpr int kDecHead = 1, kDecRows = 2;   // launch_decode's phases
 // The row-header walk of one frame alone (row-sharded decode: beside the head phase).
 void launch_rowwalk_only(const Geom &g, const DecWs &ws, const uint8_t *d_packed, size_t in_stride,
                          const uint32_t *d_sizes, hipStream_t stream);
+// ... up to (not including) block row `row_end`; resume: go on where the launch before stopped.
+void launch_rowwalk_range(const Geom &g, const DecWs &ws, const uint8_t *d_packed, size_t in_stride,
+                          const uint32_t *d_sizes, int row_end, bool resume, hipStream_t stream);
 
 // Row-sharded encode of one frame (multi-GPU): phases between the collectives.
 void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_base,

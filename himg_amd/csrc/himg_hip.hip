@@ -140,6 +140,8 @@ struct himg_hip_ctx {
   DecWs dec_ws{};
   int dec_batch = 0;
   bool dec_valid = false;
+  hipEvent_t ev_range[HIMG_MAX_WALK_RANGES] = {};   // himg_hip_decode_walk_ranges_device: behind every row range
+  int n_ranges = 0;
   // What the last himg_hip_decode_head_device prepared (the frame tables and the low-res plane in
   // the decoder workspace): himg_hip_decode_rows_after_head_device must be handed the same
   // stream, geometry and HIP stream, with no other decode on this context in between (every
@@ -302,6 +304,8 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
     if (ctx->dstr.ev_cnt[k]) hipEventDestroy(ctx->dstr.ev_cnt[k]);
     if (ctx->dstr.ev_win[k]) hipEventDestroy(ctx->dstr.ev_win[k]);
   }
+  for (int k = 0; k < HIMG_MAX_WALK_RANGES; ++k)
+    if (ctx->ev_range[k]) hipEventDestroy(ctx->ev_range[k]);
   if (ctx->dstr.side) hipStreamDestroy(ctx->dstr.side);
   if (ctx->dstr.side2) hipStreamDestroy(ctx->dstr.side2);
   if (ctx->dstr.side3) hipStreamDestroy(ctx->dstr.side3);
@@ -849,6 +853,70 @@ extern "C" int himg_hip_decode_walk_device(himg_hip_ctx *ctx, const void *d_pack
   HIP_TRY(ctx, hipMemcpyAsync(d_rows_first, &ctx->dec_ws.frames[0].rows_first, 4, hipMemcpyDeviceToDevice, w));
   HIP_TRY(ctx, hipMemcpyAsync(d_status, &ctx->dec_ws.frames[0].walk_status, 4, hipMemcpyDeviceToDevice, w));
   HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_walk_ranges_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                                  int width, int height, int num_channels, const int *range_end,
+                                                  int n_ranges, uint32_t *d_row_index, uint32_t *d_rows_first,
+                                                  int32_t *d_range_status, void *stream) {
+  if (!ctx || !d_packed || !d_row_index || !d_rows_first || !d_range_status || !range_end || n_ranges < 1 ||
+      n_ranges > HIMG_MAX_WALK_RANGES)
+    return HIMG_ERR_ARG;
+  Geom g;
+  if (!make_geom(width, height, num_channels, num_channels, 1, &g))
+    return fail(ctx, HIMG_ERR_ARG, "bad geometry");
+  g.fix_t2 = ctx->fix_t2;
+  if (g.rows + 1 > 65535) return fail(ctx, HIMG_ERR_UNSUPPORTED, "grid too large");
+  if ((uintptr_t)d_packed & 15) return fail(ctx, HIMG_ERR_ARG, "buffers must be 16-byte aligned");
+  for (int k = 0; k < n_ranges; ++k)
+    if (range_end[k] < 0 || (k && range_end[k] < range_end[k - 1])) return fail(ctx, HIMG_ERR_ARG, "range ends must ascend");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dec_ws(ctx, g, 1);
+  if (rc) return rc;
+  for (int k = 0; k < n_ranges; ++k)
+    if (!ctx->ev_range[k]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_range[k], hipEventDisableTiming));
+  hipStream_t s = (hipStream_t)stream;
+  ctx->last_stream = s;
+  rc = stage_sizes(ctx, &packed_size, 1, s);
+  if (rc) return rc;
+  hipStream_t w = ctx->use_side ? ctx->dstr.side : s;
+  if (w != s) {
+    HIP_TRY(ctx, hipEventRecord(ctx->dstr.ev_fork, s));
+    HIP_TRY(ctx, hipStreamWaitEvent(w, ctx->dstr.ev_fork, 0));
+  }
+  int done = 0;   // rows whose index entries have been copied out
+  for (int k = 0; k < n_ranges; ++k) {
+    const bool last = k + 1 == n_ranges || range_end[k] >= g.rows;
+    const int upto = last ? g.rows : range_end[k];
+    himg_dev::launch_rowwalk_range(g, ctx->dec_ws, (const uint8_t *)d_packed, ((size_t)packed_size + 3) / 4 * 4,
+                                   (const uint32_t *)ctx->d_sizes.p, last ? 0x7fffffff : upto, k > 0, w);
+    if (upto > done) {
+      HIP_TRY(ctx, hipMemcpyAsync(d_row_index + done, ctx->dec_ws.row_off + done, (size_t)(upto - done) * 4, hipMemcpyDeviceToDevice, w));
+      HIP_TRY(ctx, hipMemcpyAsync(d_row_index + g.rows + done, ctx->dec_ws.row_len + done, (size_t)(upto - done) * 4, hipMemcpyDeviceToDevice, w));
+      done = upto;
+    }
+    if (k == 0) HIP_TRY(ctx, hipMemcpyAsync(d_rows_first, &ctx->dec_ws.frames[0].rows_first, 4, hipMemcpyDeviceToDevice, w));
+    HIP_TRY(ctx, hipMemcpyAsync(d_range_status + k, &ctx->dec_ws.frames[0].walk_status, 4, hipMemcpyDeviceToDevice, w));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_range[k], w));
+    ctx->n_ranges = k + 1;
+    if (last) {   // (ranges behind the last row: nothing left to walk; their events are this one)
+      for (int j = k + 1; j < n_ranges; ++j) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_range_status + j, &ctx->dec_ws.frames[0].walk_status, 4, hipMemcpyDeviceToDevice, w));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_range[j], w));
+      }
+      ctx->n_ranges = n_ranges;
+      break;
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return HIMG_OK;
+}
+
+extern "C" int himg_hip_decode_walk_wait_range(himg_hip_ctx *ctx, int k) {
+  if (!ctx || k < 0 || k >= ctx->n_ranges || !ctx->ev_range[k]) return HIMG_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_range[k]));
   return HIMG_OK;
 }
 

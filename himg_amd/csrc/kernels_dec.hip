@@ -3845,6 +3845,11 @@ void launch_rowwalk_only(const Geom &g, const DecWs &ws, const uint8_t *d_packed
   hipLaunchKernelGGL(k_dec_rowwalk, dim3(1), dim3(64), 0, stream, g, ws, d_packed, in_stride, d_sizes, 0x7fffffff, 0);
 }
 
+void launch_rowwalk_range(const Geom &g, const DecWs &ws, const uint8_t *d_packed, size_t in_stride,
+                          const uint32_t *d_sizes, int row_end, bool resume, hipStream_t stream) {
+  hipLaunchKernelGGL(k_dec_rowwalk, dim3(1), dim3(64), 0, stream, g, ws, d_packed, in_stride, d_sizes, row_end, resume ? 1 : 0);
+}
+
 void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_packed,
                    size_t in_stride, const uint32_t *d_sizes, uint8_t *d_out,
                    int32_t *d_status, hipStream_t stream, Profiler *prof, bool allow_fused,

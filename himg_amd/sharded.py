@@ -383,7 +383,17 @@ class ShardedDecoder:
         self.rows = (height + 7) // 8
         self.parts = shard_rows(self.rows, self.world)
         self.fix_t2 = fix_t2
-        r0, r1 = self.parts[self.rank]
+        # Who decodes which row range.  The ranges are served in the order the header walk
+        # reaches them, so rank 0 -- which walks, and can start on its own rows only when the walk
+        # is through -- takes the LAST non-empty range and ranks 1, 2, ... the ranges from the top:
+        # every remote slice is on its way while the walk is still going (the last remote one
+        # at (n - 1) / n of it).  Empty ranges (more ranks than 16-row units) go to the last ranks.
+        nonempty = [k for k, (a, b) in enumerate(self.parts) if b > a]
+        empty = [k for k, (a, b) in enumerate(self.parts) if b <= a]
+        order = ([nonempty[-1]] + nonempty[:-1] + empty) if nonempty else list(range(self.world))
+        self.range_of_rank = order                      # rank -> index into self.parts
+        self.serve_order = [r for r in range(1, self.world) if self.parts[order[r]][1] > self.parts[order[r]][0]]
+        r0, r1 = self.parts[order[self.rank]]
         y0, y1 = min(8 * r0, height), min(8 * r1, height)
         self.r0, self.r1, self.y0, self.y1 = r0, r1, y0, y1
         dev = self.dev
@@ -552,9 +562,19 @@ class ShardedDecoder:
         self.d_status.zero_()
         # The head of the stream is in `buf` once the current stream gets here: from this point
         # the engine's kernels run on the engine stream, BESIDE what follows on the current one
-        # (the index broadcast, the rows' transfers).
+        # (the rows' index slices and bytes on their way to their owners).
         self._fork()
-        if rank == 0 and d_src is not None:
+        ranges_walk = rank == 0 and d_src is not None and hasattr(self.eng, "decode_walk_ranges_device") \
+            and len(self.serve_order) + 1 <= 16
+        if ranges_walk:
+            # The header walk in the row ranges of the ranks, in the order they are served: a
+            # range's slice leaves as soon as the walk has passed it.
+            ends = [self.parts[self.range_of_rank[r]][1] for r in self.serve_order] + [rows]
+            self.d_rstat = torch.zeros(16, dtype=torch.int32, device=self.dev)
+            self.eng.decode_walk_ranges_device(buf, size, self.W, self.H, self.C, ends, self.d_index,
+                                               self.d_index[2 * rows:], self.d_rstat, self._s())
+            self.trace.append("walk_started")
+        elif rank == 0 and d_src is not None:
             self._walk_rank0(buf, size)      # (in front of the head phase: they run side by side)
             self.trace.append("walk_started")
         if pipelined:
@@ -562,73 +582,113 @@ class ShardedDecoder:
             # walks the row headers and the rows' bytes travel.
             self.eng.decode_head_device(buf, size, self.W, self.H, self.C, self._s())
             self.trace.append("head_phase")
-        # ---- stage 2: the row index, every rank's own rows, the rows' decode
-        meta = self.meta
+        # ---- stage 2: every rank's index slice and row bytes, as the walk reaches them
+        max_rows = max(b - a for a, b in self.parts)
+        mlen = 4 + 2 * max_rows                       # [ok, lo, hi, n, offsets..., lengths...]
+        my_a, my_b = self.parts[self.range_of_rank[rank]]
+        idx_ok, my_off, my_len = True, None, None
         if rank == 0:
-            if d_src is not None:
-                iok, off, ln = self._index_rank0()
-            elif self._host_index is not None:
-                iok, (off, ln) = True, self._host_index
-            else:
-                iok, off, ln = False, np.zeros(rows, np.int64), np.zeros(rows, np.int64)
-            m = np.zeros(4 + 2 * rows, np.int64)
-            m[0], m[1] = size, 1 if iok else 0
-            m[4:4 + rows], m[4 + rows:] = np.asarray(off, np.int64), np.asarray(ln, np.int64)
-            meta.copy_(torch.from_numpy(m))
-        if world > 1:
-            dist.broadcast(meta, src=0, group=group)
-            self.bytes_from_rank0 += (world - 1) * meta.numel() * 8
-        m = meta.cpu().numpy()
-        self.trace.append("index")
-        if not bool(m[1]):
-            if pipelined:
-                torch.cuda.synchronize(self.dev) if self.dev.type == "cuda" else None
-            self._join()
-            return False, None          # a row header is damaged: every rank agrees
-        off, ln = m[4:4 + rows], m[4 + rows:]
-        ranges = slice_ranges(off, ln, first, size, self.parts)
-        if world > 1:
-            # Each peer's own rows to that peer only.
-            ops, staged = [], []
-            if rank == 0:
-                for peer in range(1, world):
-                    lo, hi = ranges[peer]
-                    if hi > lo:
-                        t = buf[lo:hi] if self.comm == self.dev else buf[lo:hi].to(self.comm)
-                        ops.append(dist.P2POp(dist.isend, t, peer, group))
-                        self.bytes_from_rank0 += hi - lo
-            else:
-                lo, hi = ranges[rank]
-                if hi > lo:
-                    # What lies right behind this rank's slice is a previous frame's: the row kernels
-                    # clamp their reads to the row, but the invariant is the one-process path's
-                    # (himg_multi.hip zeroes 64 bytes behind every slot's slice) -- no decode ever
-                    # sees bytes of another frame.
-                    buf[hi:min(hi + 64, buf.numel())].zero_()
-                    t = buf[lo:hi] if self.comm == self.dev else torch.empty(hi - lo, dtype=torch.uint8, device=self.comm)
-                    ops.append(dist.P2POp(dist.irecv, t, 0, group))
-                    staged.append((lo, hi, t))
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-            if self.comm != self.dev:
-                for lo, hi, t in staged:
-                    buf[lo:hi] = t.to(self.dev)
-        self.trace.append("rows_arrived")
-        idx32 = torch.from_numpy(np.concatenate([off, ln]).astype(np.uint32).view(np.int32))
-        self.d_index[: 2 * rows] = idx32.to(self.dev)
-        # The rows phase follows the head phase on the engine stream and must also see the row
-        # bytes and the index, which arrived on the current stream.
-        self._fork()
-        if pipelined:
-            self.eng.decode_rows_after_head_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
-                                                   self.d_rows, self.d_status, self._s())
+            whole = None                               # (ok, offsets, lengths) of all rows, when known at once
+            if d_src is None:
+                whole = (True,) + tuple(self._host_index) if self._host_index is not None else \
+                    (False, np.zeros(rows, np.int64), np.zeros(rows, np.int64))
+            elif not ranges_walk:
+                whole = self._index_rank0()
+
+            def index_of(k_served, a, b):
+                """(ok, offsets, lengths) of rows [a, b): the k-th range the walk reaches."""
+                if whole is not None:
+                    return whole[0], np.asarray(whole[1][a:b], np.int64), np.asarray(whole[2][a:b], np.int64)
+                self.eng.decode_walk_wait_range(k_served)
+                h = torch.cat([self.d_index[a:b], self.d_index[rows + a: rows + b],
+                               self.d_rstat[k_served: k_served + 1]]).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                n = b - a
+                return int(h[-1]) == 0, h[:n], h[n:2 * n]
+
+            reqs, keep = [], []
+            failed = False
+            for k_served, peer in enumerate(self.serve_order):
+                a, b = self.parts[self.range_of_rank[peer]]
+                iok, off, ln = (False, None, None) if failed else index_of(k_served, a, b)
+                failed = failed or not iok
+                m = np.zeros(mlen, np.int64)
+                if not failed:
+                    lo, hi = slice_ranges(np.concatenate([np.zeros(a, np.int64), off]),
+                                          np.concatenate([np.zeros(a, np.int64), ln]), first, size, [(a, b)])[0]
+                    m[0], m[1], m[2], m[3] = 1, lo, hi, b - a
+                    m[4:4 + (b - a)], m[4 + max_rows: 4 + max_rows + (b - a)] = off, ln
+                mt = torch.from_numpy(m).to(self.comm)
+                keep.append(mt)
+                reqs.append(dist.isend(mt, peer, group=group))
+                self.bytes_from_rank0 += mlen * 8
+                if not failed and m[2] > m[1]:
+                    lo, hi = int(m[1]), int(m[2])
+                    t = buf[lo:hi] if self.comm == self.dev else buf[lo:hi].to(self.comm)
+                    keep.append(t)
+                    reqs.append(dist.isend(t, peer, group=group))
+                    self.bytes_from_rank0 += hi - lo
+                self.trace.append("slice_sent:%d" % peer)
+            # ranks without rows still learn the verdict of the index
+            for peer in range(1, world):
+                if peer not in self.serve_order:
+                    m = np.zeros(mlen, np.int64)
+                    m[0] = 0 if failed else 1
+                    mt = torch.from_numpy(m).to(self.comm)
+                    keep.append(mt)
+                    reqs.append(dist.isend(mt, peer, group=group))
+                    self.bytes_from_rank0 += mlen * 8
+            if my_b > my_a and not failed:
+                iok, my_off, my_len = index_of(len(self.serve_order), my_a, my_b)
+                failed = failed or not iok
+            elif d_src is not None and ranges_walk and not failed:
+                # (no rows of its own: the walk's final verdict still counts)
+                self.eng.decode_walk_wait_range(len(self.serve_order))
+                failed = int(self.d_rstat[len(self.serve_order)].item()) != 0
+            idx_ok = not failed
+            self.trace.append("index")
+            for req in reqs:
+                req.wait()
+            self.trace.append("rows_arrived")
         else:
-            self.eng.decode_rows_indexed_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
-                                                self.d_rows, self.d_status, self._s())
-        self.trace.append("rows_phase")
+            mt = torch.zeros(mlen, dtype=torch.int64, device=self.comm)
+            dist.recv(mt, 0, group=group)
+            m = mt.cpu().numpy()
+            idx_ok = bool(m[0])
+            self.trace.append("index")
+            if idx_ok and m[2] > m[1]:
+                lo, hi, n = int(m[1]), int(m[2]), int(m[3])
+                my_off, my_len = m[4:4 + n], m[4 + max_rows: 4 + max_rows + n]
+                # What lies right behind this rank's slice is a previous frame's: the row kernels
+                # clamp their reads to the row, but the invariant is the one-process path's
+                # (himg_multi.hip zeroes 64 bytes behind every slot's slice) -- no decode ever
+                # sees bytes of another frame.
+                buf[hi:min(hi + 64, buf.numel())].zero_()
+                if self.comm == self.dev:
+                    dist.recv(buf[lo:hi], 0, group=group)
+                else:
+                    t = torch.empty(hi - lo, dtype=torch.uint8, device=self.comm)
+                    dist.recv(t, 0, group=group)
+                    buf[lo:hi] = t.to(self.dev)
+            self.trace.append("rows_arrived")
+        if idx_ok and my_b > my_a:
+            # this rank's slice of the row index (the engine reads rows [r0, r1) of it only)
+            full = np.zeros(2 * rows, np.int64)
+            full[my_a:my_b], full[rows + my_a: rows + my_b] = my_off, my_len
+            self.d_index[: 2 * rows] = torch.from_numpy(full.astype(np.uint32).view(np.int32)).to(self.dev)
+            # The rows phase follows the head phase on the engine stream and must also see the row
+            # bytes and the index, which arrived on the current stream.
+            self._fork()
+            if pipelined:
+                self.eng.decode_rows_after_head_device(buf, size, self.W, self.H, self.C, self.r0, self.r1,
+                                                       self.d_index, self.d_rows, self.d_status, self._s())
+            else:
+                self.eng.decode_rows_indexed_device(buf, size, self.W, self.H, self.C, self.r0, self.r1, self.d_index,
+                                                    self.d_rows, self.d_status, self._s())
+            self.trace.append("rows_phase")
         self._join()                         # status and pixel rows are read on the current stream
         bad = (self.d_status[:1] != 0).to(torch.int32).to(self.comm)    # (the transfer waits for the kernels)
+        if not idx_ok:
+            bad.fill_(1)                     # a row header is damaged: every rank agrees below
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
         ok = int(bad.item()) == 0
@@ -642,9 +702,10 @@ class ShardedDecoder:
         ops, out = [], None
         if rank == 0:
             out = torch.empty((H, W, C), dtype=torch.uint8, device=self.comm)
-            out[self.y0:self.y1] = d_rows.to(self.comm)
+            if self.y1 > self.y0:
+                out[self.y0:self.y1] = d_rows.to(self.comm)
             for peer in range(1, world):
-                a, b = self.parts[peer]
+                a, b = self.parts[self.range_of_rank[peer]]
                 ya, yb = min(8 * a, H), min(8 * b, H)
                 if yb > ya:
                     ops.append(dist.P2POp(dist.irecv, out[ya:yb], peer, group))

@@ -282,6 +282,20 @@ int himg_hip_decode_walk_device(himg_hip_ctx *ctx, const void *d_packed, uint32_
                                 int width, int height, int num_channels, uint32_t *d_row_index,
                                 uint32_t *d_rows_first, int32_t *d_status, void *stream);
 int himg_hip_decode_walk_wait(himg_hip_ctx *ctx);
+/* The same walk in ROW RANGES, for the rank that scatters a stream over several ranks
+ * (replaces, on the device, the serial header walk of huffman_dec.cpp:232-248 as the reference's
+ * decoder.cpp:292-326 consumes it row by row): n_ranges launches on the context's side stream,
+ * range k ending in front of block row range_end[k] (ascending; the last one >= rows walks to the
+ * end).  Behind every range its rows' offsets / lengths are copied to d_row_index ([rows] offsets,
+ * then [rows] lengths) and the walk's verdict so far to d_range_status[k]: what a range's owner
+ * needs is complete -- and can be sent on its way -- when himg_hip_decode_walk_wait_range(k)
+ * returns, while the walk goes on through the ranges behind it.  At most HIMG_MAX_WALK_RANGES. */
+#define HIMG_MAX_WALK_RANGES 16
+int himg_hip_decode_walk_ranges_device(himg_hip_ctx *ctx, const void *d_packed, uint32_t packed_size,
+                                       int width, int height, int num_channels, const int *range_end,
+                                       int n_ranges, uint32_t *d_row_index, uint32_t *d_rows_first,
+                                       int32_t *d_range_status, void *stream);
+int himg_hip_decode_walk_wait_range(himg_hip_ctx *ctx, int k);
 
 /* ---- multi-device: several GPUs of one node behind this ABI ------------------- */
 /*

@@ -146,7 +146,10 @@ class StubDecodeEngine:
         assert size == full.size
         _, _, _, off, ln, first = himg_amd.index_host(full)
         idx = d_index.numpy().view(np.uint32)
-        assert np.array_equal(idx[:rows], off) and np.array_equal(idx[rows:2 * rows], ln), "row index differs"
+        # (a rank is handed the index of its OWN rows -- the slice that left rank 0 when the header
+        # walk had passed them; the engine reads rows [r0, r1) of the index only)
+        assert np.array_equal(idx[r0:r1], off[r0:r1]) and np.array_equal(idx[rows + r0: rows + r1], ln[r0:r1]), \
+            "row index differs"
         buf = d_packed.numpy()
         assert np.array_equal(buf[:first], full[:first]), "head of the stream differs"
         if r1 > r0:
@@ -200,6 +203,19 @@ def main_decode(mode, kind, seed, W, H, q, outfile):
         # row index is known, the rows' decode when their bytes have arrived.
         t = dec.trace
         assert t.index("head") < t.index("head_phase") < t.index("index") < t.index("rows_arrived") < t.index("rows_phase"), t
+    if rank == 0 and world > 1:
+        # Rank 0 serves the row ranges in the order the header walk reaches them -- every slice
+        # leaves behind the head phase's launch and in front of rank 0's own index -- and keeps
+        # the LAST non-empty range for itself (its rows are the last the walk reaches).
+        t = dec.trace
+        sent = [e for e in t if e.startswith("slice_sent:")]
+        assert sent == ["slice_sent:%d" % p for p in dec.serve_order], (sent, dec.serve_order)
+        if sent:
+            assert t.index("head_phase") < t.index(sent[0]) and t.index(sent[-1]) < t.index("index"), t
+        nonempty = [k for k, (a, b) in enumerate(dec.parts) if b > a]
+        assert dec.range_of_rank[0] == nonempty[-1]
+        starts = [dec.parts[dec.range_of_rank[p]][0] for p in dec.serve_order]
+        assert starts == sorted(starts) and all(s_ < dec.parts[nonempty[-1]][0] for s_ in starts)
     if rank == 0:
         if ok:
             np.asarray(pix, np.uint8).tofile(outfile)
