@@ -32,6 +32,7 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 

@@ -1145,6 +1145,13 @@ __global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
 // becomes child_a (bit 0).  Then a pre-order walk serialises the tree and
 // assigns LSB-first codes (huffman_enc.cpp:148-180).
 // ---------------------------------------------------------------------------
+// LDS stores of this wavefront visible to its own later loads (no workgroup barrier).
+__device__ __forceinline__ void wave_lds_sync_e() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int kTreeThreads = 576;   // nine waves: one lane per node of the largest tree (2 * 261 - 1)
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }   // a wave-uniform value, in an SGPR
 
@@ -1157,6 +1164,8 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(EncWs ws, int strm0) {
   __shared__ uint32_t bits[kTreeStride / 4];
   __shared__ int s_num;
   __shared__ int s_sz[2 * kNumSym];            // subtree size in bits of the serialised tree
+  __shared__ int t_cnt[2 * 64 + 2], t_sz[2 * 64 + 2];   // one batch of the merge, in pick order (see below)
+  __shared__ short t_id[2 * 64 + 2];
   static_assert(kTreeThreads >= 2 * kNumSym, "one lane per node");
 
   const int strm = blockIdx.x + strm0, f = blockIdx.y, lane = threadIdx.x;
@@ -1220,16 +1229,110 @@ __global__ __launch_bounds__(kTreeThreads) void k_tree(EncWs ws, int strm0) {
     // registers when the run of equal counts it belongs to is closed, or fetched when
     // the group before it opens.  Subtree sizes flow through VGPRs to their store.
     int lh = 0;                          // head of the sorted leaves
-    int lc = uni(s_cnt[0]), li = uni(s_idx[0]);    // the head leaf
-    int lc_nv = s_cnt[1], li_nv = s_idx[1];         // the one behind it (num > 1), still in flight (VGPRs)
-    int ib = un, ie = un, inext = un;    // current internal group [ib, ie), next group from inext
+    // ---- round 5: the merge in BATCHES ----
+    // The serial loop below is 181 dependent steps of ~1000 cycles for the bench frames' FRES
+    // alphabet (88 us of a single frame's 0.38 ms).  Most of those steps do not depend on each
+    // other: let x1, x2 be the two lightest nodes and s = count(x1) + count(x2).  Every node that
+    // a merge creates from now on weighs at least s, so ALL nodes lighter than s are consumed
+    // before any of them, in the reference's order (count ascending, index DESCENDING) and in
+    // consecutive pairs: the batch B = {nodes with count < s}, sorted by that order, becomes the
+    // pairs (B[0], B[1]), (B[2], B[3]), ... -- new nodes next, next + 1, ... with non-decreasing
+    // counts, child_a the lighter one -- and an odd last one is left over, still the lightest,
+    // for the next batch.  One batch is a handful of wave-wide steps: which leaves (sorted) and
+    // which internal nodes (created with non-decreasing counts: a prefix of the unconsumed ones)
+    // are lighter than s; each one's rank in B -- leaves are in order already, internal nodes
+    // are in order once every run of equal counts is reversed (higher index first), a leaf
+    // follows the internal nodes of its count (lower index) --; scatter by rank, pair up.
+    // Counts roughly double from batch to batch: ~40 batches instead of 181 steps.
+    // What the batch form does not take (more than 64 leaves or internal nodes in one batch that
+    // no threshold separates: long runs of equal counts, e.g. uniform noise) is left to the
+    // serial loop, which starts from wherever the batches stopped.
+    int qh = un;                         // first unconsumed internal node (all of them: [qh, next))
+    int yh = 0, yc = 0, yi = 0, ysz = 0; // the left-over node of the batch before (lighter than everything else)
+    for (;;) {
+      if ((un - lh) + (next - qh) + yh < 2) break;
+      // the two smallest counts: among the left-over, two leaves, two internal nodes
+      int hv = 0x7fffffff;
+      if (lane == 0 && yh) hv = yc;
+      if ((lane == 1 || lane == 2) && lh + lane - 1 < un) hv = s_cnt[lh + lane - 1];
+      if ((lane == 3 || lane == 4) && qh + lane - 3 < next) hv = cnt[qh + lane - 3];
+      int m1 = 0x7fffffff, m2 = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int h = __builtin_amdgcn_readlane(hv, k);
+        if (h < m1) { m2 = m1; m1 = h; } else if (h < m2) m2 = h;
+      }
+      int s_thr = m1 + m2;
+      // at most 64 of either kind: a 65th one lighter than s lowers the threshold to its count
+      if (lh + 64 < un) { const int c64 = uni(s_cnt[lh + 64]); if (c64 < s_thr) s_thr = c64; }
+      if (qh + 64 < next) { const int c64 = uni(cnt[qh + 64]); if (c64 < s_thr) s_thr = c64; }
+      const bool vl = lh + lane < un, vi = qh + lane < next;
+      const int Lc = vl ? s_cnt[lh + lane] : 0x7fffffff, Lid = vl ? (int)s_idx[lh + lane] : 0;
+      const int Ic = vi ? cnt[qh + lane] : 0x7fffffff, Isz = vi ? s_sz[qh + lane] : 0;
+      const int nl = __popcll(__ballot(vl && Lc < s_thr)), ni = __popcll(__ballot(vi && Ic < s_thr));
+      const int yin = (yh && yc < s_thr) ? 1 : 0;
+      const int m = uni(yin + nl + ni);
+      if (m < 2) break;                  // (the serial loop's case)
+      // internal nodes in the reference's order: every run of equal counts reversed
+      const int prevc = (int)wave_prev(0x80000000u, (uint32_t)Ic);
+      const unsigned long long starts = __ballot(lane < ni && (lane == 0 || Ic != prevc));
+      const int run_b = 63 - __clzll((long long)(starts & ((2ull << lane) - 1ull)));
+      const unsigned long long above = (starts >> lane) >> 1;
+      const int run_e = above ? lane + 1 + (__ffsll((long long)above) - 1) : ni;
+      const int kb = run_b + (run_e - 1 - lane);
+      int le = 0, lt = 0;                // internal nodes not heavier than this leaf / leaves lighter than this internal node
+      for (int j = 0; j < ni; ++j) le += (__builtin_amdgcn_readlane(Ic, j) <= Lc) ? 1 : 0;
+      for (int j = 0; j < nl; ++j) lt += (__builtin_amdgcn_readlane(Lc, j) < Ic) ? 1 : 0;
+      if (lane < nl) { const int rk = yin + lane + le; t_cnt[rk] = Lc; t_id[rk] = (short)Lid; t_sz[rk] = 10; }
+      if (lane < ni) { const int rk = yin + kb + lt; t_cnt[rk] = Ic; t_id[rk] = (short)(qh + lane); t_sz[rk] = Isz; }
+      if (lane == 0 && yin) { t_cnt[0] = yc; t_id[0] = (short)yi; t_sz[0] = ysz; }
+      wave_lds_sync_e();
+      const int np = m >> 1;
+      if (lane < np) {
+        const int n = next + lane;
+        ca[n] = t_id[2 * lane]; cb[n] = t_id[2 * lane + 1]; nsym[n] = -1;
+        cnt[n] = t_cnt[2 * lane] + t_cnt[2 * lane + 1];
+        s_sz[n] = 1 + t_sz[2 * lane] + t_sz[2 * lane + 1];
+      }
+      if (m & 1) { yh = 1; yc = uni(t_cnt[m - 1]); yi = uni((int)t_id[m - 1]); ysz = uni(t_sz[m - 1]); }
+      else yh = 0;
+      lh = uni(lh + nl); qh = uni(qh + ni); next = uni(next + np);
+      wave_lds_sync_e();                 // (the new nodes are read by the next batch)
+    }
+    // ---- the serial loop, from wherever the batches stopped ----
+    // Its view of the internal nodes [qh, next): runs of equal counts, s_end[first node of a run] =
+    // the node behind the run; the last run may still grow.
+    for (int q0 = qh; q0 < next; q0 += 64) {
+      const int q = q0 + lane;
+      if (q < next && (q == qh || cnt[q] != cnt[q - 1])) {
+        int e = q + 1;
+        const int c = cnt[q];
+        while (e < next && cnt[e] == c) ++e;
+        s_end[q] = (short)e;
+      }
+    }
+    wave_lds_sync_e();
+    int lc = uni(s_cnt[min(lh, un)]), li = uni((int)s_idx[min(lh, un)]);    // the head leaf (two entries of padding)
+    int lc_nv = s_cnt[min(lh + 1, un)], li_nv = s_idx[min(lh + 1, un)];        // the one behind it, still in flight (VGPRs)
+    int run0 = next, run_c = -1;         // the run of equal counts at the end of the nodes: [run0, next)
+    if (qh < next) {
+      run_c = uni(cnt[next - 1]);
+      int r0v = next - 1;
+      while (r0v > qh && uni(cnt[r0v - 1]) == run_c) --r0v;
+      run0 = r0v;
+    }
+    int ib = qh, ie = qh, inext = qh;    // current internal group [ib, ie), next group from inext
     int g = 0;                           // count of the current group
-    int run0 = un, run_c = -1;           // the run of equal counts at the end of the nodes: [run0, next)
-    int pg_v = 0, pe_v = 0;              // count / end of the group at inext when that run is closed (VGPRs)
-    for (int left = un; left > 1; --left) {
+    int pg_v = 0, pe_v = 0;              // count / end of the group at inext (VGPRs)
+    if (inext < run0) { pg_v = cnt[inext]; pe_v = s_end[inext]; }
+    for (int left = (un - lh) + (next - qh) + yh; left > 1; --left) {
       int pick[2], pc[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (t == 0 && yh) {              // the batches' left-over node: lighter than everything else
+          pick[0] = yi; pc[0] = yc; yh = 0;
+          continue;
+        }
         if (ib == ie && inext < next) {  // open the next group of equal counts
           ib = inext;
           if (ib >= run0) { g = run_c; ie = inext = next; }   // the last run (it may still grow, below)

@@ -52,6 +52,19 @@ def test_single_gpu_line():
 
 
 @pytest.mark.gpu
+def test_single_gpu_line_with_extras():
+    """The default run's side measurements (copy ceilings incl. the hand-written calibration
+    kernels, single-frame latency, host API) on a tiny batch: they must not take the line down."""
+    d = _run(["--batch", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-rows"])
+    ex = d["extras"]
+    assert ex["hbm_copy_ceiling_GBs"] > 500
+    assert ex["single_frame_latency_ms"]["encode"] > 0 and ex["single_frame_latency_ms"]["decode"] > 0
+    if os.path.exists(os.path.join(ROOT, "tools", "micro", "hbm_calib")):
+        k = ex["hbm_ceiling_kernels_GBs"]
+        assert k["read_only"] > 1000 and k["write_only"] > 1000 and k["copy_read_plus_write"] > 1000
+
+
+@pytest.mark.gpu
 def test_two_ranks_self_launched_frames():
     d = _run(["--gpus", "2", "--oversubscribe", "--batch", "2", "--steps", "2", "--warmup", "1",
               "--no-cpu-baseline", "--no-extras", "--no-rows"])

@@ -19,4 +19,6 @@ cp "$SRC"/stats_default/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_defau
 cp "$SRC"/stats_b64/*/*_kernel_stats.csv "profiles/${TAG}_kernel_stats_b64.csv"
 cp "$SRC/pmc/summary.json" "profiles/${TAG}_pmc_summary.json"
 cp "$SRC/traffic.json" profiles/traffic.json
+[ -f "$SRC/calib/calibration.json" ] && cp "$SRC/calib/calibration.json" "profiles/${TAG}_calibration.json"
+[ -f "$SRC/graph_latency.json" ] && cp "$SRC/graph_latency.json" "profiles/${TAG}_graph_latency.json"
 ls -la profiles/${TAG}_* profiles/traffic.json

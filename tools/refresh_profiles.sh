@@ -29,6 +29,10 @@ for wh in "2048 2048" "1024 1024" "1920 1080"; do
   set -- $wh
   python3 "$ROOT/bench.py" --width $1 --height $2 --batch 256 --no-rows --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 >> "$ROOT/$OUT/configs.jsonl"
 done
+# Counter calibration on known byte counts (FETCH_SIZE / WRITE_SIZE factors, copy ceilings) and the
+# single-frame chains replayed from a HIP graph.
+bash "$ROOT/tools/calibrate_pmc.sh" "$OUT/calib" > "$ROOT/$OUT/calib.log" 2>&1
+python3 "$ROOT/tools/graph_latency.py" > "$ROOT/$OUT/graph_latency.json" 2> "$ROOT/$OUT/graph_latency.err"
 cd /tmp && export TMPDIR=/tmp
 # The driver's command (default batch), then the 64-frame launch DESIGN.md's per-kernel tables are written for.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_default" -- \
