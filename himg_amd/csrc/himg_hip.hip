@@ -282,7 +282,6 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
             hipEventCreateWithFlags(&ctx->dstr.ev_win[k], hipEventDisableTiming) == hipSuccess;
   if (!ev_ok || hipStreamCreateWithPriority(&ctx->dstr.side, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipStreamCreateWithPriority(&ctx->dstr.side2, hipStreamNonBlocking, prio_least) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->dstr.side3, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->dstr.ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->side_enc, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork_e, hipEventDisableTiming) != hipSuccess ||
@@ -290,6 +289,11 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
     himg_hip_destroy(ctx);
     return HIMG_ERR_HIP;
   }
+  // The decoder's third helper stream IS the encoder's side stream (a context never encodes and
+  // decodes at once): the runtime maps streams onto FOUR hardware queues (GPU_MAX_HW_QUEUES), and
+  // a fifth stream of this context shared a queue with another one -- the encoder's LRES branch
+  // then ran behind the pixel stage instead of beside it (+1.5 ms per 128-frame step, measured).
+  ctx->dstr.side3 = ctx->side_enc;
   *out = ctx;
   return HIMG_OK;
 }
@@ -308,7 +312,6 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
     if (ctx->ev_range[k]) hipEventDestroy(ctx->ev_range[k]);
   if (ctx->dstr.side) hipStreamDestroy(ctx->dstr.side);
   if (ctx->dstr.side2) hipStreamDestroy(ctx->dstr.side2);
-  if (ctx->dstr.side3) hipStreamDestroy(ctx->dstr.side3);
   if (ctx->ev_fork_e) hipEventDestroy(ctx->ev_fork_e);
   if (ctx->ev_join_e) hipEventDestroy(ctx->ev_join_e);
   if (ctx->side_enc) hipStreamDestroy(ctx->side_enc);
