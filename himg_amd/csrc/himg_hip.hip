@@ -156,6 +156,8 @@ struct himg_hip_ctx {
 
   // Staging for the host-buffer API.
   DevBuf h_in, h_out, h_sizes, h_status, h_index;
+  uint32_t *hp_index = nullptr;          // pinned staging of the host row index (decode_core)
+  size_t hp_index_cap = 0;               // in dwords
 
   // Packed sizes handed to the decoder: the caller's array (or a by-value argument)
   // may be gone before an asynchronous copy reads it, so the sizes are first copied
@@ -333,6 +335,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status, &ctx->h_index};
   for (DevBuf *b : all) b->release();
+  if (ctx->hp_index) hipHostFree(ctx->hp_index);
   delete ctx;
 }
 
@@ -1166,8 +1169,10 @@ static int decode_core(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_s
   ctx->host_bytes = 0;
   // (The row kernels read whole dwords and a few dwords ahead: nothing of the stream decoded
   // before may lie behind this one.)
-  HIP_TRY(ctx, hipMemset((uint8_t *)ctx->h_in.p + (packed_size & ~(size_t)15), 0, in_cap - (packed_size & ~(size_t)15)));
-  HIP_TRY(ctx, hipMemcpy(ctx->h_in.p, packed, packed_size, hipMemcpyHostToDevice));
+  // (Everything below is ordered on the null stream, which the decode runs on; the one wait of
+  // this call is the read of the verdict at the end.)
+  HIP_TRY(ctx, hipMemsetAsync((uint8_t *)ctx->h_in.p + (packed_size & ~(size_t)15), 0, in_cap - (packed_size & ~(size_t)15), nullptr));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_in.p, packed, packed_size, hipMemcpyHostToDevice, nullptr));
   const uint32_t sz32 = (uint32_t)packed_size;
   // The stream is in host memory: the FRES rows are indexed HERE -- the walk over the row
   // size headers (huffman_dec.cpp:232-248) is a chain of dependent reads, microseconds on
@@ -1176,12 +1181,21 @@ static int decode_core(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_s
   // headers, a geometry it does not index) takes the device walk, which words the verdict.
   int rc = -1;
   {
-    std::vector<uint32_t> index(2 * (size_t)g.rows);
+    // The index is written into a pinned buffer the context keeps (this call returns only after
+    // the decode that reads its copy has finished) and goes up asynchronously.
+    const size_t n_idx = 2 * (size_t)g.rows;
+    if (ctx->hp_index_cap < n_idx) {
+      if (ctx->hp_index) hipHostFree(ctx->hp_index);
+      ctx->hp_index = nullptr;
+      ctx->hp_index_cap = 0;
+      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->hp_index, round_up(n_idx * 4, 4096), hipHostMallocDefault));
+      ctx->hp_index_cap = round_up(n_idx * 4, 4096) / 4;
+    }
     uint32_t first = 0;
     int w2 = 0, h2 = 0, c2 = 0;
-    if (g.rows >= 2 && ctx->h_index.reserve(round_up(index.size() * 4, 256)) &&
-        himg_hip_index_host(packed, packed_size, ctx->fix_t2, &w2, &h2, &c2, index.data(), (size_t)g.rows, &first) == HIMG_OK) {
-      HIP_TRY(ctx, hipMemcpy(ctx->h_index.p, index.data(), index.size() * 4, hipMemcpyHostToDevice));
+    if (g.rows >= 2 && ctx->h_index.reserve(round_up(n_idx * 4, 256)) &&
+        himg_hip_index_host(packed, packed_size, ctx->fix_t2, &w2, &h2, &c2, ctx->hp_index, (size_t)g.rows, &first) == HIMG_OK) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_index.p, ctx->hp_index, n_idx * 4, hipMemcpyHostToDevice, nullptr));
       rc = himg_hip_decode_rows_indexed_device(ctx, ctx->h_in.p, sz32, *W, *H, *C, 0, g.rows, (const uint32_t *)ctx->h_index.p,
                                                ctx->h_out.p, (int32_t *)ctx->h_status.p, nullptr);
     }
