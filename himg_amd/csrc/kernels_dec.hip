@@ -1280,6 +1280,90 @@ constexpr uint32_t kWinGuard = 16;
 constexpr uint32_t kRowWindow = 128u * 1024u;   // k_row_window: symbols of a row per workgroup (64 KiB windows, two
                                                 // workgroups per CU: 1.12 -> 1.69 ms at 16384^2 -- half the lanes idle,
                                                 // the per-workgroup costs twice)
+// The chain form of lean_write (the reader stands at bp): [bp, lim) is a stretch of
+// k_row_count_w's chain of groups, the groups taken from bp end exactly at lim.  The loop is bound
+// by its VALU instructions (four wavefronts per SIMD; an instruction more per step is 1 % of the
+// row kernel), scalar ones are free beside them.  Against lean_write's step:
+//  * the verdict is a lane VALUE that only the tree walk touches (as a bool it lived in scalar
+//    mask registers, three scalar instructions per step for a flag no valid stream sets);
+//  * the reader's window base is the wavefront's (a row's payload): scalar base + a lane BYTE
+//    offset -- the refill's address is one add and one min, the load takes the offset as it is;
+//  * the output position carries the LDS address of the symbol area: the group's dword address is
+//    one AND;
+//  * a tree walk's extra bits advance the position where they are found, not through a register
+//    that is zero on every other step.
+struct ChainReader {
+  unsigned long long win;
+  int nb;
+  uint32_t pre, noff, offmax;   // the prefetched word, its byte offset, the offset of the stream's last dword
+  const __attribute__((address_space(1))) uint8_t *sbase;   // (wavefront-uniform; global)
+  __device__ __forceinline__ void refill() {   // afterwards nb >= 33
+    if (nb <= 32) {
+      win |= (unsigned long long)pre << nb;
+      nb += 32;
+      noff += 4u;
+      pre = *(const __attribute__((address_space(1))) uint32_t *)(sbase + min(noff, offmax));
+    }
+  }
+  __device__ __forceinline__ void consume(int n) { win >>= n; nb -= n; }
+};
+__device__ __forceinline__ void lds_or32(uint32_t a, uint32_t v) {
+  (void)__hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t *)(uintptr_t)a, v, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &t, uint32_t bp, uint32_t lim, uint32_t op,
+                                                 uint8_t *lds_out) {
+  ChainReader rd;
+  rd.win = rd0.win; rd.nb = rd0.nb; rd.pre = rd0.pre;
+  rd.noff = 4u * rd0.next; rd.offmax = 4u * rd0.jmax;
+  {
+    const unsigned long long a = (unsigned long long)(uintptr_t)rd0.w;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    rd.sbase = (const __attribute__((address_space(1))) uint8_t *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+  }
+  uint32_t badv = 0;
+  uint32_t opa = op + lds_addr(lds_out);   // (the symbol area is dword aligned: opa & 3 == op & 3)
+  const uint32_t TM = ((1u << kLutBits) - 1u) << 3, TB = lds_addr(t.grp);
+  uint32_t tm = TM, tb = TB;
+  auto step = [&]() {
+    rd.refill();
+    const uint2 e = lds_ld64(((((uint32_t)rd.win) << 3) & tm) + tb);
+    uint32_t y = e.y, by = e.x, ntm = TM, ntb = TB;
+    if (__builtin_expect(y == 0, 0)) {
+      if ((by >> 31) && tm == TM) {
+        ntm = ((1u << (by & 255u)) - 1u) << 3;
+        ntb = TB + (((1u << kLutBits) + ((by >> 8) & 0xffffu)) << 3);
+        y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
+        by = 0;
+      } else {
+        const int base = tm == TM ? 0 : kLutBits;
+        uint32_t len;
+        bool b = false;
+        y = walk_token(rd, t, by, base, &len, &by, &b);
+        badv |= b ? 1u : 0u;
+        bp += len - (uint32_t)base;
+      }
+    }
+    tm = ntm; tb = ntb;
+    const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
+    const uint32_t n = y >> 27;
+    rd.consume((int)n);
+    const unsigned long long v = (unsigned long long)by << (8u * (opa & 3u));
+    const uint32_t a = opa & ~3u;
+    lds_or32(a, (uint32_t)v);
+    lds_or32(a + 4u, (uint32_t)(v >> 32));
+    opa += ((y >> 10) & 511u) + extra;
+    bp += n;
+  };
+  LoopCount lc;
+  while (bp < lim) { HIMG_REGION_BEGIN("dec.write"); step(); lc.step(); HIMG_REGION_END("dec.write"); }
+  lc.done(0);
+  if (tm != TM) step();
+  asm volatile("" :: "v"(rd.pre));   // (ReaderT::retire)
+  return badv == 0;
+}
+
 // chain: [bp, lim) is a stretch of k_row_count_w's chain of groups (lane_off's valid flag
 // 3): the groups taken from bp end exactly at lim, one loop without a token-by-token tail.
 template <bool CLIP = false>
@@ -1326,10 +1410,9 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       op += ((y >> 10) & 511u) + extra;
       bp += adv + n;
     };
-    LoopCount lc;
-    if (chain) {   // (uniform per row)
-      while (bp < lim) { HIMG_REGION_BEGIN("dec.write"); step(); lc.step(); HIMG_REGION_END("dec.write"); }
-      lc.done(0);
+    if (!CLIP && chain) return lean_write_chain(rd, t, bp, lim, op, lds_out);   // (uniform per row)
+    if (chain) {
+      while (bp < lim) step();
       if (tm != TM) step();
       rd.retire();
       return !bad;
