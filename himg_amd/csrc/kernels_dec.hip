@@ -1324,20 +1324,21 @@ __device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &
   }
   uint32_t badv = 0;
   uint32_t opa = op + lds_addr(lds_out);   // (the symbol area is dword aligned: opa & 3 == op & 3)
-  const uint32_t TM = ((1u << kLutBits) - 1u) << 3, TB = lds_addr(t.grp);
-  uint32_t tm = TM, tb = TB;
+  // (the table a step indexes is lane state: index bits and base -- v_bfe, v_lshl_add)
+  const uint32_t TW = (uint32_t)kLutBits, TB = lds_addr(t.grp);
+  uint32_t tm = TW, tb = TB;
   auto step = [&]() {
     rd.refill();
-    const uint2 e = lds_ld64(((((uint32_t)rd.win) << 3) & tm) + tb);
-    uint32_t y = e.y, by = e.x, ntm = TM, ntb = TB;
+    const uint2 e = lds_ld64((__builtin_amdgcn_ubfe((uint32_t)rd.win, 0u, tm) << 3) + tb);
+    uint32_t y = e.y, by = e.x, ntm = TW, ntb = TB;
     if (__builtin_expect(y == 0, 0)) {
-      if ((by >> 31) && tm == TM) {
-        ntm = ((1u << (by & 255u)) - 1u) << 3;
+      if ((by >> 31) && tm == TW) {
+        ntm = by & 255u;
         ntb = TB + (((1u << kLutBits) + ((by >> 8) & 0xffffu)) << 3);
         y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
         by = 0;
       } else {
-        const int base = tm == TM ? 0 : kLutBits;
+        const int base = tm == TW ? 0 : kLutBits;
         uint32_t len;
         bool b = false;
         y = walk_token(rd, t, by, base, &len, &by, &b);
@@ -1359,7 +1360,7 @@ __device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &
   LoopCount lc;
   while (bp < lim) { HIMG_REGION_BEGIN("dec.write"); step(); lc.step(); HIMG_REGION_END("dec.write"); }
   lc.done(0);
-  if (tm != TM) step();
+  if (tm != TW) step();
   asm volatile("" :: "v"(rd.pre));   // (ReaderT::retire)
   return badv == 0;
 }
