@@ -3305,19 +3305,19 @@ __device__ __forceinline__ void grp_count_lds(const LdsBits &bits, const GrpTabl
   uint32_t c = 0;
   if (pos < lim) {
     bool bad = false;
-    const uint32_t TM = ((1u << kLutBits) - 1u) << 2;
+    const uint32_t TM = (uint32_t)kLutBits;   // (index BITS: the address is a v_bfe and a v_lshl_add)
     const uint32_t TB = lds_addr(t.gy);
     const uint32_t XOFF = (uint32_t)kTabEntries * 4u;   // from a step word to its .x
     uint32_t tm = TM, tb = TB;   // which table the next step indexes (lean_count: long codes take two steps)
     auto step = [&]() {
       uint32_t win = bits.window(pos);
-      const uint32_t a = ((win << 2) & tm) + tb;
+      const uint32_t a = (__builtin_amdgcn_ubfe(win, 0u, tm) << 2) + tb;
       uint32_t y = lds_ld32(a);
       uint32_t ntm = TM, ntb = TB;
       if (__builtin_expect(y == 0, 0)) {
         const uint32_t x = lds_ld32(a + XOFF);
         if ((x >> 31) && tm == TM) {
-          ntm = ((1u << (x & 255u)) - 1u) << 2;
+          ntm = x & 255u;
           ntb = TB + (((1u << kLutBits) + ((x >> 8) & 0xffffu)) << 2);
           y = (uint32_t)kLutBits | ((uint32_t)kLutBits << 27);
         } else {
