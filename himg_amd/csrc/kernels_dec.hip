@@ -3311,7 +3311,8 @@ __device__ __forceinline__ void grp_count_lds(const LdsBits &bits, const GrpTabl
     uint32_t tm = TM, tb = TB;   // which table the next step indexes (lean_count: long codes take two steps)
     auto step = [&]() {
       uint32_t win = bits.window(pos);
-      const uint32_t a = (__builtin_amdgcn_ubfe(win, 0u, tm) << 2) + tb;
+      uint32_t a;   // (index << 2) + tb in ONE instruction (the compiler splits it: shift, add)
+      asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a) : "v"(__builtin_amdgcn_ubfe(win, 0u, tm)), "v"(tb));
       uint32_t y = lds_ld32(a);
       uint32_t ntm = TM, ntb = TB;
       if (__builtin_expect(y == 0, 0)) {
