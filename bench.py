@@ -454,13 +454,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
-    if world > 1:
-        # The runtime maps a process's streams onto 4 hardware queues by default; a rank of the rows
-        # leg has more than that in flight (torch's stream, RCCL's, the engine stream and the
-        # context's three helper streams), and streams that share a queue run one after the other.
-        # Must be in the environment before the HIP runtime starts (torch is imported below); with
-        # one rank it makes no difference (84.1 vs 84.3 Gpx/s, profiles/r05_experiments.md).
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # The runtime maps a process's streams onto 4 hardware queues by default, and streams that share
+    # a queue run one after the other.  A rank of the rows leg has more than four in flight (torch's
+    # stream, RCCL's, the engine stream, the context's three helper streams), and so has the one-rank
+    # run once the extras have created their contexts (rows decode 2.92 ms with 4 queues, 2.80 with
+    # 8; the frames line is the same either way: 85.2 / 84.9 Gpx/s).  Must be in the environment
+    # before the HIP runtime starts (torch is imported below).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import torch.distributed as dist
