@@ -1311,8 +1311,11 @@ __device__ __forceinline__ void lds_or32(uint32_t a, uint32_t v) {
   (void)__hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t *)(uintptr_t)a, v, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// CLIP (k_row_window): as in lean_write -- lds_out is a window of the block, a group is OR-ed in when its first byte
+// lies less than 8 bytes in front of the window or inside it.
+template <bool CLIP = false>
 __device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &t, uint32_t bp, uint32_t lim, uint32_t op,
-                                                 uint8_t *lds_out) {
+                                                 uint8_t *lds_out, uint32_t win_span = 0) {
   ChainReader rd;
   rd.win = rd0.win; rd.nb = rd0.nb; rd.pre = rd0.pre;
   rd.noff = 4u * rd0.next; rd.offmax = 4u * rd0.jmax;
@@ -1324,6 +1327,7 @@ __device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &
   }
   uint32_t badv = 0;
   uint32_t opa = op + lds_addr(lds_out);   // (the symbol area is dword aligned: opa & 3 == op & 3)
+  const uint32_t clip_lo = lds_addr(lds_out) + (kWinGuard - 8u), clip_span = win_span - (kWinGuard - 8u);   // (CLIP)
   // (the table a step indexes is lane state: index bits and base -- v_bfe, v_lshl_add)
   const uint32_t TW = (uint32_t)kLutBits, TB = lds_addr(t.grp);
   uint32_t tm = TW, tb = TB;
@@ -1350,10 +1354,12 @@ __device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &
     const uint32_t extra = __builtin_amdgcn_ubfe((uint32_t)rd.win, y, y >> 5);
     const uint32_t n = y >> 27;
     rd.consume((int)n);
-    const unsigned long long v = (unsigned long long)by << (8u * (opa & 3u));
-    const uint32_t a = opa & ~3u;
-    lds_or32(a, (uint32_t)v);
-    lds_or32(a + 4u, (uint32_t)(v >> 32));
+    if (!CLIP || opa - clip_lo < clip_span) {
+      const unsigned long long v = (unsigned long long)by << (8u * (opa & 3u));
+      const uint32_t a = opa & ~3u;
+      lds_or32(a, (uint32_t)v);
+      lds_or32(a + 4u, (uint32_t)(v >> 32));
+    }
     opa += ((y >> 10) & 511u) + extra;
     bp += n;
   };
@@ -1411,13 +1417,7 @@ __device__ __forceinline__ bool lean_write(GReader &rd, const GrpTables &t, uint
       op += ((y >> 10) & 511u) + extra;
       bp += adv + n;
     };
-    if (!CLIP && chain) return lean_write_chain(rd, t, bp, lim, op, lds_out);   // (uniform per row)
-    if (chain) {
-      while (bp < lim) step();
-      if (tm != TM) step();
-      rd.retire();
-      return !bad;
-    }
+    if (chain) return lean_write_chain<CLIP>(rd, t, bp, lim, op, lds_out, win_span);   // (uniform per row)
     while ((int)bp <= limk) step();
     if (tm != TM) step();
     while (bp < lim) {
