@@ -28,7 +28,7 @@ SYNTH = {"grad": 0, "gradn": 1, "rand": 2, "randtile": 3}
 DBG = {
     "avg": 0, "lowres": 1, "lres_sym": 2, "fres_sym": 3, "lres_hist": 4, "fres_hist": 5,
     "lres_len": 6, "fres_len": 7, "lres_code": 8, "fres_code": 9, "fres_row_bytes": 10,
-    "dec_stats": 11, "parse_stats": 12, "rowcount_stats": 13, "loop_counts": 14,
+    "dec_stats": 11, "parse_stats": 12, "rowcount_stats": 13, "loop_counts": 14, "fres_tok_sym": 15,
 }
 DBG_DECODER = 0x100
 
@@ -281,7 +281,7 @@ class Engine:
 
     def get_option(self, option):
         """himg_hip_get_option: the option as the context holds it (names as in set_option)."""
-        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3}[option] if isinstance(option, str) else int(option)
+        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3, "row_tokens": 4}[option] if isinstance(option, str) else int(option)
         v = C.c_int(0)
         self._check(lib().himg_hip_get_option(self._ctx, opt, C.byref(v)), "get_option")
         return v.value
@@ -289,7 +289,7 @@ class Engine:
     def set_option(self, option, value):
         """himg_hip_set_option; option names: "fix_t2", and the kernel-variant selectors
         "count_wave" / "emit_rows" (-1 = by launch size, 0 / 1 = force; see include/himg_hip.h)."""
-        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3}[option] if isinstance(option, str) else int(option)
+        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3, "row_tokens": 4}[option] if isinstance(option, str) else int(option)
         self._check(lib().himg_hip_set_option(self._ctx, opt, int(value)), "set_option")
         if opt == 1:
             self.fix_t2 = bool(value)   # (the row-sharded decoder's host index follows it, sharded.py)

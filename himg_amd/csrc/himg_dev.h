@@ -38,6 +38,8 @@ struct Geom {
   int wide_q;                // decoder, rows wider than the LDS: the host's estimate says a quarter sub-sequence of a row
                              // (1/4096 of its payload) fits k_row_count_q's staging buffer -- that kernel counts
   int emit_rows;             // encoder: k_emit_t<8> (a wavefront per row) instead of a workgroup per row
+  int row_tokens;            // encoder: FRES rows as a token stream (k_tok -> k_emit_tok) instead of k_tok_hist / k_emit_t
+                             // over the dense symbol plane twice
   long long frame_bytes;     // W*H*stride
   long long fres_size;       // rows*row_block
 };
@@ -59,7 +61,21 @@ struct EncWs {
   uint64_t *span_bit0;       // [f][lres_spans + rows] absolute start bit in the frame's output
   uint32_t *span_bits;       // [f][lres_spans + rows] payload bits of the span
   int32_t *status;           // [f]
+  // Token stream of the FRES rows (k_tok -> k_emit_tok; nullptr: k_tok_hist / k_emit_t work on the dense symbol plane).
+  // A block row is cut into tok_nseg segments of tok_seg symbols; segment s of row r of frame f owns
+  // tok_cap 16-bit slots at tok + ((f * rows + r) * tok_nseg + s) * tok_cap and its slot count
+  // (a multiple of 8 slots is always written: the tail is padded with no-op slots) in tok_cnt.
+  uint16_t *tok;
+  uint32_t *tok_cnt;         // [f][rows][tok_nseg]
+  int tok_seg, tok_nseg, tok_cap;
 };
+
+// Token slots (16 bits; see k_tok): literal | zeros in front << 8 (literal 1..255, 0..255 zeros);
+// 0 = no-op; a run of zeros on its own takes an even-aligned pair of slots: kTokRunMark, then its length.
+constexpr uint32_t kTokRunMark = 0x0100u;
+constexpr int kTokMaxRun = 255;          // zeros a literal slot can carry
+constexpr int kTokIter = 2048;           // symbols per wavefront iteration of the tokeniser (32 per lane)
+constexpr int kTokSegPad = 64;           // slots a segment can need beyond its symbol count (runs on their own, padding)
 
 // Container bytes that do not depend on the pixel data, built on the host.
 struct StaticChunks {
@@ -161,6 +177,13 @@ struct DecWs {
 // ---- launch wrappers (defined in kernels_enc.hip / kernels_dec.hip) --------
 
 struct Profiler;  // host-side, see himg_hip.hip
+
+// Does launch_encode tokenise the FRES rows into slots (and so need EncWs::tok) for this call?
+bool enc_uses_row_tokens(const Geom &g, int batch);
+// Symbols per token segment for this geometry (a multiple of kTokIter).
+int enc_tok_seg(const Geom &g);
+// Debug: expand frame `frame`'s token stream into symbols again (dst: fres_size bytes).
+void launch_tok_expand(const Geom &g, const EncWs &ws, int frame, uint8_t *dst, hipStream_t stream);
 
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
                    uint8_t *d_out, size_t out_stride, uint32_t *d_sizes,

@@ -117,6 +117,7 @@ struct himg_hip_ctx {
   int lead_bits = 128;     // HIMG_LEAD_BITS: tuning knob, see Geom::lead_bits
   int lres_serial = 0;     // HIMG_FORCE_LRES_SERIAL=1: test knob, see Geom::lres_serial
   int count_wave = -1, emit_rows = -1;   // HIMG_OPT_COUNT_WAVE / _EMIT_ROWS (-1: by launch size)
+  int row_tokens = -1;                   // HIMG_OPT_ROW_TOKENS (-1: by launch size)
   // Batched host API: H2D of frame i+1, kernels of frame i and D2H of frame i-1 overlap
   // on three streams; staging is double buffered.
   struct Pipe {
@@ -128,7 +129,7 @@ struct himg_hip_ctx {
   } pipe;
 
   // Encoder workspace.
-  DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist;
+  DevBuf e_planes, e_lres, e_fres, e_small, e_spanhist, e_tok, e_tokx;
   Geom enc_geom{};
   EncWs enc_ws{};
   int enc_batch = 0;
@@ -219,7 +220,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->max_sub = 4096;
   g->lead_bits = 128;
   g->lres_serial = 0;
-  g->count_wave = g->emit_rows = -1;
+  g->count_wave = g->emit_rows = g->row_tokens = -1;
   g->wide_q = 0;
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
@@ -257,6 +258,7 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   }
   if (const char *e = std::getenv("HIMG_COUNT_WAVE")) ctx->count_wave = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_EMIT_ROWS")) ctx->emit_rows = atoi(e) ? 1 : 0;
+  if (const char *e = std::getenv("HIMG_ROW_TOKENS")) ctx->row_tokens = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_LEAD_BITS")) {
     const int v = std::atoi(e);
     if (v >= 0 && v <= 4096) ctx->lead_bits = v;
@@ -331,7 +333,7 @@ extern "C" void himg_hip_destroy(himg_hip_ctx *ctx) {
     hipHostFree(ctx->pipe.h_meta);
   }
   DevBuf *all[] = {&ctx->fmap_lut, &ctx->e_planes, &ctx->e_lres, &ctx->e_fres, &ctx->e_small,
-                   &ctx->e_spanhist, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_gyc, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
+                   &ctx->e_spanhist, &ctx->e_tok, &ctx->e_tokx, &ctx->d_frames, &ctx->d_nodes, &ctx->d_grp, &ctx->d_gyc, &ctx->d_sub, &ctx->d_lane, &ctx->d_rows,
                    &ctx->d_lres, &ctx->d_fres, &ctx->d_planes, &ctx->d_sizes, &ctx->d_stats, &ctx->d_spec, &ctx->h_in,
                    &ctx->h_out, &ctx->h_sizes, &ctx->h_status, &ctx->h_index};
   for (DevBuf *b : all) b->release();
@@ -359,6 +361,7 @@ extern "C" int himg_hip_get_option(himg_hip_ctx *ctx, int option, int *value) {
   if (option == HIMG_OPT_FIX_T2) { *value = ctx->fix_t2; return HIMG_OK; }
   if (option == HIMG_OPT_COUNT_WAVE) { *value = ctx->count_wave; return HIMG_OK; }
   if (option == HIMG_OPT_EMIT_ROWS) { *value = ctx->emit_rows; return HIMG_OK; }
+  if (option == HIMG_OPT_ROW_TOKENS) { *value = ctx->row_tokens; return HIMG_OK; }
   return fail(ctx, HIMG_ERR_ARG, "unknown option");
 }
 
@@ -368,6 +371,7 @@ extern "C" int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value) {
   const int tri = value < 0 ? -1 : (value ? 1 : 0);
   if (option == HIMG_OPT_COUNT_WAVE) { ctx->count_wave = tri; return HIMG_OK; }
   if (option == HIMG_OPT_EMIT_ROWS) { ctx->emit_rows = tri; return HIMG_OK; }
+  if (option == HIMG_OPT_ROW_TOKENS) { ctx->row_tokens = value == 2 ? 2 : tri; return HIMG_OK; }   // (2: on + k_emit_tok's spelled-out path, a test knob)
   return fail(ctx, HIMG_ERR_ARG, "unknown option");
 }
 
@@ -442,8 +446,10 @@ static int stage_sizes(himg_hip_ctx *ctx, const uint32_t *src, int n, hipStream_
   return HIMG_OK;
 }
 
-static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
+static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g_in, int batch, bool allow_row_tokens = true) {
   EncWs &w = ctx->enc_ws;
+  Geom g = g_in;
+  g.row_tokens = ctx->row_tokens;
   // A row-sharded encode in progress belongs to the geometry it was started with.
   {
     const Geom &o = ctx->shard.g;
@@ -455,8 +461,15 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   const size_t lres = round_up((size_t)g.lres_size + 16, 256);
   const size_t fres = round_up((size_t)g.fres_size + 16, 256);
   const int nsp = g.lres_spans + g.rows;
+  // FRES rows as a token stream between the tokeniser and the bit packer (batches): 16-bit slots,
+  // worst case 2 bytes per symbol (+ padding per segment), ~0.7 in use.
+  const bool row_tok = allow_row_tokens && himg_dev::enc_uses_row_tokens(g, batch);
+  const int tok_seg = row_tok ? himg_dev::enc_tok_seg(g) : 0;
+  const int tok_nseg = row_tok ? (g.row_block + tok_seg - 1) / tok_seg : 0;
+  const int tok_cap = tok_seg + himg_dev::kTokSegPad;
   if (!ctx->e_planes.reserve(2 * plane * batch) || !ctx->e_lres.reserve(lres * batch) ||
-      !ctx->e_fres.reserve(fres * batch))
+      !ctx->e_fres.reserve(fres * batch) ||
+      (row_tok && !ctx->e_tok.reserve((size_t)batch * g.rows * tok_nseg * ((size_t)tok_cap * 2 + 4))))
     return fail(ctx, HIMG_ERR_HIP, "encoder workspace allocation failed");
   // Small per-frame arrays, carved from one allocation.
   size_t off = 0;
@@ -479,6 +492,9 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g, int batch) {
   w.plane_stride = plane;
   w.lres_sym = (uint8_t *)ctx->e_lres.p; w.lres_stride = lres;
   w.fres_sym = (uint8_t *)ctx->e_fres.p; w.fres_stride = fres;
+  w.tok = row_tok ? (uint16_t *)ctx->e_tok.p : nullptr;
+  w.tok_cnt = row_tok ? (uint32_t *)((uint8_t *)ctx->e_tok.p + (size_t)batch * g.rows * tok_nseg * (size_t)tok_cap * 2) : nullptr;
+  w.tok_seg = tok_seg; w.tok_nseg = tok_nseg; w.tok_cap = tok_cap;
   w.hist = (uint32_t *)(sm + o_hist);
   w.codes = (uint64_t *)(sm + o_codes);
   w.lens = (uint32_t *)(sm + o_lens);
@@ -630,6 +646,7 @@ extern "C" int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, i
   hipStream_t s = (hipStream_t)stream;
   ctx->last_stream = s;
   g.emit_rows = ctx->emit_rows;
+  g.row_tokens = ctx->row_tokens;
   launch_encode(g, ctx->enc_ws, batch, (const uint8_t *)d_frames, (uint8_t *)d_out, out_stride,
                 d_sizes, sc, st, lt, (const uint8_t *)ctx->fmap_lut.p, s, &ctx->prof,
                 ctx->use_side ? ctx->side_enc : nullptr, ctx->ev_fork_e, ctx->ev_join_e);
@@ -1404,7 +1421,7 @@ extern "C" int himg_hip_shard_stats(himg_hip_ctx *ctx, const void *d_frame_base,
   if (row0 < 0 || row1 > g.rows || row0 > row1 || g.rows > 65535)
     return fail(ctx, HIMG_ERR_ARG, "bad block-row range");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_enc_ws(ctx, g, 1);
+  int rc = ensure_enc_ws(ctx, g, 1, false);   // (the row-sharded phases work on the dense symbol plane)
   if (rc) return rc;
   auto &sh = ctx->shard;
   rc = build_static(g, quality, &sh.sc, &sh.st, &sh.lt);
@@ -1533,6 +1550,14 @@ extern "C" int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void 
       case HIMG_DBG_LOWRES: src = w.low + frame * w.plane_stride; n = (size_t)g.C * g.rows * g.cols; break;
       case HIMG_DBG_LRES_SYM: src = w.lres_sym + frame * w.lres_stride; n = (size_t)g.lres_size; break;
       case HIMG_DBG_FRES_SYM: src = w.fres_sym + frame * w.fres_stride; n = (size_t)g.fres_size; break;
+      case HIMG_DBG_FRES_TOK_SYM: {
+        // The token stream of the last batch encode expanded into symbols again (a scratch plane).
+        if (!w.tok) return HIMG_ERR_ARG;
+        if (!ctx->e_tokx.reserve(round_up((size_t)g.fres_size + 16, 256))) return fail(ctx, HIMG_ERR_HIP, "scratch plane allocation failed");
+        himg_dev::launch_tok_expand(g, w, frame, (uint8_t *)ctx->e_tokx.p, nullptr);
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        src = ctx->e_tokx.p; n = (size_t)g.fres_size; break;
+      }
       case HIMG_DBG_LRES_HIST: src = w.hist + ((size_t)frame * 2 + 0) * kHistStride; n = kNumSym * 4; break;
       case HIMG_DBG_FRES_HIST: src = w.hist + ((size_t)frame * 2 + 1) * kHistStride; n = kNumSym * 4; break;
       case HIMG_DBG_LRES_LEN: src = w.lens + ((size_t)frame * 2 + 0) * kHistStride; n = kNumSym * 4; break;

@@ -699,6 +699,13 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
 // Entropy coder helpers.
 // ---------------------------------------------------------------------------
 
+// LDS stores of this wavefront visible to its own later loads (no workgroup barrier).
+__device__ __forceinline__ void wave_lds_sync_e() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct ZR {   // zero-run summary of a symbol range
   int tz;     // trailing zeros
   int az;     // 1 when the range is all zeros
@@ -1139,19 +1146,256 @@ __global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
 }
 
 // ---------------------------------------------------------------------------
+// k_tok: RLE tokeniser + token histogram of the FRES block rows of a batch, leaving the rows
+// as a stream of 16-bit SLOTS for k_emit_tok (huffman_enc.cpp:98-144; replaces k_tok_hist for
+// batches: the bit packer then reads 0.7 bytes per symbol instead of the dense plane, and
+// every one of its lanes has eight tokens to pack on every step).
+// A workgroup of four wavefronts per block row.  The row is cut into tok_nseg segments which
+// the wavefronts take from a counter (the low-frequency segments hold several times the tokens
+// of the high-frequency ones); a segment is walked 2048 symbols at a time WITHOUT workgroup
+// barriers: the zeros in front of the segment come from a look back over the row, the zero-run
+// state of a lane from one maximum scan (DPP), slot positions from one add scan.  A lane's 32
+// symbols stay in registers and are walked as two halves of 16 (the symbol byte by v_perm).
+// Every non-zero symbol becomes one slot (literal | zeros in front << 8) and one LDS atomic in
+// the 2-D histogram of k_tok_hist; runs beyond 255 zeros and the row's trailing zeros are split
+// as the reference does (huffman_enc.cpp:111-141, trap T6) into even-aligned slot pairs (mark,
+// length).  Slots are staged per wavefront (2.25 KiB: eight workgroups per CU) and leave as
+// whole 16-byte pieces; an iteration that outgrows the buffer (more than ~56 % non-zero) is
+// staged half by half.
+// ---------------------------------------------------------------------------
+constexpr int kTokThreads = 256;
+constexpr int kTokWaves = kTokThreads / 64;
+constexpr int kTokStage = 1152;            // slots of a wavefront's staging buffer (a half's worst case: 1024 + runs on their own + < 8 carried over)
+constexpr int kTokSegs = 16;               // segments per block row at most (tok_nseg)
+
+__device__ __forceinline__ int run_token_symbol(int len) {   // huffman_enc.cpp:111-141
+  return len == 1 ? 0 : len == 2 ? 256 : len <= 6 ? 257 : len <= 22 ? 258 : len <= 278 ? 259 : 260;
+}
+__device__ __forceinline__ uint32_t run_token_count(int len) { return (uint32_t)(len / 16662 + (len % 16662 != 0 ? 1 : 0)); }
+
+// 32 symbols of a row (two 16-byte loads), zeros beyond `end`.
+__device__ __forceinline__ void load32(const uint8_t *p, bool valid, uint32_t w[8]) {
+  uint4 a = {0u, 0u, 0u, 0u}, b = a;
+  if (valid) { a = reinterpret_cast<const uint4 *>(p)[0]; b = reinterpret_cast<const uint4 *>(p)[1]; }
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+
+__global__ __launch_bounds__(kTokThreads) void k_tok(Geom g, EncWs ws, int r0) {
+  __shared__ uint32_t hist[kHistStride];
+  __shared__ uint32_t hist2[kPairRuns + 1][257];   // (as k_tok_hist)
+  __shared__ uint32_t hrun[kRunTab + 1];
+  __shared__ __attribute__((aligned(16))) uint16_t stage[kTokWaves][kTokStage];
+  __shared__ uint32_t next_seg;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row = (int)blockIdx.x + r0, f = blockIdx.y;
+  const int row_block = g.row_block, seg = ws.tok_seg, nseg = ws.tok_nseg;
+  const uint8_t *S = ws.fres_sym + (size_t)f * ws.fres_stride + (size_t)row * row_block;
+  for (int k = tid; k < kHistStride; k += kTokThreads) hist[k] = 0;
+  for (int k = tid; k < (kPairRuns + 1) * 257; k += kTokThreads) (&hist2[0][0])[k] = 0;
+  for (int k = tid; k < kRunTab + 1; k += kTokThreads) hrun[k] = 0;
+  if (tid == 0) next_seg = 0;
+  __syncthreads();
+  uint16_t *stg = stage[wv];
+  for (;;) {
+    // (No branch around the atomic: behind `if (lane == 0)` the compiler threads the two paths
+    // through the loop body separately -- the body then runs with lane 0 alone, then with the rest.)
+    const int sg = __builtin_amdgcn_readfirstlane((int)atomicAdd(&next_seg, lane == 0 ? 1u : 0u));
+    if (sg >= nseg) break;
+    const int p0 = sg * seg, p1 = min(p0 + seg, row_block);
+    // Zeros immediately in front of the segment (runs cross segments, never block rows).
+    int run_carry = 0;
+    for (int q = p0 - kTokIter; q >= 0; q -= kTokIter) {
+      uint32_t w[8];
+      load32(S + q + 32 * lane, true, w);
+      const uint32_t m = nonzero_mask16(w, 16) | (nonzero_mask16(w + 4, 16) << 16);
+      const unsigned long long nzl = __ballot(m != 0);
+      if (nzl == 0) { run_carry += kTokIter; continue; }
+      const int hl = 63 - __clzll((long long)nzl);
+      const uint32_t mh = (uint32_t)__builtin_amdgcn_readlane((int)m, hl);
+      run_carry += (63 - hl) * 32 + __clz((int)mh);
+      break;
+    }
+    const size_t seg_index = ((size_t)f * g.rows + row) * nseg + sg;
+    uint16_t *seg_out = ws.tok + seg_index * (size_t)ws.tok_cap;
+    uint32_t flushed = 0, c = 0;   // slots in HBM (a multiple of 8); slots waiting at the head of stg (< 8)
+    // Whole 16-byte pieces of the c + added staged slots leave; what is left (< 8 slots) moves to
+    // the head of the buffer.  (LDS operations of a wavefront execute in order.)
+    auto flush = [&](uint32_t added) {
+      wave_lds_sync_e();
+      const uint32_t ntot = c + added, nch = ntot >> 3, rem = ntot & 7u;
+      for (uint32_t j = lane; j < nch; j += 64)
+        *reinterpret_cast<uint4 *>(seg_out + flushed + 8 * j) = reinterpret_cast<const uint4 *>(stg)[j];
+      uint16_t keep = 0;
+      if ((uint32_t)lane < rem) keep = stg[nch * 8 + lane];
+      wave_lds_sync_e();
+      if ((uint32_t)lane < rem) stg[lane] = keep;
+      flushed += nch * 8;
+      c = rem;
+    };
+    LoopCount lci;
+    for (int q = p0; q < p1; q += kTokIter) {
+      HIMG_REGION_BEGIN("tokr.iter");
+      lci.step();
+      uint32_t w[8];   // (no prefetch: eight wavefronts per SIMD hide the load, eight more registers would cost one of them)
+      load32(S + q + 32 * lane, q + 32 * lane < p1, w);
+      const int nsym = min(kTokIter, p1 - q);   // (a multiple of 64: a lane holds 32 symbols or none)
+      const uint32_t mask = nonzero_mask16(w, 16) | (nonzero_mask16(w + 4, 16) << 16);
+      // Zeros in front of every lane: one past the last non-zero symbol of the iteration so far
+      // (0: none), an exclusive maximum scan on the DPP path.
+      uint32_t pm = mask ? (uint32_t)(32 * lane + 32 - __clz((int)mask)) : 0u;
+      pm = max(pm, dpp_from<kDppRowShr1, 0xf>(0, pm));
+      pm = max(pm, dpp_from<kDppRowShr2, 0xf>(0, pm));
+      pm = max(pm, dpp_from<kDppRowShr4, 0xf>(0, pm));
+      pm = max(pm, dpp_from<kDppRowShr8, 0xf>(0, pm));
+      pm = max(pm, dpp_from<kDppBcast15, 0xa>(0, pm));
+      pm = max(pm, dpp_from<kDppBcast31, 0xc>(0, pm));
+      const uint32_t pprev = wave_prev(0, pm);
+      const int run_in = 32 * lane - (int)pprev + (pprev ? 0 : run_carry);
+      const uint32_t plast = (uint32_t)__builtin_amdgcn_readlane((int)pm, 63);
+      run_carry = plast ? nsym - (int)plast : run_carry + nsym;
+      // The lane's two halves of 16 symbols, each with the zeros in front of it.  Slots of a half:
+      // its non-zero symbols; a run of more than 255 zeros in front of its first one, and the
+      // row's trailing zeros, as runs on their own (three slots per token of the reference).
+      const uint32_t mA = mask & 0xffffu, mB = mask >> 16;
+      const int rinA = run_in, rinB = mA ? __clz((int)mA) - 16 : run_in + 16;
+      const int leadA = mA ? rinA + __ffs((int)mA) - 1 : 0, leadB = mB ? rinB + __ffs((int)mB) - 1 : 0;
+      const bool longA = leadA > kTokMaxRun, longB = leadB > kTokMaxRun;
+      int trail = 0;
+      if (q + 32 * lane + 32 == row_block) trail = mB ? __clz((int)mB) - 16 : rinB + 16;
+      uint32_t nA = (uint32_t)__popc(mA), nB = (uint32_t)__popc(mB);
+      if (__builtin_expect(__any(longA || longB || trail != 0), 0)) {
+        nA += longA ? 3u * run_token_count(leadA) : 0u;
+        nB += (longB ? 3u * run_token_count(leadB) : 0u) + (trail ? 3u * run_token_count(trail) : 0u);
+      }
+      // One half's walk; `slot` is where the lane's slots of this half begin in stg.
+      auto half = [&](uint32_t mh, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int rin, int lead, bool lng,
+                      int trl, uint32_t slot) {
+        auto long_run = [&](int len) {
+          while (len > 0) {
+            const int piece = min(len, 16662);
+            const uint32_t odd = slot & 1u;   // (what is in HBM is a multiple of 8 slots: the parity in stg is the parity in the segment)
+            stg[slot + odd] = (uint16_t)kTokRunMark;
+            stg[slot + odd + 1] = (uint16_t)piece;
+            stg[slot + (odd ? 0 : 2)] = 0;
+            slot += 3;
+            atomicAdd(&hist[run_token_symbol(piece)], 1u);
+            len -= piece;
+          }
+        };
+        int prev1 = -rin;   // one past the previous non-zero symbol, relative to the half
+        if (__builtin_expect(__any(lng), 0)) {
+          if (lng) { long_run(lead); prev1 = __ffs((int)mh) - 1; }
+        }
+        uint32_t m = mh;
+        uint16_t *tp = stg + slot;
+        LoopCount lc;
+        while (m) {
+          HIMG_REGION_BEGIN("tokr.walk");
+          lc.step();
+          const int k = __ffs((int)m) - 1;
+          m &= m - 1;
+          const int run = k - prev1;
+          prev1 = k + 1;
+          const bool hi = k >= 8;
+          const uint32_t sy = __builtin_amdgcn_perm(hi ? w3 : w1, hi ? w2 : w0, ((uint32_t)k & 7u) | 0x0c0c0c00u);
+          // The literal always counts in the 2-D histogram (row kPairRuns: after a longer run); a
+          // longer run counts on its own, by exact length.
+          atomicAdd(&(&hist2[0][0])[__umul24((uint32_t)min(run, kPairRuns), 257u) + sy], 1u);   // (24-bit multiply-add: one full-rate instruction)
+          if (__builtin_expect(run >= kPairRuns, 0)) atomicAdd(&hrun[run], 1u);
+          *tp++ = (uint16_t)(sy | ((uint32_t)run << 8));
+          HIMG_REGION_END("tokr.walk");
+        }
+        lc.done(4);
+        if (__builtin_expect(__any(trl != 0), 0)) {
+          slot = (uint32_t)(tp - stg);
+          if (trl) long_run(trl);
+        }
+      };
+      const uint32_t n = nA + nB;
+      const uint32_t incl = wave_scan_add(n);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      // A dense iteration (more slots than the buffer holds) is staged in two parts: lanes 0..31,
+      // then lanes 32..63 -- the slots of a part are consecutive in the stream (lane-major order).
+      const bool split = c + total > (uint32_t)kTokStage;
+      const uint32_t mid = split ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) : total;
+#pragma unroll 1
+      for (int part = 0; part < (split ? 2 : 1); ++part) {
+        if (!split || (lane >> 5) == part) {
+          const uint32_t slot = c + incl - n - (part ? mid : 0u);
+          half(mA, w[0], w[1], w[2], w[3], rinA, leadA, longA, 0, slot);
+          half(mB, w[4], w[5], w[6], w[7], rinB, leadB, longB, trail, slot + nA);
+        }
+        flush(part ? total - mid : mid);
+      }
+      HIMG_REGION_END("tokr.iter");
+    }
+    lci.done(3);
+    if (c) {   // the tail, padded with no-op slots to a whole piece
+      if ((uint32_t)lane >= c && lane < 8) stg[lane] = 0;
+      wave_lds_sync_e();
+      if (lane == 0) *reinterpret_cast<uint4 *>(seg_out + flushed) = reinterpret_cast<const uint4 *>(stg)[0];
+      wave_lds_sync_e();
+    }
+    if (lane == 0) ws.tok_cnt[seg_index] = flushed + c;
+  }
+  __syncthreads();
+  // Fold the 2-D histogram into the 261 token bins (as k_tok_hist).
+  {
+    const int sy = tid;   // one lane per literal value
+    uint32_t lit = 0, r1c = hist2[1][sy], r2c = hist2[2][sy], r3c = 0;
+#pragma unroll
+    for (int rr = 0; rr <= kPairRuns; ++rr) lit += hist2[rr][sy];
+#pragma unroll
+    for (int rr = 3; rr < kPairRuns; ++rr) r3c += hist2[rr][sy];
+    if (lit) atomicAdd(&hist[sy], lit);
+    if (r1c) atomicAdd(&hist[0], r1c);
+    if (r2c) atomicAdd(&hist[256], r2c);
+    if (r3c) atomicAdd(&hist[257], r3c);
+  }
+  for (int rr = kPairRuns + tid; rr < kRunTab; rr += kTokThreads) {   // 7..22 -> 258, 23..278 -> 259
+    const uint32_t cnt = hrun[rr];
+    if (cnt) atomicAdd(&hist[rr <= 22 ? 258 : 259], cnt);
+  }
+  __syncthreads();
+  uint32_t *sh = ws.span_hist_f + ((size_t)f * g.rows + row) * kHistStride;
+  uint32_t *gh = ws.hist + ((size_t)f * 2 + 1) * kHistStride;
+  for (int k = tid; k < kHistStride; k += kTokThreads) {
+    const uint32_t cnt = hist[k];
+    sh[k] = cnt;
+    if (cnt && k < kNumSym) atomicAdd(&gh[k], cnt);
+  }
+}
+
+// k_tok_expand (debug read-back only): the symbols of one frame's block rows from their
+// slots, one lane per row (dst is zeroed first by the caller).
+__global__ __launch_bounds__(64) void k_tok_expand(Geom g, EncWs ws, int frame, uint8_t *out) {
+  const int v = blockIdx.x * 64 + threadIdx.x;
+  if (v >= g.rows) return;
+  uint8_t *dst = out + (size_t)v * g.row_block;
+  long long pos = 0;
+  for (int sg = 0; sg < ws.tok_nseg; ++sg) {
+    const size_t si = ((size_t)frame * g.rows + v) * ws.tok_nseg + sg;
+    const uint16_t *t = ws.tok + si * (size_t)ws.tok_cap;
+    const uint32_t n = min(ws.tok_cnt[si], (uint32_t)ws.tok_cap);
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t s = t[k];
+      if (s == 0) continue;
+      if (s == kTokRunMark) { pos += t[k + 1]; ++k; continue; }
+      pos += s >> 8;
+      if (pos < g.row_block) dst[pos] = (uint8_t)s;
+      ++pos;
+    }
+  }
+  if (pos != g.row_block) atomicMax(&ws.status[frame], 7);   // the slots do not cover the row exactly
+}
+
+// ---------------------------------------------------------------------------
 // k_tree: one workgroup (nine wavefronts) per (stream, frame).  Builds the Huffman tree with the
 // reference's tie-breaking (trap T5): repeatedly join the two lightest nodes
 // under the total order (count ascending, node index DESCENDING); the lighter
 // becomes child_a (bit 0).  Then a pre-order walk serialises the tree and
 // assigns LSB-first codes (huffman_enc.cpp:148-180).
 // ---------------------------------------------------------------------------
-// LDS stores of this wavefront visible to its own later loads (no workgroup barrier).
-__device__ __forceinline__ void wave_lds_sync_e() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 constexpr int kTreeThreads = 576;   // nine waves: one lane per node of the largest tree (2 * 261 - 1)
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }   // a wave-uniform value, in an SGPR
 
@@ -1929,6 +2173,196 @@ __global__ __launch_bounds__(ROWS > 1 ? 64 * ROWS : (WIDE ? 1024 : 256)) void k_
 }
 
 // ---------------------------------------------------------------------------
+// k_emit_tok: bit packing of FRES block rows from their slots (k_tok), a wavefront per row,
+// ROWS rows per workgroup sharing the tables.  A lane takes eight consecutive slots (one 16-byte
+// load), so every lane is busy on every step and nothing is searched for: a literal slot costs two
+// table reads -- the run token of the zeros in front of it (code + extra bits, <= 24 bits) and the
+// literal's code -- joined into one word; the two slots of a dword join into one piece of <= 64
+// bits; a wave scan of the lanes' bit counts places the pieces, which are OR-ed into the
+// wavefront's circular staging buffer and leave as whole dwords (as k_emit_t).  Slots that do
+// not fit (a code beyond 24 bits, more than 32 bits for run + literal) or an iteration beyond
+// the staging window take the slot-by-slot path with the reference's tokens spelled out
+// (huffman_enc.cpp:290-358).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTokBad = 0x80000000u;   // table entry: not representable on the fast path (length field 128)
+template <int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void k_emit_tok(Geom g, EncWs ws, uint8_t *out, size_t out_stride,
+                                                        const uint32_t *sizes, int r0, int r1) {
+  constexpr int kStage = 512;                                   // staging dwords per wavefront (a power of two)
+  constexpr uint32_t kWindow = (uint32_t)(kStage - 4) * 32u;    // + carry word + spill
+  __shared__ uint32_t stage_all[ROWS * kStage];
+  __shared__ unsigned long long s_cl[kHistStride];              // code | length << 32
+  __shared__ uint32_t s_runp[256];    // zeros in front of a literal, 0..255: run token bits | length << 24
+  __shared__ uint32_t s_lit[256];     // literal: code | length << 24; [0] = 0: the no-op slot
+  __shared__ uint32_t s_prun[kRunTab + 1];   // a run on its own of r < 279 zeros
+  const int f = blockIdx.y, lane = lane_id(), wave = wave_id();
+  const int row = r0 + (int)blockIdx.x * ROWS + wave;
+  if (sizes[f] == 0) return;   // frame failed (status says why)
+  const bool live = row < r1;
+  const int nthreads = 64 * ROWS, t_all = (int)threadIdx.x;
+  const size_t tab = ((size_t)f * 2 + 1) * kHistStride;
+  for (int k = t_all; k < kHistStride; k += nthreads)
+    s_cl[k] = (unsigned long long)(uint32_t)ws.codes[tab + k] | ((unsigned long long)ws.lens[tab + k] << 32);
+  for (int k = t_all; k < ROWS * kStage; k += nthreads) stage_all[k] = 0;
+  __syncthreads();
+  auto run_entry = [&](int r) -> uint32_t {   // the single token of r zeros, 0 < r < 279
+    const int rs = r == 1 ? 0 : r == 2 ? 256 : r <= 6 ? 257 : r <= 22 ? 258 : 259;
+    const int eb = r <= 2 ? 0 : r <= 6 ? 2 : r <= 22 ? 4 : 8;
+    const int ev = r <= 2 ? 0 : r <= 6 ? r - 3 : r <= 22 ? r - 7 : r - 23;
+    const unsigned long long cl = s_cl[rs];
+    const int len = (int)(cl >> 32);
+    return (len > 0 && len + eb <= 24) ? ((uint32_t)cl | ((uint32_t)ev << len) | ((uint32_t)(len + eb) << 24)) : kTokBad;
+  };
+  for (int k = t_all; k < 256; k += nthreads) {
+    s_runp[k] = k ? run_entry(k) : 0u;
+    const unsigned long long cl = s_cl[k];
+    const int len = (int)(cl >> 32);
+    s_lit[k] = k == 0 ? 0u : (len > 0 && len <= 24) ? ((uint32_t)cl | ((uint32_t)len << 24)) : kTokBad;
+  }
+  for (int k = t_all; k <= kRunTab; k += nthreads) s_prun[k] = (k > 0 && k < kRunTab) ? run_entry(k) : kTokBad;
+  __syncthreads();
+  if (!live) return;   // (nothing below is a workgroup barrier)
+
+  uint32_t *stage = stage_all + wave * kStage;
+  const int nsp = g.lres_spans + g.rows;
+  const unsigned long long B0 = ws.span_bit0[(size_t)f * nsp + g.lres_spans + row];
+  const unsigned long long B1 = B0 + ws.span_bits[(size_t)f * nsp + g.lres_spans + row];
+  uint8_t *o8 = out + (size_t)f * out_stride;
+  uint32_t *o32 = reinterpret_cast<uint32_t *>(o8);
+  const unsigned long long gw0 = B0 >> 5;
+  uint32_t sbit = (uint32_t)(B0 & 31);  // position of the next token, in bits from dword gw0
+  uint32_t fw = 0;                      // words already flushed
+  // FRES rows are byte aligned: the dwords at a row's two ends are shared with its neighbours
+  // and written byte by byte (one owner per byte).
+  auto store_word = [&](unsigned long long gw, uint32_t val) {
+    const unsigned long long wb0 = gw * 32ull;
+    if (wb0 >= B0 && wb0 + 32ull <= B1) {
+      o32[gw] = val;
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned long long bb = (gw * 4ull + b) * 8ull;
+        if (bb >= B0 && bb < B1) o8[gw * 4ull + b] = (uint8_t)(val >> (8 * b));
+      }
+    }
+  };
+  auto flush_to = [&](uint32_t end_bit) {   // complete words below end_bit leave; each lane re-zeroes what it flushed
+    const uint32_t nw = end_bit >> 5;
+    for (uint32_t k = fw + lane; k < nw; k += 64) {
+      const uint32_t slot = k & (kStage - 1);
+      store_word(gw0 + k, stage[slot]);
+      stage[slot] = 0;
+    }
+    fw = nw;
+  };
+  // n <= 32 bits at bit position pos (relative to dword gw0).
+  auto put32 = [&](uint32_t pos, uint32_t v, uint32_t n) {
+    if (n == 0) return;
+    const unsigned long long x = (unsigned long long)v << (pos & 31);
+    const uint32_t wi = (pos >> 5) & (kStage - 1);
+    atomicOr(&stage[wi], (uint32_t)x);
+    if ((uint32_t)(x >> 32)) atomicOr(&stage[(wi + 1) & (kStage - 1)], (uint32_t)(x >> 32));
+  };
+
+  const size_t seg0 = ((size_t)f * g.rows + row) * ws.tok_nseg;
+  LoopCount lci;
+  for (int sg = 0; sg < ws.tok_nseg; ++sg) {
+    const uint32_t nslots = min(ws.tok_cnt[seg0 + sg], (uint32_t)ws.tok_cap);   // (a count no producer wrote must not send the walk astray)
+    const uint32_t nch = (nslots + 7) >> 3;
+    const uint4 *src = reinterpret_cast<const uint4 *>(ws.tok + (seg0 + sg) * (size_t)ws.tok_cap);
+    for (uint32_t base = 0; base < nch; base += 64) {
+      HIMG_REGION_BEGIN("tok.iter");
+      lci.step();
+      uint4 q = {0u, 0u, 0u, 0u};
+      if (base + lane < nch) q = src[base + lane];
+      const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+      unsigned long long piece[4];
+      uint32_t np[4], bad = g.row_tokens == 2 ? 1u : 0u, mybits = 0;   // (2: test knob, every iteration takes the spelled-out path)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const uint32_t s0 = d[p] & 0xffffu, s1 = d[p] >> 16;
+        const uint32_t ra = s_runp[s0 >> 8], la = s_lit[s0 & 255u], rb = s_runp[s1 >> 8], lb = s_lit[s1 & 255u];
+        const uint32_t na = (ra >> 24) + (la >> 24), nb = (rb >> 24) + (lb >> 24);
+        const uint32_t ba = (ra & 0xffffffu) | ((la & 0xffffffu) << (ra >> 24));
+        const uint32_t bb = (rb & 0xffffffu) | ((lb & 0xffffffu) << (rb >> 24));
+        piece[p] = (unsigned long long)ba | ((unsigned long long)bb << na);
+        np[p] = na + nb;
+        uint32_t over = (na > 32u || nb > 32u) ? 1u : 0u;
+        if (__builtin_expect(__any(s0 == kTokRunMark), 0)) {
+          if (s0 == kTokRunMark) {   // a run on its own: s1 zeros
+            const uint32_t e = s_prun[min(s1, (uint32_t)kRunTab)];
+            const unsigned long long c260 = s_cl[260];
+            const uint32_t l260 = (uint32_t)(c260 >> 32);
+            if (s1 < (uint32_t)kRunTab) { piece[p] = e & 0xffffffu; np[p] = e >> 24; over = e >> 31; }
+            else { piece[p] = (unsigned long long)(uint32_t)c260 | ((unsigned long long)(s1 - 279u) << l260); np[p] = l260 + 14u; over = l260 == 0u; }
+          }
+        }
+        bad |= over;
+        mybits += np[p];
+      }
+      const uint32_t bincl = wave_scan_add(mybits);
+      const uint32_t iter_bits = (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
+      if (__builtin_expect(!__any(bad) && iter_bits <= kWindow, 1)) {
+        uint32_t pos = sbit + bincl - mybits;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const uint32_t sh = pos & 31u, wi = (pos >> 5) & (kStage - 1);
+          const unsigned long long lo = piece[p] << sh;
+          const uint32_t hi = (uint32_t)((piece[p] >> 33) >> (31u - sh));   // bits 64.. of the shifted piece
+          atomicOr(&stage[wi], (uint32_t)lo);
+          if (__any((uint32_t)(lo >> 32) != 0u)) atomicOr(&stage[(wi + 1) & (kStage - 1)], (uint32_t)(lo >> 32));
+          if (__any(hi != 0u)) atomicOr(&stage[(wi + 2) & (kStage - 1)], hi);
+          pos += np[p];
+        }
+        wave_lds_sync_e();
+        sbit += iter_bits;
+        flush_to(sbit);
+        wave_lds_sync_e();
+        HIMG_REGION_END("tok.iter");
+        continue;
+      }
+      // The reference's tokens spelled out (any code length), sixteen lanes at a time: 128 slots
+      // of at most 78 bits fit the staging window whatever they hold.
+      auto slot_tokens = [&](int k, auto &&fn) {
+        const uint32_t dw = d[k >> 1];
+        const uint32_t s0 = dw & 0xffffu, s1 = dw >> 16;
+        int run = 0, lit = 0;   // what the slot stands for: zeros, then a literal (0: none)
+        if (s0 == kTokRunMark) { if (!(k & 1)) run = (int)s1; }
+        else { const uint32_t sl = (k & 1) ? s1 : s0; lit = (int)(sl & 255u); run = lit ? (int)(sl >> 8) : 0; }
+        if (run) emit_run(run, fn);
+        if (lit) fn(lit, 0, 0);
+      };
+      uint32_t nb = 0;
+#pragma unroll 1
+      for (int k = 0; k < 8; ++k) slot_tokens(k, [&](int sym, int eb, int) { nb += (uint32_t)(s_cl[sym] >> 32) + (uint32_t)eb; });
+      const uint32_t incl = wave_scan_add(nb);
+#pragma unroll 1
+      for (int grp = 0; grp < 4; ++grp) {
+        if ((lane >> 4) == grp) {
+          uint32_t pos = sbit + incl - nb;
+#pragma unroll 1
+          for (int k = 0; k < 8; ++k)
+            slot_tokens(k, [&](int sym, int eb, int ev) {
+              const unsigned long long cl = s_cl[sym];
+              const uint32_t len = (uint32_t)(cl >> 32);
+              put32(pos, (uint32_t)cl, len);
+              pos += len;
+              put32(pos, (uint32_t)ev, (uint32_t)eb);
+              pos += (uint32_t)eb;
+            });
+        }
+        wave_lds_sync_e();
+        flush_to(sbit + (uint32_t)__builtin_amdgcn_readlane((int)incl, 16 * grp + 15));
+        wave_lds_sync_e();
+      }
+      sbit += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+  }
+  lci.done(5);
+  if (lane == 0 && (sbit & 31)) store_word(gw0 + (sbit >> 5), stage[(sbit >> 5) & (kStage - 1)]);
+}
+
+// ---------------------------------------------------------------------------
 // k_padfix (trap T1): the reference packs every block row into ONE scratch
 // buffer that is never cleared, and WriteBits only touches the bits it writes
 // (huffman_enc.cpp:31-50,288,355-358).  The unused high bits of a row's last
@@ -2135,6 +2569,43 @@ static void launch_emit(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t o
   }
 }
 
+// ---- FRES rows through the token stream (k_tok + k_emit_tok) ----
+bool enc_uses_row_tokens(const Geom &g, int batch) {
+  if (g.row_tokens == 0 || g.row_block % 64 != 0) return false;
+  // (a single frame keeps the latency-tuned kernels: its 512 rows are a quarter of the chip's slots)
+  return g.row_tokens > 0 || (long long)g.rows * batch >= 8192;
+}
+// Symbols per token segment: a multiple of the tokeniser's iteration, at most kTokSegs segments per row.
+int enc_tok_seg(const Geom &g) {
+  const int per = (g.row_block + kTokSegs - 1) / kTokSegs;
+  return (per + kTokIter - 1) / kTokIter * kTokIter;
+}
+
+static void launch_tok_rows(const Geom &g, const EncWs &ws, int r0, int r1, int batch, hipStream_t stream, Profiler *prof) {
+  if (r1 <= r0) return;
+  prof_begin(prof, "k_tok", stream);
+  hipLaunchKernelGGL(k_tok, dim3(r1 - r0, batch), dim3(kTokThreads), lds_pad(), stream, g, ws, r0);
+  prof_end(prof, stream);
+}
+
+static void launch_emit_tok(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_stride, const uint32_t *d_sizes,
+                            int r0, int r1, int batch, hipStream_t stream, Profiler *prof) {
+  if (r1 <= r0) return;
+  prof_begin(prof, "k_emit_tok", stream);
+  static const int rows_env = [] { const char *e = getenv("HIMG_EMIT_TOK_ROWS"); return e ? atoi(e) : 0; }();   // (A/B knob)
+  if (rows_env == 4)
+    hipLaunchKernelGGL(k_emit_tok<4>, dim3((r1 - r0 + 3) / 4, batch), dim3(256), 0, stream, g, ws, d_out, out_stride, d_sizes, r0, r1);
+  else
+    hipLaunchKernelGGL(k_emit_tok<kEmitRows>, dim3((r1 - r0 + kEmitRows - 1) / kEmitRows, batch), dim3(64 * kEmitRows), 0,
+                       stream, g, ws, d_out, out_stride, d_sizes, r0, r1);
+  prof_end(prof, stream);
+}
+
+void launch_tok_expand(const Geom &g, const EncWs &ws, int frame, uint8_t *dst, hipStream_t stream) {
+  (void)hipMemsetAsync(dst, 0, (size_t)g.fres_size, stream);
+  hipLaunchKernelGGL(k_tok_expand, dim3((g.rows + 63) / 64), dim3(64), 0, stream, g, ws, frame, dst);
+}
+
 int loop_counts_read_enc(unsigned long long *out) { return loop_counts_read(out); }
 
 void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_frames,
@@ -2191,13 +2662,15 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   if (side) (void)hipEventRecord(ev_join, side);
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
   const bool pix = use_pix_path(g);
+  const bool row_tok = ws.tok != nullptr && enc_uses_row_tokens(g, batch);
   if (pix) {
     launch_pix(g, ws, d_frames, st, d_fmap_lut, 0, g.rows, batch, stream, prof);
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,
                 ws.low, ws.plane_stride, ws.fres_sym, ws.fres_stride, d_fmap_lut, st, 0);
   }
-  launch_tok_hist_rows(g, ws, 0, g.rows, batch, stream, prof);   // FRES rows
+  if (row_tok) launch_tok_rows(g, ws, 0, g.rows, batch, stream, prof);   // FRES rows: slots + histograms
+  else launch_tok_hist_rows(g, ws, 0, g.rows, batch, stream, prof);
   if (side) (void)hipStreamWaitEvent(stream, ev_join, 0);
   HIMG_LAUNCH(k_tree, dim3(2, batch), dim3(kTreeThreads), ws, 0);
   HIMG_LAUNCH(k_span_bits, dim3((nsp + 3) / 4, batch), b256, g, ws, 0, nsp, (uint32_t *)nullptr);
@@ -2212,7 +2685,12 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
     (void)hipEventRecord(ev_fork, stream);
     (void)hipStreamWaitEvent(lres_side, ev_fork, 0);
   }
-  launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof, lres_side);
+  if (row_tok) {
+    launch_emit(g, ws, d_out, out_stride, d_sizes, 0, g.lres_spans, batch, stream, prof, lres_side);
+    launch_emit_tok(g, ws, d_out, out_stride, d_sizes, 0, g.rows, batch, stream, prof);
+  } else {
+    launch_emit(g, ws, d_out, out_stride, d_sizes, 0, nsp, batch, stream, prof, lres_side);
+  }
   if (lres_side) (void)hipEventRecord(ev_join, lres_side);
   HIMG_LAUNCH(k_padfix, dim3((g.rows + 3) / 4, batch), b256, g, ws, d_out, out_stride,
               d_sizes);

@@ -59,9 +59,14 @@ const char *himg_hip_last_error(const himg_hip_ctx *ctx);
  * value -1 = by launch size (the default), 0 / 1 = force off / on:
  *   HIMG_OPT_COUNT_WAVE  FRES row index records by a wavefront per row (batches) instead of
  *                        a workgroup per row (single frames)            [env HIMG_COUNT_WAVE]
- *   HIMG_OPT_EMIT_ROWS   bit packing of FRES rows by a wavefront per row (batches) [env HIMG_EMIT_ROWS] */
+ *   HIMG_OPT_EMIT_ROWS   bit packing of FRES rows by a wavefront per row (batches) [env HIMG_EMIT_ROWS]
+ *   HIMG_OPT_ROW_TOKENS  encoder: FRES rows go from the tokeniser to the bit packer as a stream of 16-bit
+ *                        tokens (k_tok / k_emit_tok) instead of both walking the dense symbol plane (batches);
+ *                        value 2 = on, and the bit packer takes its spelled-out path on every step (a test knob)
+ *                                                                      [env HIMG_ROW_TOKENS] */
 #define HIMG_OPT_COUNT_WAVE 2
 #define HIMG_OPT_EMIT_ROWS 3
+#define HIMG_OPT_ROW_TOKENS 4
 int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value);
 /* The option as the context holds it -- including what it took from the environment when it
  * was created (HIMG_FIX_T2=1): a binding that mirrors an option (the row-sharded decoder's host
@@ -362,6 +367,10 @@ enum {
   HIMG_DBG_LOOP_COUNTS = 14 /* u64 [8][2] trip counts of the marked hot loops since the last read (wavefront
                                iterations, lane iterations), encoder or decoder kernels; only in a library
                                built with -DHIMG_LOOP_COUNTS (tools/dynamic_mix.py), HIMG_ERR_ARG otherwise */
+  ,
+  HIMG_DBG_FRES_TOK_SYM = 15 /* encoder, after a batch encode that went through the token stream (HIMG_OPT_ROW_TOKENS):
+                                u8 [rows][C][64][cols], the slots of k_tok expanded into symbols again; status 7 is
+                                raised when a row's slots do not cover it exactly */
 };
 int himg_hip_debug_read(himg_hip_ctx *ctx, int what, int frame, void *host_dst,
                         size_t dst_bytes, size_t *bytes_written);
