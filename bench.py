@@ -175,11 +175,11 @@ def measure_extras(torch, himg_amd, eng, dev, d_frames, d_out, d_sizes, d_st_e, 
     out["hbm_copy_ceiling_GBs"] = round(2.0 * n * 10 / (time.perf_counter() - t) / 1e9, 1)
     del a, b
     torch.cuda.empty_cache()
-    # The same ceilings from hand-written kernels on a known byte count (tools/micro/hbm_calib:
+    # The same ceilings from hand-written kernels on a known byte count (himg_amd/bin/hbm_calib, built from tools/micro/hbm_calib.hip:
     # 16 bytes per lane, read only / write only / 1:1 copy, best grid of a sweep, buffers far
     # larger than L2 + Infinity Cache): what "HBM-bound" is measured against in DESIGN.md.  A
     # child process (its own HIP context; this one keeps its frames).
-    exe = os.path.join(ROOT, "tools", "micro", "hbm_calib")
+    exe = os.path.join(ROOT, "himg_amd", "bin", "hbm_calib")
     if os.path.exists(exe):
         try:
             r = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=120)
@@ -664,7 +664,7 @@ def main():
         alg_bytes_side = B * W * H * 4.0 + packed_total
         alg_bytes_launch = alg_bytes_side * G / B   # one launch processes G = B/streams frames
         enc_stages = {"k_lowres_avg", "k_lowres_blend", "k_lres_predict", "k_tile_fwd", "k_pix_fwd", "k_lres_summary",
-                      "k_tok_hist", "k_tree", "k_sizes", "k_emit", "k_padfix", "memset"}
+                      "k_tok_hist", "k_tok", "k_tree", "k_sizes", "k_emit", "k_emit_tok", "k_padfix", "memset"}
         # Per encode / decode call of one group (a kernel launched twice per call --
         # k_tok_hist: LRES spans, then FRES rows -- counts with both launches).
         calls = max(1, args.steps * len(engines))
@@ -682,6 +682,7 @@ def main():
             std = (W, H, Q, args.kind) == (4096, 4096, 50, "randtile")
             key = dom.strip("()").split("<")[0]
             pmc = {}
+            dyn_src = None
             if os.path.exists(tpath) and std:
                 tj = json.load(open(tpath))
                 per_frame = {k.split("<")[0]: v for k, v in tj.get("bytes_per_frame", {}).items()}
@@ -697,8 +698,12 @@ def main():
                 pmc = tj.get("valu", {})
                 # The three kernels whose hot loops carry trip counters (tools/dynamic_mix.py): the
                 # class-weighted cost taken over what they EXECUTE instead of over their static mix.
-                dpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_dynamic_mix.json")
-                if os.path.exists(dpath):
+                # (the newest round's file: the mix must describe the kernels that were timed)
+                import glob
+                dfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_dynamic_mix.json")))
+                dpath = dfiles[-1] if dfiles else ""
+                dyn_src = os.path.basename(dpath) if dpath else None
+                if dpath:
                     for k, v in json.load(open(dpath)).get("kernels", {}).items():
                         if k in pmc:
                             pmc[k]["mean_cost_per_valu_dynamic"] = v["mean_cost_per_valu_dynamic"]
@@ -748,11 +753,11 @@ def main():
                                        "1024 SIMDs need to ISSUE that count -- at the guide's 2 cycles per wave64 "
                                        "instruction (SIMD-32) and at the kernel's class-weighted measured cost "
                                        "(plain VOP1/VOP2 ~2.2, VOP3 / packed / DPP / compares ~4.1 cycles: "
-                                       "profiles/r03_valu_rate.txt, profiles/r04_isa_mix.json); "
+                                       "profiles/r03_valu_rate.txt, the newest profiles/rNN_isa_mix.json); "
                                        "issue_frac_dynamic_mix where the kernel's hot loops carry trip counters: "
                                        "the cost weighted by what is EXECUTED (measured trip counts x each loop's "
-                                       "hot path, profiles/r04_dynamic_mix.json) instead of by the static mix",
-                               "source": traffic_src, "kernels": pmc} if pmc else None),
+                                       "hot path, `dynamic_mix_source`) instead of by the static mix",
+                               "source": traffic_src, "dynamic_mix_source": dyn_src, "kernels": pmc} if pmc else None),
             "stages_ms": {k: round(v["ms"], 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if world == 1 and not args.no_extras:

@@ -133,7 +133,7 @@ def build_unit_checks(verbose=False):
     os.makedirs(BINDIR, exist_ok=True)
     # (the HBM calibration kernels bench.py's extras and tools/calibrate_pmc.sh run)
     cal_src = os.path.join(ROOT, "tools", "micro", "hbm_calib.hip")
-    cal_exe = os.path.join(ROOT, "tools", "micro", "hbm_calib")
+    cal_exe = os.path.join(BINDIR, "hbm_calib")   # (built here, never taken from the tree: the binary matches the source and the box's ROCm)
     if _stale(cal_exe, [cal_src]):
         subprocess.run([_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", cal_src, "-o", cal_exe], check=True)
     src = os.path.join(ROOT, "tools", "micro", "tile_plane_check.hip")

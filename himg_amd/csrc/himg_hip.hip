@@ -1205,7 +1205,12 @@ static int decode_core(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_s
       if (ctx->hp_index) hipHostFree(ctx->hp_index);
       ctx->hp_index = nullptr;
       ctx->hp_index_cap = 0;
-      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->hp_index, round_up(n_idx * 4, 4096), hipHostMallocDefault));
+      // (An error return from here on first waits for the uploads above: the caller may free or
+      // overwrite `packed` the moment this call returns.)
+      if (hipHostMalloc((void **)&ctx->hp_index, round_up(n_idx * 4, 4096), hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamSynchronize(nullptr);
+        return fail(ctx, HIMG_ERR_HIP, "pinned index allocation failed");
+      }
       ctx->hp_index_cap = round_up(n_idx * 4, 4096) / 4;
     }
     uint32_t first = 0;
@@ -1220,7 +1225,10 @@ static int decode_core(himg_hip_ctx *ctx, const uint8_t *packed, size_t packed_s
   if (rc == -1)
     rc = himg_hip_decode_device(ctx, ctx->h_in.p, in_cap, &sz32, 1, *W, *H, *C, ctx->h_out.p,
                                 (int32_t *)ctx->h_status.p, nullptr);
-  if (rc) return rc;
+  if (rc) {
+    (void)hipStreamSynchronize(nullptr);   // the stream / index uploads may still be reading the caller's and the pinned buffer
+    return rc;
+  }
   int32_t st = 0;
   HIP_TRY(ctx, hipMemcpy(&st, ctx->h_status.p, 4, hipMemcpyDeviceToHost));
   if (st) {

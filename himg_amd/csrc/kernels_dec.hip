@@ -2973,8 +2973,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     q.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
     q.tot = po[kDecThreads]; q.endrel = po[kDecThreads + 1]; q.valid = po[kDecThreads + 2]; q.rounds = po[kDecThreads + 3];
     const uint32_t off_r = ws.row_off[ri], len_r = ws.row_len[ri];
+    // The row before ends by reading sh->err / sh->endbit with no barrier behind the reads: a slow
+    // wavefront must not meet this row's reset while it still decides that one.
+    if (i > 0) __syncthreads();
     if (tid == 0) { sh->err = 0; sh->endbit = ~0ull; }
-    __syncthreads();   // (also: the row before is done with sh)
+    __syncthreads();
     uint32_t *st = ws.stats + ((size_t)f * (g.rows + 1) + r + 1) * 8;
     const int rc = decode_row_recorded(p, sizes[f], off_r, len_r, (uint32_t)g.row_block, tb, sh, sym0 + (size_t)i * rb16, st, q);
     if (rc >= 0) return rc;

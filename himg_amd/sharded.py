@@ -360,12 +360,18 @@ class ShardedDecoder:
          WHILE rank 0 indexes the block rows once (the serial walk over the row size
          headers: microseconds on the host for a stream in host memory, 1.3 ms of
          dependent loads on its GPU otherwise)
-        broadcast   the row index (offsets and lengths of all block rows)
-        send/recv   to every other rank ONLY the bytes of its own block rows, each over
-                    that peer's own link
+        send/recv   to every other rank the index SLICE and ONLY the bytes of its own block
+                    rows, each over that peer's own link, the moment the walk has passed them
+                    (the walk runs in the ranks' row ranges; a stream in host memory is indexed
+                    at once)
       -> every rank decodes its rows (himg_hip_decode_rows_after_head_device) from a
          buffer that holds just the head and its own rows at their stream offsets; no
          rank repeats the header walk.  All buffers are allocated once.
+    WHICH rows a rank decodes: NOT shard_rows(rows, world)[rank] (the encoder's split).  The ranges
+    are served in the order the walk reaches them, so rank 0 -- which walks -- takes the LAST
+    non-empty range and rank r >= 1 the (r - 1)-th from the top: `range_of_rank[rank]` indexes
+    `parts`; `r0, r1` (block rows) and `y0, y1` (pixel rows) of THIS rank are attributes.  A caller of
+    decode(..., gather=False) places its rows at y0 (decode_sharded returns them with the range).
     `trace` of the last call lists the steps in the order this rank took them (the tests
     pin that the head phase is launched before the row index is known).
     `bytes_from_rank0` of the last call = what left rank 0 (the tests bound it by
@@ -399,6 +405,10 @@ class ShardedDecoder:
         dev = self.dev
         self.d_rows = torch.empty((max(y1 - y0, 1), width, channels), dtype=torch.uint8, device=dev)
         self.d_status = torch.zeros(2, dtype=torch.int32, device=dev)
+        # Per-range verdicts of the header walk: allocated ONCE (the walk, on the engine and side
+        # streams, writes every entry it reports; a fill on the current stream behind _fork() could
+        # land on top of an early range's verdict).
+        self.d_rstat = torch.zeros(16, dtype=torch.int32, device=dev)
         self.d_index = torch.zeros(2 * self.rows + 2, dtype=torch.int32, device=dev)   # offsets, lengths, first
         self.meta = torch.zeros(4 + 2 * self.rows, dtype=torch.int64, device=self.comm)
         self.d_packed = None      # grown on demand; the bytes behind the stream are zeroed per decode (_buffer)
@@ -570,7 +580,6 @@ class ShardedDecoder:
             # The header walk in the row ranges of the ranks, in the order they are served: a
             # range's slice leaves as soon as the walk has passed it.
             ends = [self.parts[self.range_of_rank[r]][1] for r in self.serve_order] + [rows]
-            self.d_rstat = torch.zeros(16, dtype=torch.int32, device=self.dev)
             self.eng.decode_walk_ranges_device(buf, size, self.W, self.H, self.C, ends, self.d_index,
                                                self.d_index[2 * rows:], self.d_rstat, self._s())
             self.trace.append("walk_started")
@@ -725,7 +734,11 @@ def decode_sharded(engine, packed, width, height, channels=4, group=None, gather
     (ShardedDecoder; the decoder and its buffers are kept on `engine` between calls).
     Returns (ok, pixels): `ok` is the AND over the ranks (a stream the reference rejects
     is rejected); with gather=True rank 0 gets the whole H x W x C image (None
-    elsewhere), otherwise every rank gets its own pixel rows as a tensor.
+    elsewhere), otherwise every rank gets the pixel rows it decoded as a tensor -- rows
+    [dec.y0, dec.y1) of the picture, where dec = engine._sharded_decoders[...] / the
+    ShardedDecoder; NOT the encoder's shard_rows(rows, world)[rank] split: rank 0 holds the
+    LAST non-empty range, rank r >= 1 the (r - 1)-th (see ShardedDecoder; sharded_range()
+    below returns a rank's (y0, y1) without a decoder).
     `engine` provides decode_index_device / decode_rows_indexed_device
     (himg_amd.Engine); `comm_device` is where the process group can move tensors
     (CUDA for nccl/RCCL, "cpu" for gloo)."""
@@ -739,3 +752,16 @@ def decode_sharded(engine, packed, width, height, channels=4, group=None, gather
         dec = cache[key] = ShardedDecoder(engine, width, height, channels, group, device, comm_device, stream,
                                           fix_t2=fix_t2)
     return dec.decode(packed, gather)
+
+
+def sharded_range(height, world, rank):
+    """(y0, y1): the pixel rows rank `rank` of `world` holds after decode_sharded(..., gather=False)
+    of a frame `height` pixels high -- the assignment ShardedDecoder makes (rank 0: the last
+    non-empty range of shard_rows, rank r >= 1: the (r - 1)-th; empty ranges to the last ranks)."""
+    rows = (height + 7) // 8
+    parts = shard_rows(rows, world)
+    nonempty = [k for k, (a, b) in enumerate(parts) if b > a]
+    empty = [k for k, (a, b) in enumerate(parts) if b <= a]
+    order = ([nonempty[-1]] + nonempty[:-1] + empty) if nonempty else list(range(world))
+    r0, r1 = parts[order[rank]]
+    return min(8 * r0, height), min(8 * r1, height)

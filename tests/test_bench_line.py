@@ -59,7 +59,7 @@ def test_single_gpu_line_with_extras():
     ex = d["extras"]
     assert ex["hbm_copy_ceiling_GBs"] > 500
     assert ex["single_frame_latency_ms"]["encode"] > 0 and ex["single_frame_latency_ms"]["decode"] > 0
-    if os.path.exists(os.path.join(ROOT, "tools", "micro", "hbm_calib")):
+    if os.path.exists(os.path.join(ROOT, "himg_amd", "bin", "hbm_calib")):
         k = ex["hbm_ceiling_kernels_GBs"]
         assert k["read_only"] > 1000 and k["write_only"] > 1000 and k["copy_read_plus_write"] > 1000
 

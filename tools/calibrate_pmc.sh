@@ -7,11 +7,11 @@ set -u
 OUT=${1:-gpurun_out/calib}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
-"$ROOT/tools/micro/hbm_calib" 4 > "$ROOT/$OUT/hbm_calib.json" 2> "$ROOT/$OUT/hbm_calib.err"
+"$ROOT/himg_amd/bin/hbm_calib" 4 > "$ROOT/$OUT/hbm_calib.json" 2> "$ROOT/$OUT/hbm_calib.err"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$ROOT/$OUT/$c" -- \
-      "$ROOT/tools/micro/hbm_calib" 2 > "$ROOT/$OUT/$c.log" 2>&1
+      "$ROOT/himg_amd/bin/hbm_calib" 2 > "$ROOT/$OUT/$c.log" 2>&1
   echo "$c exit=$?"
 done
 cd "$ROOT"
