@@ -2304,15 +2304,24 @@ __global__ __launch_bounds__(64 * ROWS) void k_emit_tok(Geom g, EncWs ws, uint8_
       const uint32_t iter_bits = (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
       if (__builtin_expect(!__any(bad) && iter_bits <= kWindow, 1)) {
         uint32_t pos = sbit + bincl - mybits;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        auto place = [&](unsigned long long v, uint32_t n) {   // a piece of n <= 64 bits at `pos`
           const uint32_t sh = pos & 31u, wi = (pos >> 5) & (kStage - 1);
-          const unsigned long long lo = piece[p] << sh;
-          const uint32_t hi = (uint32_t)((piece[p] >> 33) >> (31u - sh));   // bits 64.. of the shifted piece
+          const unsigned long long lo = v << sh;
+          const uint32_t hi = (uint32_t)((v >> 33) >> (31u - sh));   // bits 64.. of the shifted piece
           atomicOr(&stage[wi], (uint32_t)lo);
           if (__any((uint32_t)(lo >> 32) != 0u)) atomicOr(&stage[(wi + 1) & (kStage - 1)], (uint32_t)(lo >> 32));
           if (__any(hi != 0u)) atomicOr(&stage[(wi + 2) & (kStage - 1)], hi);
-          pos += np[p];
+          pos += n;
+        };
+        // Four slots are ~23 bits on average: where every lane's two quads fit 64 bits the pieces
+        // are joined once more -- half the placements (and a third fewer LDS atomics).
+        const uint32_t q0 = np[0] + np[1], q1 = np[2] + np[3];
+        if (!__any(max(q0, q1) > 64u)) {
+          place(piece[0] | (np[0] < 64u ? piece[1] << np[0] : 0ull), q0);
+          place(piece[2] | (np[2] < 64u ? piece[3] << np[2] : 0ull), q1);
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) place(piece[p], np[p]);
         }
         wave_lds_sync_e();
         sbit += iter_bits;
