@@ -281,7 +281,7 @@ class Engine:
 
     def get_option(self, option):
         """himg_hip_get_option: the option as the context holds it (names as in set_option)."""
-        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3, "row_tokens": 4}[option] if isinstance(option, str) else int(option)
+        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3, "row_tokens": 4, "front": 5}[option] if isinstance(option, str) else int(option)
         v = C.c_int(0)
         self._check(lib().himg_hip_get_option(self._ctx, opt, C.byref(v)), "get_option")
         return v.value
@@ -289,7 +289,7 @@ class Engine:
     def set_option(self, option, value):
         """himg_hip_set_option; option names: "fix_t2", and the kernel-variant selectors
         "count_wave" / "emit_rows" (-1 = by launch size, 0 / 1 = force; see include/himg_hip.h)."""
-        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3, "row_tokens": 4}[option] if isinstance(option, str) else int(option)
+        opt = {"fix_t2": 1, "count_wave": 2, "emit_rows": 3, "row_tokens": 4, "front": 5}[option] if isinstance(option, str) else int(option)
         self._check(lib().himg_hip_set_option(self._ctx, opt, int(value)), "set_option")
         if opt == 1:
             self.fix_t2 = bool(value)   # (the row-sharded decoder's host index follows it, sharded.py)

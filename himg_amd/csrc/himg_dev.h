@@ -38,6 +38,7 @@ struct Geom {
   int wide_q;                // decoder, rows wider than the LDS: the host's estimate says a quarter sub-sequence of a row
                              // (1/4096 of its payload) fits k_row_count_q's staging buffer -- that kernel counts
   int emit_rows;             // encoder: k_emit_t<8> (a wavefront per row) instead of a workgroup per row
+  int front;                 // encoder: k_front (averages + low-res plane + pixel stage in one pass over the pixels)
   int row_tokens;            // encoder: FRES rows as a token stream (k_tok -> k_emit_tok) instead of k_tok_hist / k_emit_t
                              // over the dense symbol plane twice
   long long frame_bytes;     // W*H*stride

@@ -118,6 +118,7 @@ struct himg_hip_ctx {
   int lres_serial = 0;     // HIMG_FORCE_LRES_SERIAL=1: test knob, see Geom::lres_serial
   int count_wave = -1, emit_rows = -1;   // HIMG_OPT_COUNT_WAVE / _EMIT_ROWS (-1: by launch size)
   int row_tokens = -1;                   // HIMG_OPT_ROW_TOKENS (-1: by launch size)
+  int front = -1;                        // HIMG_OPT_FRONT (-1: by launch size)
   // Batched host API: H2D of frame i+1, kernels of frame i and D2H of frame i-1 overlap
   // on three streams; staging is double buffered.
   struct Pipe {
@@ -220,7 +221,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->max_sub = 4096;
   g->lead_bits = 128;
   g->lres_serial = 0;
-  g->count_wave = g->emit_rows = g->row_tokens = -1;
+  g->count_wave = g->emit_rows = g->row_tokens = g->front = -1;
   g->wide_q = 0;
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
@@ -259,6 +260,7 @@ extern "C" int himg_hip_create(int device, himg_hip_ctx **out) {
   if (const char *e = std::getenv("HIMG_COUNT_WAVE")) ctx->count_wave = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_EMIT_ROWS")) ctx->emit_rows = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_ROW_TOKENS")) ctx->row_tokens = atoi(e) ? 1 : 0;
+  if (const char *e = std::getenv("HIMG_FRONT")) ctx->front = atoi(e) ? 1 : 0;
   if (const char *e = std::getenv("HIMG_LEAD_BITS")) {
     const int v = std::atoi(e);
     if (v >= 0 && v <= 4096) ctx->lead_bits = v;
@@ -362,6 +364,7 @@ extern "C" int himg_hip_get_option(himg_hip_ctx *ctx, int option, int *value) {
   if (option == HIMG_OPT_COUNT_WAVE) { *value = ctx->count_wave; return HIMG_OK; }
   if (option == HIMG_OPT_EMIT_ROWS) { *value = ctx->emit_rows; return HIMG_OK; }
   if (option == HIMG_OPT_ROW_TOKENS) { *value = ctx->row_tokens; return HIMG_OK; }
+  if (option == HIMG_OPT_FRONT) { *value = ctx->front; return HIMG_OK; }
   return fail(ctx, HIMG_ERR_ARG, "unknown option");
 }
 
@@ -371,6 +374,7 @@ extern "C" int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value) {
   const int tri = value < 0 ? -1 : (value ? 1 : 0);
   if (option == HIMG_OPT_COUNT_WAVE) { ctx->count_wave = tri; return HIMG_OK; }
   if (option == HIMG_OPT_EMIT_ROWS) { ctx->emit_rows = tri; return HIMG_OK; }
+  if (option == HIMG_OPT_FRONT) { ctx->front = tri; return HIMG_OK; }
   if (option == HIMG_OPT_ROW_TOKENS) { ctx->row_tokens = value == 2 ? 2 : tri; return HIMG_OK; }   // (2: on + k_emit_tok's spelled-out path, a test knob)
   return fail(ctx, HIMG_ERR_ARG, "unknown option");
 }
@@ -647,6 +651,7 @@ extern "C" int himg_hip_encode_device(himg_hip_ctx *ctx, const void *d_frames, i
   ctx->last_stream = s;
   g.emit_rows = ctx->emit_rows;
   g.row_tokens = ctx->row_tokens;
+  g.front = ctx->front;
   launch_encode(g, ctx->enc_ws, batch, (const uint8_t *)d_frames, (uint8_t *)d_out, out_stride,
                 d_sizes, sc, st, lt, (const uint8_t *)ctx->fmap_lut.p, s, &ctx->prof,
                 ctx->use_side ? ctx->side_enc : nullptr, ctx->ev_fork_e, ctx->ev_join_e);

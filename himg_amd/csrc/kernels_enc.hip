@@ -696,6 +696,294 @@ __global__ __launch_bounds__(kPixThreads, 2) void k_pix_fwd(Geom g, const uint8_
 }
 
 // ---------------------------------------------------------------------------
+// k_front: box averages, low-res plane AND pixel stage in one pass over the pixels (batches of
+// full RGBA8 frames, rows of at most 512 tiles) -- k_lowres_avg + k_lowres_blend + k_pix_fwd
+// read every pixel twice; here a workgroup walks DOWN a chunk of block rows, one lane per tile of
+// the row's width, and a pixel is read from HBM once:
+//   step t   the tile row t arrives in registers (requested during the step before);
+//            its 5x5 / 3x5 / 5x3 / 3x3 corner sums give, with the row above's, the 8x8 windows at
+//            offset -3 (downsampled.cpp:76-96): box averages of row t, exchanged through LDS;
+//            low-res samples of row t (downsampled.cpp:98-113) from the averages of rows t - 1, t;
+//            THEN tile row t - 1 is transformed (it needed the low-res rows t - 1 and t), its pixels
+//            read from the wavefront's 16 KiB parking slot in LDS; once the second channel pair has
+//            read them, row t is parked in the same slot and row t + 1 is requested: the loads fly
+//            under the second pair's WHT / quantise / stores.
+// A chunk starts two tile rows above its first (their sums only) -- 3 % more pixel reads at 64 rows
+// per chunk.  Same arithmetic as k_pix_fwd (pix_pair, lowres_quads_e, packed WHT, group-tested
+// companding), same symbols; avg / low planes are written for the LRES branch and the tests.
+// ---------------------------------------------------------------------------
+constexpr int kFrontExch = 5;   // dwords per tile in the exchange area: right-column sums of both pairs (top, bottom), averages
+
+// Corner sums of one tile for one channel pair: TL = rows 0..4 x columns 0..4, TR = rows 0..4 x
+// columns 5..7, BL / BR = rows 5..7 (the window of tile (u, v) is x in [8u-3, 8u+4], y alike).
+template <bool YCBCR, int PAIR>
+__device__ __forceinline__ void front_sums(const uint32_t (&px)[64], pk16 &tl, pk16 &tr, pk16 &bl, pk16 &br) {
+  const pk16 z = {0, 0};
+  tl = tr = bl = br = z;
+#pragma unroll
+  for (int y = 0; y < 8; ++y)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const pk16 v = pix_pair<YCBCR, PAIR>(px[y * 8 + x]);
+      if (y < 5) { if (x < 5) tl += v; else tr += v; }
+      else { if (x < 5) bl += v; else br += v; }
+    }
+}
+
+// Channel bytes (c0..c3 in a dword) <-> the two packed pairs of pix_pair.
+template <bool YCBCR>
+__device__ __forceinline__ uint32_t front_pack_channels(uint32_t p0x, uint32_t p0y, uint32_t p1x, uint32_t p1y) {
+  // YCBCR: pair 0 = (Cr, Cb) = channels (2, 1), pair 1 = (Y, A) = channels (0, 3); else (0, 2), (1, 3)
+  return YCBCR ? (p1x | (p0y << 8) | (p0x << 16) | (p1y << 24)) : (p0x | (p1x << 8) | (p0y << 16) | (p1y << 24));
+}
+
+// low = blend of the averages at (t-1, t) x (u-1, u) (downsampled.cpp:98-113), four channel bytes at once.
+__device__ __forceinline__ uint32_t front_blend(uint32_t a11, uint32_t a12, uint32_t a21, uint32_t a22) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t x11 = (a11 >> (8 * c)) & 255u, x12 = (a12 >> (8 * c)) & 255u;
+    const uint32_t x21 = (a21 >> (8 * c)) & 255u, x22 = (a22 >> (8 * c)) & 255u;
+    const uint32_t b1 = (x11 + 15u * x12 + 8u) >> 4, b2 = (x21 + 15u * x22 + 8u) >> 4;
+    out |= ((b1 + 15u * b2 + 8u) >> 4) << (8 * c);
+  }
+  return out;
+}
+
+// (One argument block: the quantiser's tables are read through the kernel-argument segment at
+// offsetof(FrontArgs, pq) -- see the walk below.)
+struct FrontArgs {
+  Geom g;
+  const uint8_t *frames;
+  uint8_t *avg, *low;
+  size_t plane_stride;
+  uint8_t *fres_sym;
+  size_t fres_stride;
+  const uint8_t *fmap_lut;
+  int chunk_rows;
+  PixQuant pq;
+};
+typedef const __attribute__((address_space(4))) uint32_t *KargWords;
+
+template <bool YCBCR, int COLS>
+__global__ __launch_bounds__(512) void k_front(FrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Geom &g = a.g;
+  const uint8_t *frames = a.frames, *fmap_lut = a.fmap_lut;
+  uint8_t *avg = a.avg, *low = a.low, *fres_sym = a.fres_sym;
+  const size_t plane_stride = a.plane_stride, fres_stride = a.fres_stride;
+  const int chunk_rows = a.chunk_rows;
+  const int cols = COLS ? COLS : g.cols;
+  const int nt = (int)blockDim.x;                       // 64 x wavefronts per row
+  uint4 *park = reinterpret_cast<uint4 *>(smem);        // [wave][16][64]: the tile row in waiting
+  uint8_t *s_lut = smem + (size_t)nt * 256;             // (nt / 64 waves x 16 KiB)
+  uint32_t *s_ex = reinterpret_cast<uint32_t *>(s_lut + kPixLut);   // [kFrontExch][nt]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int f = blockIdx.y;
+  const int v0 = (int)blockIdx.x * chunk_rows, v1 = min(v0 + chunk_rows, g.rows);
+  for (int k = tid; k < kPixLut / 16; k += nt)
+    reinterpret_cast<uint4 *>(s_lut)[k] = reinterpret_cast<const uint4 *>(fmap_lut)[k];
+  const int u = tid;
+  const bool valid = u < cols;
+  const int uc = valid ? u : cols - 1;
+  const uint8_t *img = frames + (long long)f * g.frame_bytes;
+  const size_t pitch = (size_t)g.W * 4;
+  uint4 *slot = park + (size_t)wv * 16 * 64 + lane;     // + k * 64: piece k (pixel row k >> 1, half k & 1)
+  const __amdgpu_buffer_rsrc_t sym_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      fres_sym + (size_t)f * fres_stride, 0, (int)g.fres_size, 0x00020000);
+  uint8_t *avg_f = avg + (size_t)f * plane_stride, *low_f = low + (size_t)f * plane_stride;
+  const size_t chan = (size_t)g.rows * cols;
+
+  uint32_t px[64];
+  auto load_row = [&](int t) {
+    const uint8_t *row0 = img + ((long long)(8 * t) * g.W + 8 * uc) * 4;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(row0 + (size_t)y * pitch);
+      const uint4 q0 = rp[0], q1 = rp[1];
+      px[y * 8 + 0] = q0.x; px[y * 8 + 1] = q0.y; px[y * 8 + 2] = q0.z; px[y * 8 + 3] = q0.w;
+      px[y * 8 + 4] = q1.x; px[y * 8 + 5] = q1.y; px[y * 8 + 6] = q1.z; px[y * 8 + 7] = q1.w;
+    }
+  };
+  auto park_row = [&]() {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      uint4 q;
+      q.x = px[k * 4 + 0]; q.y = px[k * 4 + 1]; q.z = px[k * 4 + 2]; q.w = px[k * 4 + 3];
+      slot[k * 64] = q;
+    }
+  };
+
+  const int t_begin = max(v0 - 2, 0), t_end = v1;   // rows whose sums this chunk needs (t_end == rows: nothing to load)
+  load_row(t_begin);
+  const pk16 zero2 = {0, 0};
+  pk16 bl_prev[2] = {zero2, zero2}, brl_prev[2] = {zero2, zero2};   // BL(u, t-1), BR(u-1, t-1)
+  uint32_t avg_prev[3] = {0, 0, 0};    // averages of row t - 1 at u - 1, u, u + 1 (clipped)
+  uint32_t low_prev[2] = {0, 0};       // low-res row t - 1 at u, u2
+  __syncthreads();                     // (the LUT)
+
+  for (int t = t_begin; t <= t_end; ++t) {
+    // The quantiser's 384 words are scalar loads from the kernel arguments AT THEIR USES, as in
+    // k_pix_fwd: through a pointer the compiler cannot see through, or it hoists all of them out
+    // of this loop (370 scalar registers spilled).
+    KargWords qw = (KargWords)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() +
+                               offsetof(FrontArgs, pq));
+    asm volatile("" : "+s"(qw));
+    const bool have = t < g.rows;
+    uint32_t low_cur[2] = {low_prev[0], low_prev[1]};   // (t == rows: the row below the last one is the last one)
+    if (have) {
+      // ---- corner sums of tile row t, windows, box averages ----
+      pk16 tl[2], tr[2], bl[2], br[2];
+      front_sums<YCBCR, 0>(px, tl[0], tr[0], bl[0], br[0]);
+      front_sums<YCBCR, 1>(px, tl[1], tr[1], bl[1], br[1]);
+      s_ex[0 * nt + tid] = __builtin_bit_cast(uint32_t, tr[0]);
+      s_ex[1 * nt + tid] = __builtin_bit_cast(uint32_t, tr[1]);
+      s_ex[2 * nt + tid] = __builtin_bit_cast(uint32_t, br[0]);
+      s_ex[3 * nt + tid] = __builtin_bit_cast(uint32_t, br[1]);
+      __syncthreads();
+      pk16 trl[2] = {zero2, zero2}, brl[2] = {zero2, zero2};   // of the tile to the left (none at u = 0)
+      if (u > 0) {
+        trl[0] = __builtin_bit_cast(pk16, s_ex[0 * nt + tid - 1]); trl[1] = __builtin_bit_cast(pk16, s_ex[1 * nt + tid - 1]);
+        brl[0] = __builtin_bit_cast(pk16, s_ex[2 * nt + tid - 1]); brl[1] = __builtin_bit_cast(pk16, s_ex[3 * nt + tid - 1]);
+      }
+      const upk16 w0 = __builtin_bit_cast(upk16, (pk16)(tl[0] + trl[0] + bl_prev[0] + brl_prev[0]));
+      const upk16 w1 = __builtin_bit_cast(upk16, (pk16)(tl[1] + trl[1] + bl_prev[1] + brl_prev[1]));
+      // (sum + cnt / 2) / cnt with cnt = (u ? 8 : 5) * (t ? 8 : 5): a 24-bit multiply by 2^22 / cnt
+      // rounded up, exact for sums up to 255 * 64.
+      const uint32_t cnt = (u ? 8u : 5u) * (t ? 8u : 5u);
+      const uint32_t half = cnt >> 1, mul = cnt == 64u ? 65536u : cnt == 40u ? 104858u : 167773u;
+      auto mean = [&](uint32_t sum) { return __umul24(sum + half, mul) >> 22; };
+      const uint32_t a_cur = front_pack_channels<YCBCR>(mean(w0.x), mean(w0.y), mean(w1.x), mean(w1.y));
+      s_ex[4 * nt + tid] = a_cur;
+      bl_prev[0] = bl[0]; bl_prev[1] = bl[1];
+      brl_prev[0] = brl[0]; brl_prev[1] = brl[1];
+      __syncthreads();
+      const uint32_t a_l = s_ex[4 * nt + (u > 0 ? tid - 1 : tid)];
+      const uint32_t a_r = s_ex[4 * nt + min(u + 1, cols - 1)];
+      if (t == 0) { avg_prev[0] = a_l; avg_prev[1] = a_cur; avg_prev[2] = a_r; }   // (row -1 reads as row 0)
+      low_cur[0] = front_blend(avg_prev[0], avg_prev[1], a_l, a_cur);
+      low_cur[1] = front_blend(avg_prev[1], avg_prev[2], a_cur, a_r);
+      if (u == cols - 1) low_cur[1] = low_cur[0];
+      avg_prev[0] = a_l; avg_prev[1] = a_cur; avg_prev[2] = a_r;
+      if (valid && t >= v0 && t < v1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          avg_f[(size_t)c * chan + (size_t)t * cols + u] = (uint8_t)(a_cur >> (8 * c));
+          low_f[(size_t)c * chan + (size_t)t * cols + u] = (uint8_t)(low_cur[0] >> (8 * c));
+        }
+      }
+      __syncthreads();   // (everybody has read the exchange area: the next step may write it)
+    }
+    const int v = t - 1;
+    bool requested = false;   // has tile row t + 1 been requested (and row t parked) inside the transform?
+    if (v >= v0 && v < v1) {
+      // ---- transform of tile row v: pixels from the parking slot, low-res rows v (low_prev) and v + 1 (low_cur) ----
+      uint32_t lr0[4], lr8[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        lr0[c] = ((low_prev[0] >> (8 * c)) & 255u) | (((low_prev[1] >> (8 * c)) & 255u) << 8);
+        lr8[c] = ((low_cur[0] >> (8 * c)) & 255u) | (((low_cur[1] >> (8 * c)) & 255u) << 8);
+      }
+      const uint32_t row_off = (uint32_t)v * (uint32_t)g.row_block;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int cA = YCBCR ? (pr == 0 ? 2 : 0) : (pr == 0 ? 0 : 1);
+        const int cB = YCBCR ? (pr == 0 ? 1 : 3) : (pr == 0 ? 2 : 3);
+        pk16 b[64];
+        {
+          uint32_t LA[2][8], LB[2][8];
+          lowres_quads_e(lr0[cA], lr8[cA], LA);
+          lowres_quads_e(lr0[cB], lr8[cB], LB);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const uint4 q = slot[k * 64];
+            const uint32_t p4[4] = {q.x, q.y, q.z, q.w};
+            const int y = k >> 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int x = (k & 1) * 4 + j;
+              const uint32_t sel = 0x0c000c00u | (uint32_t)(y & 3) | ((uint32_t)(4 + (y & 3)) << 16);
+              const pk16 lo = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(LB[y >> 2][x], LA[y >> 2][x], sel));
+              const pk16 pv = pr == 0 ? pix_pair<YCBCR, 0>(p4[j]) : pix_pair<YCBCR, 1>(p4[j]);
+              b[y * 8 + x] = pv - lo;
+            }
+          }
+        }
+        if (pr == 1 && have) {
+          // The slot has been read for the last time: tile row t takes it, and row t + 1 is requested --
+          // the loads fly under this pair's WHT, quantiser and stores.
+          park_row();
+          if (t + 1 <= t_end && t + 1 < g.rows) load_row(t + 1);
+          requested = true;
+        }
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+          wht8_pk(b[y * 8 + 0], b[y * 8 + 1], b[y * 8 + 2], b[y * 8 + 3], b[y * 8 + 4], b[y * 8 + 5],
+                  b[y * 8 + 6], b[y * 8 + 7]);
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          wht8_pk(b[x], b[8 + x], b[16 + x], b[24 + x], b[32 + x], b[40 + x], b[48 + x], b[56 + x]);
+        const uint32_t offA = row_off + (uint32_t)(cA * 64 * cols), offB = row_off + (uint32_t)(cB * 64 * cols);
+        const int qt = (YCBCR && pr == 0) ? 1 : 0;
+        // (quantise / compand / store in groups of coefficients: see k_pix_fwd)
+        auto group = [&](auto i0c, auto nc) {
+          constexpr int I0 = decltype(i0c)::value, N = decltype(nc)::value;
+          pk16 q[N];
+          upk16 top = {0, 0};
+          for_seq<N>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, i = I0 + k, pos = kScan[i];
+            const pk16 x = b[pos];
+            const pk16 fifteen = {15, 15};
+            const pk16 sign = x >> fifteen;
+            const pk16 rr = __builtin_bit_cast(pk16, qw[(0 * 2 + qt) * 64 + i]), kk = __builtin_bit_cast(pk16, qw[(1 * 2 + qt) * 64 + i]);
+            const pk16 ss = __builtin_bit_cast(pk16, qw[(2 * 2 + qt) * 64 + i]);
+            q[k] = (sign * kk + x + rr) >> ss;
+            const upk16 fifty = {50, 50};
+            top = __builtin_elementwise_max(top, (upk16)(__builtin_bit_cast(upk16, q[k]) + fifty));
+          });
+          const upk16 hundred = {100, 100};
+          const uint32_t over = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(top, hundred));
+          if (__builtin_expect(__any(over != 0u), 0)) {
+            for_seq<N>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              const pk16 fifteen = {15, 15};
+              const pk16 sign = q[k] >> fifteen;
+              const pk16 mag = (q[k] ^ sign) - sign;
+              const uint32_t ma = min((uint32_t)(uint16_t)mag.x, (uint32_t)(kPixLut - 1));
+              const uint32_t mb = min((uint32_t)(uint16_t)mag.y, (uint32_t)(kPixLut - 1));
+              pk16 code;
+              code.x = (short)s_lut[ma];
+              code.y = (short)s_lut[mb];
+              q[k] = (code ^ sign) - sign;
+            });
+          }
+          if (valid) {
+            for_seq<N>([&](auto kc) {
+              constexpr int k = decltype(kc)::value, i = I0 + k;
+              __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q[k].x, sym_rsrc, (uint32_t)uc, offA + (uint32_t)(i * cols), 0);
+              __builtin_amdgcn_raw_buffer_store_b8((uint8_t)q[k].y, sym_rsrc, (uint32_t)uc, offB + (uint32_t)(i * cols), 0);
+            });
+          }
+        };
+        using std::integral_constant;
+        group(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+        group(integral_constant<int, 4>{}, integral_constant<int, 4>{});
+        group(integral_constant<int, 8>{}, integral_constant<int, 4>{});
+        group(integral_constant<int, 12>{}, integral_constant<int, 4>{});
+        group(integral_constant<int, 16>{}, integral_constant<int, 16>{});
+        group(integral_constant<int, 32>{}, integral_constant<int, 16>{});
+        group(integral_constant<int, 48>{}, integral_constant<int, 16>{});
+      }
+    }
+    if (!requested && have) {
+      park_row();
+      if (t + 1 <= t_end && t + 1 < g.rows) load_row(t + 1);
+    }
+    low_prev[0] = low_cur[0]; low_prev[1] = low_cur[1];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Entropy coder helpers.
 // ---------------------------------------------------------------------------
 
@@ -2527,6 +2815,52 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
 #undef HIMG_PIX
 }
 
+// k_front (box averages + low-res plane + pixel stage in one pass over the pixels) serves batches of
+// full RGBA8 frames whose rows are at most 512 tiles wide (HIMG_OPT_FRONT forces the three-kernel
+// front / this one).
+static bool use_front(const Geom &g, int batch) {
+  if (!use_pix_path(g) || g.cols > 512 || g.front == 0) return false;
+  return g.front > 0 || (long long)g.rows * batch >= 8192;
+}
+static void launch_front(const Geom &g, const EncWs &ws, const uint8_t *d_frames, const ShiftTables &st,
+                         const uint8_t *d_fmap_lut, int batch, hipStream_t stream, Profiler *prof) {
+  const int wpr = (g.cols + 63) / 64, nt = 64 * wpr;
+  static const int chunk_env = [] { const char *e = getenv("HIMG_FRONT_CHUNK"); return e ? atoi(e) : 0; }();   // (A/B knob)
+  const int target = chunk_env > 0 ? chunk_env : 64;
+  const int nchunks = g.rows >= target + target / 2 ? (g.rows + target / 2) / target : 1;   // ~64 block rows per workgroup
+  const int chunk = (g.rows + nchunks - 1) / nchunks;
+  const size_t lds = (size_t)nt * 256 + kPixLut + (size_t)kFrontExch * nt * 4;
+  const dim3 grid((unsigned)((g.rows + chunk - 1) / chunk), (unsigned)batch), block((unsigned)nt);
+  FrontArgs fa;
+  fa.g = g; fa.frames = d_frames; fa.avg = ws.avg; fa.low = ws.low; fa.plane_stride = ws.plane_stride;
+  fa.fres_sym = ws.fres_sym; fa.fres_stride = ws.fres_stride; fa.fmap_lut = d_fmap_lut; fa.chunk_rows = chunk;
+  fa.pq = make_pix_quant(st);
+  static_assert(sizeof(((PixQuant *)0)->rr) == 2 * 64 * 4 && offsetof(PixQuant, kk) == 512 && offsetof(PixQuant, ss) == 1024,
+                "k_front indexes the quantiser's words as [table][luma / chroma][coefficient]");
+#define HIMG_FRONT(Y, COLS)                                                                               \
+  do {                                                                                                    \
+    static bool attr_done = false;                                                                        \
+    if (!attr_done) {                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<Y, COLS>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      attr_done = true;                                                                                   \
+    }                                                                                                     \
+    prof_begin(prof, "k_front", stream);                                                                  \
+    hipLaunchKernelGGL((k_front<Y, COLS>), grid, block, lds, stream, fa);                                 \
+    prof_end(prof, stream);                                                                               \
+  } while (0)
+  static const bool no_cols = getenv("HIMG_NO_COLS") != nullptr;
+  if (g.ycbcr) {
+    if (g.cols == 512) HIMG_FRONT(true, 512);
+    else if (g.cols == 256 && !no_cols) HIMG_FRONT(true, 256);
+    else if (g.cols == 240 && !no_cols) HIMG_FRONT(true, 240);
+    else HIMG_FRONT(true, 0);
+  } else {
+    HIMG_FRONT(false, 0);
+  }
+#undef HIMG_FRONT
+}
+
 constexpr long long kWideRows = 1024;   // up to this many FRES rows per call: 1024 lanes per row (k_tok_hist, k_emit)
 
 // k_tok_hist over the FRES rows [r0, r1) of every frame: a workgroup of 256 lanes per row,
@@ -2643,13 +2977,20 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   }
   prof_end(prof, stream);
 
-  HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride, 0);
-  if ((g.cols & 3) == 0 && (ws.plane_stride & 3) == 0)
-    HIMG_LAUNCH(k_lowres_blend<true>, dim3((g.cols / 4 + 255) / 256, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256,
-                g, ws.avg, ws.low, ws.plane_stride, 0, g.rows);
-  else
-    HIMG_LAUNCH(k_lowres_blend<false>, dim3(gx, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256, g, ws.avg, ws.low,
-                ws.plane_stride, 0, g.rows);
+  // Batches of full RGBA8 frames: one pass over the pixels (k_front) gives the box averages, the
+  // low-res plane and the symbols; the LRES branch then forks behind it and runs beside the tokeniser.
+  const bool front = use_front(g, batch);
+  if (front) {
+    launch_front(g, ws, d_frames, st, d_fmap_lut, batch, stream, prof);
+  } else {
+    HIMG_LAUNCH(k_lowres_avg, dim3(gx, g.rows, batch), b256, g, d_frames, ws.avg, ws.plane_stride, 0);
+    if ((g.cols & 3) == 0 && (ws.plane_stride & 3) == 0)
+      HIMG_LAUNCH(k_lowres_blend<true>, dim3((g.cols / 4 + 255) / 256, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256,
+                  g, ws.avg, ws.low, ws.plane_stride, 0, g.rows);
+    else
+      HIMG_LAUNCH(k_lowres_blend<false>, dim3(gx, (g.rows + kBlendRows - 1) / kBlendRows, batch * g.C), b256, g, ws.avg, ws.low,
+                  ws.plane_stride, 0, g.rows);
+  }
   // The LRES branch (predictor selection + delta chain, zero-run summaries, token
   // histogram of the LRES spans: 1/64 of the data, latency-bound kernels) forks to the
   // side stream and runs beside the pixel stage and the FRES histogram; the two
@@ -2672,7 +3013,9 @@ void launch_encode(const Geom &g, const EncWs &ws, int batch, const uint8_t *d_f
   const unsigned gxt = (unsigned)((g.cols + kTileThreads - 1) / kTileThreads);
   const bool pix = use_pix_path(g);
   const bool row_tok = ws.tok != nullptr && enc_uses_row_tokens(g, batch);
-  if (pix) {
+  if (front) {
+    // (the symbols are there already)
+  } else if (pix) {
     launch_pix(g, ws, d_frames, st, d_fmap_lut, 0, g.rows, batch, stream, prof);
   } else {
     HIMG_LAUNCH((k_tile_fwd<false, 0>), dim3(gxt, g.rows, batch), dim3(kTileThreads), g, d_frames,

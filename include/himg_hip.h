@@ -63,10 +63,14 @@ const char *himg_hip_last_error(const himg_hip_ctx *ctx);
  *   HIMG_OPT_ROW_TOKENS  encoder: FRES rows go from the tokeniser to the bit packer as a stream of 16-bit
  *                        tokens (k_tok / k_emit_tok) instead of both walking the dense symbol plane (batches);
  *                        value 2 = on, and the bit packer takes its spelled-out path on every step (a test knob)
- *                                                                      [env HIMG_ROW_TOKENS] */
+ *                                                                      [env HIMG_ROW_TOKENS]
+ *   HIMG_OPT_FRONT       encoder, full RGBA8 frames with rows of at most 512 tiles: box averages, low-res
+ *                        plane and pixel stage in ONE pass over the pixels (k_front) instead of three
+ *                        kernels reading them twice (batches)               [env HIMG_FRONT] */
 #define HIMG_OPT_COUNT_WAVE 2
 #define HIMG_OPT_EMIT_ROWS 3
 #define HIMG_OPT_ROW_TOKENS 4
+#define HIMG_OPT_FRONT 5
 int himg_hip_set_option(himg_hip_ctx *ctx, int option, int value);
 /* The option as the context holds it -- including what it took from the environment when it
  * was created (HIMG_FIX_T2=1): a binding that mirrors an option (the row-sharded decoder's host

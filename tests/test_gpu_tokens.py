@@ -87,3 +87,28 @@ def test_token_stream_is_what_batches_take():
     stages = eng.profile_read()
     assert "k_tok" not in stages and "k_emit" in stages, sorted(stages)
     eng.close()
+
+
+FRONT_SHAPES = [(512, 64), (1024, 72), (4096, 64), (1920, 136), (200, 72), (2048, 40), (8, 8), (64, 1024), (4096, 1032)]
+
+
+@pytest.mark.parametrize("w,h", FRONT_SHAPES)
+def test_front_kernel_matches_oracle(w, h):
+    """k_front (box averages, low-res plane and pixel stage in one pass down the frame, what batches
+    take) forced on single frames: every product it leaves -- averages, low-res plane, symbols --
+    and the stream against the oracle; shapes with one row, one column of tiles, ragged last
+    wavefronts, several chunks of block rows (rows >= 96)."""
+    eng = himg_amd.Engine(0)
+    eng.set_option("front", 1)
+    imgs = [("randtile", himg_amd.synth("randtile", 2, w, h)), ("rand", himg_amd.synth("rand", 5, w, h)),
+            ("gradn", himg_amd.synth("gradn", 1, w, h))]
+    for name, img in imgs:
+        for q, ycc in ((50, True), (90, False), (10, True)):
+            want, tr = ol.oracle_encode(img, q, ycc, trace=True)
+            got = eng.encode(img, q, ycc)
+            n_plane = 4 * tr["rows"] * tr["cols"]
+            assert np.array_equal(eng.debug_read("avg", 0, n_plane), tr["avg"]), (name, q, ycc, "box averages")
+            assert np.array_equal(eng.debug_read("lowres", 0, n_plane), tr["lowres"]), (name, q, ycc, "low-res plane")
+            assert np.array_equal(eng.debug_read("fres_sym", 0, tr["fres_sym"].size), tr["fres_sym"]), (name, q, ycc, "symbols")
+            assert got.size == want.size and np.array_equal(got, want), (name, q, ycc)
+    eng.close()
