@@ -1454,7 +1454,6 @@ __global__ __launch_bounds__(NT) void k_tok_hist(Geom g, EncWs ws, int sp0) {
 constexpr int kTokThreads = 256;
 constexpr int kTokWaves = kTokThreads / 64;
 constexpr int kTokStage = 1152;            // slots of a wavefront's staging buffer (a half's worst case: 1024 + runs on their own + < 8 carried over)
-constexpr int kTokSegs = 16;               // segments per block row at most (tok_nseg)
 
 __device__ __forceinline__ int run_token_symbol(int len) {   // huffman_enc.cpp:111-141
   return len == 1 ? 0 : len == 2 ? 256 : len <= 6 ? 257 : len <= 22 ? 258 : len <= 278 ? 259 : 260;
@@ -2820,14 +2819,22 @@ static void launch_pix(const Geom &g, const EncWs &ws, const uint8_t *d_frames, 
 // front / this one).
 static bool use_front(const Geom &g, int batch) {
   if (!use_pix_path(g) || g.cols > 512 || g.front == 0) return false;
-  return g.front > 0 || (long long)g.rows * batch >= 8192;
+  if (g.front > 0) return true;
+  // By launch size: batches; and rows of at least four wavefronts -- a workgroup holds 16 KiB of LDS per
+  // wavefront plus the 8 KiB table, so narrower rows leave a CU with six wavefronts instead of eight
+  // (256 x 1024^2: 97 against 109 Gpx/s with the three kernels).
+  return g.cols > 192 && (long long)g.rows * batch >= 8192;
 }
 static void launch_front(const Geom &g, const EncWs &ws, const uint8_t *d_frames, const ShiftTables &st,
                          const uint8_t *d_fmap_lut, int batch, hipStream_t stream, Profiler *prof) {
   const int wpr = (g.cols + 63) / 64, nt = 64 * wpr;
+  // ~64 block rows per workgroup (a chunk re-reads two tile rows above it), more chunks when the batch
+  // alone does not give every CU two rounds of workgroups; never fewer than 16 rows.
   static const int chunk_env = [] { const char *e = getenv("HIMG_FRONT_CHUNK"); return e ? atoi(e) : 0; }();   // (A/B knob)
   const int target = chunk_env > 0 ? chunk_env : 64;
-  const int nchunks = g.rows >= target + target / 2 ? (g.rows + target / 2) / target : 1;   // ~64 block rows per workgroup
+  int nchunks = g.rows >= target + target / 2 ? (g.rows + target / 2) / target : 1;
+  const int slots = 256 * (8 / wpr > 0 ? 8 / wpr : 1);
+  nchunks = max(nchunks, min((2 * slots + batch - 1) / batch, max(1, g.rows / 16)));
   const int chunk = (g.rows + nchunks - 1) / nchunks;
   const size_t lds = (size_t)nt * 256 + kPixLut + (size_t)kFrontExch * nt * 4;
   const dim3 grid((unsigned)((g.rows + chunk - 1) / chunk), (unsigned)batch), block((unsigned)nt);
@@ -2918,10 +2925,18 @@ bool enc_uses_row_tokens(const Geom &g, int batch) {
   // (a single frame keeps the latency-tuned kernels: its 512 rows are a quarter of the chip's slots)
   return g.row_tokens > 0 || (long long)g.rows * batch >= 8192;
 }
-// Symbols per token segment: a multiple of the tokeniser's iteration, at most kTokSegs segments per row.
+// Symbols per token segment (a multiple of the tokeniser's iteration): eight segments per row, four
+// for rows below 64 Ki symbols -- enough for the row's four wavefronts to balance the dense
+// low-frequency segments against the sparse ones, few enough that the look back in front of a
+// segment and the ragged last step of k_emit_tok per segment stay small (measured, r06_experiments.md:
+// sixteen segments cost 3 % at 4096 pixels, 10 % at 1080p and 20 % at 1024 pixels).
 int enc_tok_seg(const Geom &g) {
-  const int per = (g.row_block + kTokSegs - 1) / kTokSegs;
-  return (per + kTokIter - 1) / kTokIter * kTokIter;
+  static const int seg_env = [] { const char *e = getenv("HIMG_TOK_SEG"); return e ? atoi(e) : 0; }();   // (A/B knob)
+  const int nseg = g.row_block >= 65536 ? 8 : 4;
+  const int per = (g.row_block + nseg - 1) / nseg;
+  int seg = (per + kTokIter - 1) / kTokIter * kTokIter;
+  if (seg_env > 0) seg = (seg_env + kTokIter - 1) / kTokIter * kTokIter;
+  return seg;
 }
 
 static void launch_tok_rows(const Geom &g, const EncWs &ws, int r0, int r1, int batch, hipStream_t stream, Profiler *prof) {
