@@ -872,7 +872,10 @@ __global__ __launch_bounds__(512) void k_front(FrontArgs a) {
           low_f[(size_t)c * chan + (size_t)t * cols + u] = (uint8_t)(low_cur[0] >> (8 * c));
         }
       }
-      __syncthreads();   // (everybody has read the exchange area: the next step may write it)
+      // (No third barrier.  The sums' words are next written in front of the next step's first
+      // barrier: by then every wavefront has passed this step's SECOND barrier, which it reached with
+      // its reads of the sums done.  The averages' word is next written behind the next step's first
+      // barrier, which nobody passes before everybody has read this step's averages.)
     }
     const int v = t - 1;
     bool requested = false;   // has tile row t + 1 been requested (and row t parked) inside the transform?

@@ -21,4 +21,7 @@ cp "$SRC/pmc/summary.json" "profiles/${TAG}_pmc_summary.json"
 cp "$SRC/traffic.json" profiles/traffic.json
 [ -f "$SRC/calib/calibration.json" ] && cp "$SRC/calib/calibration.json" "profiles/${TAG}_calibration.json"
 [ -f "$SRC/graph_latency.json" ] && cp "$SRC/graph_latency.json" "profiles/${TAG}_graph_latency.json"
+[ -f "$SRC/isa_mix.json" ] && cp "$SRC/isa_mix.json" "profiles/${TAG}_isa_mix.json"
+[ -f "$SRC/loop_counts.json" ] && cp "$SRC/loop_counts.json" "profiles/${TAG}_loop_counts.json"
+[ -f "$SRC/dynamic_mix.json" ] && cp "$SRC/dynamic_mix.json" "profiles/${TAG}_dynamic_mix.json"
 ls -la profiles/${TAG}_* profiles/traffic.json

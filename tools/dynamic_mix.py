@@ -37,12 +37,16 @@ ROWS = H // 8
 LOOPS = {
     "dec.write": ("k_dec_row_fused<512>", "dec", 0),
     "dec.count": ("k_row_count_w", "dec", 1),
-    "enc.iter": ("k_emit_t<8, false>", "enc", 0),
-    "enc.walk": ("k_emit_t<8, false>", "enc", 1),
-    "enc.stage": ("k_emit_t<8, false>", "enc", 2),
+    # (round 6: batches tokenise with k_tok and pack with k_emit_tok; k_emit_t's loops -- enc.iter /
+    # enc.walk / enc.stage, counters 0..2 -- only run for single frames and LRES spans now)
+    "tokr.iter": ("k_tok", "enc", 3),
+    "tokr.walk": ("k_tok", "enc", 4),
+    "tok.iter": ("k_emit_tok<8>", "enc", 5),
 }
+# an outer loop's hot path passes through its inner loops (once per inlined copy): taken out of it
+INNER = {"tokr.iter": [("tokr.walk", 2)], "enc.iter": [("enc.walk", 1), ("enc.stage", 1)]}
 REGIONS = {"dec.transform": ("k_dec_row_fused<512>", 16 * ROWS)}   # wavefronts per frame that run it once
-WAVES = {"k_dec_row_fused<512>": 16 * ROWS, "k_row_count_w": ROWS, "k_emit_t<8, false>": ROWS}
+WAVES = {"k_dec_row_fused<512>": 16 * ROWS, "k_row_count_w": ROWS, "k_tok": 4 * ROWS, "k_emit_tok<8>": ROWS}
 
 
 def run(out_path, frames):
@@ -147,15 +151,16 @@ def analyse(counts_path, out_path):
                           "active_lanes_per_wave_iteration": round(lane_it / wave_it, 2) if wave_it else None,
                           "iterations_per_wavefront": round(wave_it / waves, 2),
                           "mean_cost": hp["mean_cost_per_valu"]})
-        # enc.iter's path contains one pass of enc.walk and enc.stage: take them out of it
+        # an outer loop's path contains one pass of each copy of its inner loops: take them out of it
         for p in parts:
-            if p["part"].startswith("enc.iter"):
-                for inner in ("enc.walk", "enc.stage"):
+            outer = p["part"].split(" ")[0]
+            if outer in INNER and "hot_path" in p:
+                for inner, copies in INNER[outer]:
                     if inner in inner_once:
                         for key in ("valu", "valu_fast", "valu_slow"):
-                            p["hot_path"][key] -= inner_once[inner][key]
+                            p["hot_path"][key] = max(p["hot_path"][key] - copies * inner_once[inner][key], 0)
                 p["valu_static"] = p["hot_path"]["valu"]
-                p["mean_cost"] = round(cost(p["hot_path"]) / p["hot_path"]["valu"], 3)
+                p["mean_cost"] = round(cost(p["hot_path"]) / p["hot_path"]["valu"], 3) if p["hot_path"]["valu"] else None
         for p in parts:
             if "hot_path" not in p:
                 continue

@@ -253,8 +253,8 @@ def main():
         elif args[0] == "--rates":
             rates = args[1]
         args = args[2:]
-    want = args or ["k_pix_fwdILb1ELi512ELb1", "k_tok_hist", "k_emit_t", "k_row_countILb1", "k_row_count_w",
-                    "k_dec_row_fusedILi512", "k_lowres_avg"]
+    want = args or ["k_frontILb1ELi512", "5k_tokENS", "k_emit_tokILi8", "k_pix_fwdILb1ELi512ELb1", "k_tok_hist", "k_emit_tILi",
+                    "k_row_countILb1", "k_row_count_w", "k_dec_row_fusedILi512", "k_lowres_avg"]
     fast_c, slow_c = load_rates(rates)
     report = {"issue_cycles": {"fast": fast_c, "slow": slow_c, "guide": 2.0,
                                "source": os.path.relpath(rates, ROOT) if os.path.exists(rates) else "defaults"},

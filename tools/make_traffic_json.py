@@ -28,8 +28,10 @@ x2 = {k: round((v.get("hbm_read_MB_x2", 0) + v.get("hbm_write_MB", 0)) * 1e6 / f
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 mix = {}
-mpath = os.path.join(ROOT, "profiles", "r04_isa_mix.json")
-if os.path.exists(mpath):
+import glob
+mfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_isa_mix.json")))   # the newest round's static mix
+mpath = mfiles[-1] if mfiles else ""
+if mpath:
     mj = json.load(open(mpath))
     mix = {k.split("<")[0]: v["kernel"]["mean_cost_per_valu"] for k, v in mj["kernels"].items()}
 SIMDS = 256 * 4
@@ -60,7 +62,7 @@ json.dump({"note": "HBM bytes per 4096x4096 RGBA q50 randtile frame per kernel l
                    "raw and x2 figures beside it) + WRITE_SIZE, separate passes, %d frames per launch, "
                    "tools/profile_pmc.sh.  valu: SQ_INSTS_VALU per symbol; issue_frac_* = the SIMD issue time of that count "
                    "(at the guide's 2 cycles per instruction / at the kernel's class-weighted measured cost, "
-                   "profiles/r04_isa_mix.json) over the kernel's duration on 1024 SIMDs." % frames_per_launch,
+                   "%s) over the kernel's duration on 1024 SIMDs." % (frames_per_launch, os.path.relpath(mpath, ROOT) if mpath else "no isa_mix file"),
            "git_sha": sha, "frames_per_launch": frames_per_launch,
            "bytes_per_launch": {k: round((v.get("hbm_read_MB_corrected", 0) + v.get("hbm_write_MB", 0)) * 1e6) for k, v in d.items()},
            "bytes_per_frame": t, "bytes_per_frame_fetch_raw": raw, "bytes_per_frame_fetch_x2": x2,

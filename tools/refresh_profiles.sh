@@ -40,4 +40,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_defaul
 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_b64" -- \
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --batch 64 --no-cpu-baseline --no-extras --no-rows > "$ROOT/$OUT/stats_b64.log" 2>&1
 cd "$ROOT"
+# Static instruction mix of the wide kernels (no GPU needed, but this commit's sources), then the loops'
+# measured trip counts from a build with the counters compiled in (the snapshot's library is rebuilt
+# for it, and rebuilt again without them).
+python3 tools/isa_mix.py --json "$OUT/isa_mix.json" > "$OUT/isa_mix.txt" 2>&1
+HIMG_EXTRA_HIPCC_FLAGS=-DHIMG_LOOP_COUNTS python3 tools/dynamic_mix.py --run "$OUT/loop_counts.json" 8 > "$OUT/loop_counts.log" 2>&1
+python3 -c "from himg_amd import build; build.build_lib()" > /dev/null 2>&1
+python3 tools/dynamic_mix.py --analyse "$OUT/loop_counts.json" "$OUT/dynamic_mix.json" > "$OUT/dynamic_mix.txt" 2>&1
 ls "$ROOT/$OUT"

@@ -37,7 +37,9 @@ _DEFAULT_FACTORS = {"stream16": {"fetch": 0.5000, "write": 1.0}, "rowlike": {"fe
 
 def _load_factors():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "profiles", "r05_calibration.json")
+    import glob
+    files = sorted(glob.glob(os.path.join(here, "..", "profiles", "r[0-9][0-9]_calibration.json")))   # the newest round's
+    path = files[-1] if files else ""
     try:
         f = json.load(open(path))["factors"]
         return {k: {"fetch": float(f[k]["fetch"]), "write": float(f[k]["write"])} for k in ("stream16", "rowlike")}
@@ -49,7 +51,7 @@ FACTORS = _load_factors()
 PATTERN = {
     # 16 bytes per lane, coalesced
     "k_lowres_avg": "stream16", "k_pix_fwd": "stream16", "k_tok_hist": "stream16", "k_emit": "stream16",
-    "k_emit_t": "stream16", "k_tok": "stream16", "k_emit_tok": "stream16", "k_emit_m": "stream16", "k_lres_summary": "stream16", "k_place_fres": "stream16",
+    "k_emit_t": "stream16", "k_tok": "stream16", "k_emit_tok": "stream16", "k_front": "stream16", "k_emit_m": "stream16", "k_lres_summary": "stream16", "k_place_fres": "stream16",
     "k_tile_inv": "stream16", "k_tile_fwd": "stream16", "k_cal_read": "stream16", "k_cal_copy": "stream16",
     # bit readers: a dword per lane along the lane's own sub-sequence of the payload
     "k_dec_row_fused": "rowlike", "k_row_count": "rowlike", "k_row_count_w": "rowlike", "k_row_count_q": "rowlike",
