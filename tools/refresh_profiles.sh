@@ -44,7 +44,7 @@ cd "$ROOT"
 # measured trip counts from a build with the counters compiled in (the snapshot's library is rebuilt
 # for it, and rebuilt again without them).
 python3 tools/isa_mix.py --json "$OUT/isa_mix.json" > "$OUT/isa_mix.txt" 2>&1
-HIMG_EXTRA_HIPCC_FLAGS=-DHIMG_LOOP_COUNTS python3 tools/dynamic_mix.py --run "$OUT/loop_counts.json" 8 > "$OUT/loop_counts.log" 2>&1
+HIMG_EXTRA_HIPCC_FLAGS=-DHIMG_LOOP_COUNTS python3 tools/dynamic_mix.py --run "$OUT/loop_counts.json" 16 > "$OUT/loop_counts.log" 2>&1
 python3 -c "from himg_amd import build; build.build_lib()" > /dev/null 2>&1
 python3 tools/dynamic_mix.py --analyse "$OUT/loop_counts.json" "$OUT/dynamic_mix.json" > "$OUT/dynamic_mix.txt" 2>&1
 ls "$ROOT/$OUT"
