@@ -450,7 +450,7 @@ static int stage_sizes(himg_hip_ctx *ctx, const uint32_t *src, int n, hipStream_
   return HIMG_OK;
 }
 
-static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g_in, int batch, bool allow_row_tokens = true) {
+static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g_in, int batch, bool allow_row_tokens = true, bool force_row_tokens = false) {
   EncWs &w = ctx->enc_ws;
   Geom g = g_in;
   g.row_tokens = ctx->row_tokens;
@@ -467,7 +467,7 @@ static int ensure_enc_ws(himg_hip_ctx *ctx, const Geom &g_in, int batch, bool al
   const int nsp = g.lres_spans + g.rows;
   // FRES rows as a token stream between the tokeniser and the bit packer (batches): 16-bit slots,
   // worst case 2 bytes per symbol (+ padding per segment), ~0.7 in use.
-  const bool row_tok = allow_row_tokens && himg_dev::enc_uses_row_tokens(g, batch);
+  const bool row_tok = allow_row_tokens && (force_row_tokens || himg_dev::enc_uses_row_tokens(g, batch));
   const int tok_seg = row_tok ? himg_dev::enc_tok_seg(g) : 0;
   const int tok_nseg = row_tok ? (g.row_block + tok_seg - 1) / tok_seg : 0;
   const int tok_cap = tok_seg + himg_dev::kTokSegPad;
@@ -1434,7 +1434,11 @@ extern "C" int himg_hip_shard_stats(himg_hip_ctx *ctx, const void *d_frame_base,
   if (row0 < 0 || row1 > g.rows || row0 > row1 || g.rows > 65535)
     return fail(ctx, HIMG_ERR_ARG, "bad block-row range");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_enc_ws(ctx, g, 1, false);   // (the row-sharded phases work on the dense symbol plane)
+  // A range of a thousand block rows and more goes through the token stream (k_tok / k_emit_tok: a
+  // wavefront per row packs it in ~0.3 ms whatever the number of rows; below, the 1024-lane kernels
+  // over the dense plane are faster); HIMG_OPT_ROW_TOKENS forces either.
+  const bool shard_tok = ctx->row_tokens != 0 && (ctx->row_tokens > 0 || row1 - row0 >= 1024);
+  int rc = ensure_enc_ws(ctx, g, 1, shard_tok, shard_tok);
   if (rc) return rc;
   auto &sh = ctx->shard;
   rc = build_static(g, quality, &sh.sc, &sh.st, &sh.lt);

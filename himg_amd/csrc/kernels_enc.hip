@@ -3095,7 +3095,9 @@ void launch_shard_stats(const Geom &g, const EncWs &ws, const uint8_t *d_frame_b
   HIMG_LAUNCH(k_lowres_blend<false>, dim3(gx, (l1 - r0 + kBlendRows - 1) / kBlendRows, g.C), b256, g, ws.avg, ws.low,
               ws.plane_stride, r0, l1);
   launch_tile_rows(g, ws, d_frame_base, st, d_fmap_lut, r0, r1 - r0, stream, prof);
-  launch_tok_hist_rows(g, ws, r0, r1, 1, stream, prof);
+  // (rows through the token stream when the workspace holds one: himg_hip_shard_stats decides by the range's size)
+  if (ws.tok) launch_tok_rows(g, ws, r0, r1, 1, stream, prof);
+  else launch_tok_hist_rows(g, ws, r0, r1, 1, stream, prof);
 }
 
 void launch_shard_row_bits(const Geom &g, const EncWs &ws, int r0, int r1, uint32_t *d_bits_out,
@@ -3110,7 +3112,8 @@ void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
                        uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof) {
   HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1, r0, r1);
   if (r1 > r0)
-    launch_emit(g, ws, d_rel, rel_cap, d_rel_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
+    if (ws.tok) launch_emit_tok(g, ws, d_rel, rel_cap, d_rel_size, r0, r1, 1, stream, prof);
+    else launch_emit(g, ws, d_rel, rel_cap, d_rel_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
 }
 
 void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &sc,
@@ -3173,7 +3176,10 @@ void launch_shard_head(const Geom &g, const EncWs &ws, const StaticChunks &sc, c
   HIMG_LAUNCH(k_sizes, dim3(1), b256, g, ws, sc, d_out, out_cap, d_size, d_all_row_bits, 0, 0, g.rows);
   hipLaunchKernelGGL(k_shard_head_info, dim3(1), dim3(1), 0, stream, g, ws, d_size, d_head);
   launch_emit(g, ws, d_out, out_cap, d_size, 0, g.lres_spans, 1, stream, prof);
-  if (r1 > r0) launch_emit(g, ws, d_out, out_cap, d_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
+  if (r1 > r0) {
+    if (ws.tok) launch_emit_tok(g, ws, d_out, out_cap, d_size, r0, r1, 1, stream, prof);
+    else launch_emit(g, ws, d_out, out_cap, d_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
+  }
 }
 
 void launch_shard_finish(const Geom &g, const EncWs &ws, uint8_t *d_out, size_t out_cap, const uint32_t *d_size,
