@@ -1357,8 +1357,13 @@ __device__ __forceinline__ bool lean_write_chain(GReader &rd0, const GrpTables &
     if (!CLIP || opa - clip_lo < clip_span) {
       const unsigned long long v = (unsigned long long)by << (8u * (opa & 3u));
       const uint32_t a = opa & ~3u;
+      // (HIMG_DEC_KO: timing builds of tools/dec_knockout.sh -- they decode wrongly on purpose)
+#if !defined(HIMG_DEC_KO) || !(HIMG_DEC_KO & 1)
       lds_or32(a, (uint32_t)v);
+#endif
+#if !defined(HIMG_DEC_KO) || !(HIMG_DEC_KO & 3)
       lds_or32(a + 4u, (uint32_t)(v >> 32));
+#endif
     }
     opa += ((y >> 10) & 511u) + extra;
     bp += n;
@@ -2704,7 +2709,12 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
           lr0 = (uint32_t)m[(size_t)v * cols + u] | ((uint32_t)m[(size_t)v * cols + u2] << 8);
           lr8 = (uint32_t)m[(size_t)v2 * cols + u] | ((uint32_t)m[(size_t)v2 * cols + u2] << 8);
         }
-        tile_plane<COLS>(sym + (size_t)c * 64 * cols + u, cols, s_unmap, s_shift + chroma * 64,
+#if defined(HIMG_DEC_KO) && (HIMG_DEC_KO & 4)
+        const int c_addr = cc;   // (both lanes of a pair read planes 0, 1: no bank shared between the half-waves)
+#else
+        const int c_addr = c;
+#endif
+        tile_plane<COLS>(sym + (size_t)c_addr * 64 * cols + u, cols, s_unmap, s_shift + chroma * 64,
                          s_shiftp + chroma * 32, lr0, lr8, O, COLS != 0 ? s_shiftp + 64 + 2 * chroma : nullptr);
       } else {
 #pragma unroll
@@ -2770,7 +2780,12 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
           px[4 * h + 3] = __builtin_amdgcn_perm(w1, t1, 0x07060302u);
         }
       }
+#if defined(HIMG_DEC_KO) && (HIMG_DEC_KO & 16)
+      asm volatile("" :: "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(px[4]), "v"(px[5]), "v"(px[6]), "v"(px[7]));   // (computed, not stored)
+      if (false) {
+#else
       if (store_ok && (FULL4 || y < bh)) {
+#endif
         uint8_t *dst = img + ((size_t)(8 * v + y) * g.W + 8 * u) * C;
         if (FULL4 || (C == 4 && bw == 8)) {
           uint4 o0, o1;
