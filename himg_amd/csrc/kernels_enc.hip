@@ -3111,9 +3111,10 @@ void launch_shard_emit(const Geom &g, const EncWs &ws, const StaticChunks &sc,
                        const uint32_t *d_all_row_bits, uint8_t *d_rel, size_t rel_cap,
                        uint32_t *d_rel_size, int r0, int r1, hipStream_t stream, Profiler *prof) {
   HIMG_LAUNCH(k_sizes, dim3(1), dim3(256), g, ws, sc, d_rel, rel_cap, d_rel_size, d_all_row_bits, 1, r0, r1);
-  if (r1 > r0)
+  if (r1 > r0) {
     if (ws.tok) launch_emit_tok(g, ws, d_rel, rel_cap, d_rel_size, r0, r1, 1, stream, prof);
     else launch_emit(g, ws, d_rel, rel_cap, d_rel_size, g.lres_spans + r0, g.lres_spans + r1, 1, stream, prof);
+  }
 }
 
 void launch_shard_assemble(const Geom &g, const EncWs &ws, const StaticChunks &sc,
