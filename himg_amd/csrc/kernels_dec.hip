@@ -2298,12 +2298,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // critical path between k_row_count and the row kernel.
 constexpr int kUnpredWaves = 4;
 __global__ __launch_bounds__(64 * kUnpredWaves) void k_lres_unpredict(Geom g, DecWs ws) {
-  __shared__ uint8_t rec_s[kUnpredWaves][4][16][17];
+  __shared__ uint8_t rec_s[kUnpredWaves][4][17][18];   // the reconstructed blocks with a border row / column in front
   __shared__ uint8_t dl_s[kUnpredWaves][4][16][16];   // the blocks' deltas: the chain below reads one per step
   __shared__ int16_t s_lmap[128];   // the chain below looks a delta up per step: LDS, not global
   __shared__ int s_status;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, b = lane >> 4, dv = lane & 15;
-  uint8_t (*rec)[16][17] = rec_s[wv];
+  uint8_t (*rec)[17][18] = rec_s[wv];
   uint8_t (*dl)[16][16] = dl_s[wv];
   const int mu = (blockIdx.x * kUnpredWaves + wv) * 4 + b, mv = blockIdx.y;
   const int f = blockIdx.z / g.C, c = blockIdx.z % g.C;
@@ -2328,21 +2328,32 @@ __global__ __launch_bounds__(64 * kUnpredWaves) void k_lres_unpredict(Geom g, De
   }
   __syncthreads();
   if (s_status) return;
+  // The chain, branch free (as k_lres_predict's): neighbours from a copy of the block with a border
+  // (index + 1), the edge cases of downsampled.cpp:318-382 as four selects, all predictors computed
+  // and the block's selected -- the four blocks of a wavefront use different ones.
+  const bool row_live = dv < bh, up_ok = dv > 0;
+  uint8_t *rrow = &rec[b][dv + 1][1];          // rrow[du] = reconstructed sample (dv, du)
+  const uint8_t *urow = &rec[b][dv][1];        // the row above
+  uint8_t *mrow = m + (size_t)(v0 + dv) * g.cols + u0;
   for (int d = 0; d < 31; ++d) {
     const int du = d - dv;
-    if (dv < bh && du >= 0 && du < bw) {
-      int s1, s2, s3;
-      if (du > 0 && dv > 0) { s1 = rec[b][dv - 1][du - 1]; s2 = rec[b][dv - 1][du]; s3 = rec[b][dv][du - 1]; }
-      else if (du > 0) { s1 = s2 = s3 = rec[b][dv][du - 1]; }
-      else if (dv > 0) { s1 = s2 = s3 = rec[b][dv - 1][du]; }
-      else { s1 = s2 = s3 = 128; }
-      const int predicted = predict_d(s1, s2, s3, pc);
-      const int sc = (int8_t)dl[b][dv][du];
-      // mapper.h:33-35 with the mirrored table (mapper.cpp:148-154).
-      const int un = sc >= 0 ? s_lmap[sc] : (sc == -128 ? -s_lmap[127] : -s_lmap[-sc]);
-      const int val = clamp255d((int)(int16_t)(predicted + un));
-      rec[b][dv][du] = (uint8_t)val;
-      m[(size_t)(v0 + dv) * g.cols + u0 + du] = (uint8_t)val;
+    const bool active = row_live && du >= 0 && du < bw;
+    const int duc = active ? du : 0;
+    const int left = rrow[duc - 1], up = urow[duc], ul = urow[duc - 1];
+    const bool left_ok = duc > 0;
+    const int f = up_ok ? up : (left_ok ? left : 128);
+    const int s3 = left_ok ? left : f, s2 = f, s1 = (up_ok && left_ok) ? ul : f;
+    const int t = s2 + s3;
+    const int p0 = clamp255d((3 * t - 2 * s1 + 2) >> 2), p3 = (t + 1) >> 1, p4 = clamp255d(t - s1);
+    const int predicted = pc == 1 ? s2 : pc == 2 ? s3 : pc == 3 ? p3 : pc == 4 ? p4 : p0;
+    const int sc = (int8_t)dl[b][dv][duc];
+    // mapper.h:33-35 with the mirrored table (mapper.cpp:148-154).
+    const int mag = s_lmap[sc < 0 ? (sc == -128 ? 127 : -sc) : sc];
+    const int un = sc < 0 ? -mag : mag;
+    const int val = clamp255d((int)(int16_t)(predicted + un));
+    if (active) {
+      rrow[du] = (uint8_t)val;
+      mrow[du] = (uint8_t)val;
     }
     wave_lds_sync();   // (the exchange is inside the wavefront)
   }

@@ -159,6 +159,11 @@ __global__ __launch_bounds__(256) void k_lowres_blend(Geom g, const uint8_t *avg
   }
 }
 
+// The value of the lane before inside a DPP row of 16 lanes (lane 0 of a row: its own).
+__device__ __forceinline__ uint32_t dpp_row_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
 // Predictors of downsampled.cpp:41-60.
 __device__ __forceinline__ int predict(int s1, int s2, int s3, int p) {
   switch (p) {
@@ -185,8 +190,8 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
   // FOUR macro blocks per wavefront, 16 lanes each (lane & 15 = row of the block):
   // the delta chain only ever has 16 rows to work on, so one block per wave left
   // three quarters of it idle -- and a 4096x4096 frame is 4096 blocks per channel.
-  __shared__ uint8_t mb[4][16][17];
-  __shared__ uint8_t rec[4][16][17];
+  __shared__ __attribute__((aligned(4))) uint8_t mb[4][16][20];   // (rows dword aligned: the fast path stores them as dwords)
+  __shared__ uint8_t recp[4][17][18];   // the reconstructed block with a border row / column in front (see the chain below)
   // The companding tables in LDS: the delta chain below looks them up twice per
   // step, and out of the kernel-argument segment each lookup is a global load on
   // the critical path of 31 dependent steps.
@@ -202,12 +207,49 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
   const int u0 = mu * 16, v0 = mv * 16;
   const int bw = live ? min(16, g.cols - u0) : 0, bh = min(16, g.rows - v0);
 
+  int err[5] = {0, 0, 0, 0, 0};
+  // Four full blocks in rows of sixteen-byte-aligned samples (every block of the BASELINE frames
+  // but those at the right / bottom edge of odd sizes): the lane's row is ONE 16-byte load and stays
+  // in registers, the row above comes from the lane before by DPP (a block is a DPP row of 16
+  // lanes), and the predictors' squared errors are accumulated without a branch or an LDS read.
+  const bool fast = __all(live && bw == 16 && bh == 16) && (g.cols & 15) == 0;
+  if (fast) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(m + (size_t)(v0 + dv) * g.cols + u0);
+    const uint32_t R[4] = {q.x, q.y, q.z, q.w};
+    uint32_t U[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      U[k] = dpp_row_shr1(R[k]);
+      *reinterpret_cast<uint32_t *>(&mb[b][dv][4 * k]) = R[k];
+    }
+    const bool up_ok1 = dv > 0;
+#pragma unroll
+    for (int du = 0; du < 16; ++du) {
+      const int actual = (int)((R[du >> 2] >> (8 * (du & 3))) & 255u);
+      const int up = (int)((U[du >> 2] >> (8 * (du & 3))) & 255u);
+      int s1, s2, s3;
+      if (du > 0) {
+        const int left = (int)((R[(du - 1) >> 2] >> (8 * ((du - 1) & 3))) & 255u);
+        const int ul = (int)((U[(du - 1) >> 2] >> (8 * ((du - 1) & 3))) & 255u);
+        s3 = left; s2 = up_ok1 ? up : left; s1 = up_ok1 ? ul : left;
+      } else {
+        s1 = s2 = s3 = up_ok1 ? up : 128;
+      }
+      const int t = s2 + s3;
+      const int pr[5] = {clamp255((3 * t - 2 * s1 + 2) >> 2), s2, s3, (t + 1) >> 1, clamp255(t - s1)};
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        const int dd = actual - pr[p];
+        err[p] += dd * dd;
+      }
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
   for (int du = 0; du < 16; ++du)
     mb[b][dv][du] = (dv < bh && du < bw) ? m[(size_t)(v0 + dv) * g.cols + u0 + du] : 0;
   __syncthreads();
 
-  int err[5] = {0, 0, 0, 0, 0};
   if (dv < bh) {
     for (int du = 0; du < bw; ++du) {
       int s1, s2, s3;
@@ -222,6 +264,7 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
         err[p] += d * d;
       }
     }
+  }
   }
 #pragma unroll
   for (int p = 0; p < 5; ++p)
@@ -238,20 +281,34 @@ __global__ __launch_bounds__(64) void k_lres_predict(Geom g, const uint8_t *low,
   const int pc = best <= 1 ? 0 : best;
 
   uint8_t *dst = out + g.mrows * g.mcols + (size_t)v0 * g.cols + (size_t)bh * u0;
+  // The delta chain, branch free: the three reconstructed neighbours are read from a copy of the
+  // block with a border (index + 1: the reads of row / column -1 land on it, their values are
+  // not used), the cases of downsampled.cpp:263-281 are four selects (f = the neighbour that
+  // stands for all three at an edge), all five predictors are computed and the block's is
+  // selected -- the four blocks of a wavefront code with different predictors, and a switch ran
+  // every case taken by any of them.  (~100 -> ~45 instructions per anti-diagonal step.)
+  const bool row_live = dv < bh;
+  const bool up_ok = dv > 0;
+  uint8_t *rrow = &recp[b][dv + 1][1];          // rrow[du] = reconstructed sample (dv, du)
+  const uint8_t *urow = &recp[b][dv][1];        // the row above
   for (int d = 0; d < 31; ++d) {
     const int du = d - dv;
-    if (dv < bh && du >= 0 && du < bw) {
-      int s1, s2, s3;
-      if (du > 0 && dv > 0) { s1 = rec[b][dv - 1][du - 1]; s2 = rec[b][dv - 1][du]; s3 = rec[b][dv][du - 1]; }
-      else if (du > 0) { s1 = s2 = s3 = rec[b][dv][du - 1]; }
-      else if (dv > 0) { s1 = s2 = s3 = rec[b][dv - 1][du]; }
-      else { s1 = s2 = s3 = 128; }
-      const int predicted = predict(s1, s2, s3, pc);
-      const int delta = (int)mb[b][dv][du] - predicted;
-      const uint8_t code = s_code[delta + 255];
-      const int sc = (int8_t)code;
-      const int un = sc >= 0 ? s_tab[sc] : -s_tab[-sc];
-      rec[b][dv][du] = (uint8_t)clamp255(predicted + un);
+    const bool active = row_live && du >= 0 && du < bw;
+    const int duc = active ? du : 0;
+    const int left = rrow[duc - 1], up = urow[duc], ul = urow[duc - 1];
+    const bool left_ok = duc > 0;
+    const int f = up_ok ? up : (left_ok ? left : 128);
+    const int s3 = left_ok ? left : f, s2 = f, s1 = (up_ok && left_ok) ? ul : f;
+    const int t = s2 + s3;
+    const int p0 = clamp255((3 * t - 2 * s1 + 2) >> 2), p3 = (t + 1) >> 1, p4 = clamp255(t - s1);
+    const int predicted = pc == 2 ? s3 : pc == 3 ? p3 : pc == 4 ? p4 : p0;   // (pc is 0, 2, 3 or 4: selections 0 and 1 both code with 0)
+    const int delta = (int)mb[b][dv][duc] - predicted;
+    const uint8_t code = s_code[delta + 255];
+    const int sc = (int8_t)code;
+    const int mag = s_tab[sc < 0 ? -sc : sc];
+    const int un = sc < 0 ? -mag : mag;
+    if (active) {
+      rrow[du] = (uint8_t)clamp255(predicted + un);
       dst[dv * bw + du] = code;
     }
     __syncthreads();
