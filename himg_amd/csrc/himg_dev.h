@@ -34,6 +34,7 @@ struct Geom {
   int max_sub;               // decoder: longest sub-sequence in bits (4096; tests lower it to force several chunks per stream)
   int lead_bits;             // decoder: lead-in before a lane's nominal start (lean_fixpoint; 0 = start blind)
   // Kernel variants (context options, see himg_hip.h HIMG_OPT_*): -1 = chosen by the launch size.
+  int prefetch_rows;         // decoder: the row kernel touches the packed bytes of the row that takes its CU next (HIMG_PREFETCH_ROWS=0 turns it off: an A/B knob)
   int count_wave;            // decoder: k_row_count_w (a wavefront per row) instead of k_row_count
   int wide_q;                // decoder, rows wider than the LDS: the host's estimate says a quarter sub-sequence of a row
                              // (1/4096 of its payload) fits k_row_count_q's staging buffer -- that kernel counts

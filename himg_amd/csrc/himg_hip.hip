@@ -223,6 +223,7 @@ static bool make_geom(int width, int height, int pixel_stride, int num_channels,
   g->lres_serial = 0;
   g->count_wave = g->emit_rows = g->row_tokens = g->front = -1;
   g->wide_q = 0;
+  { static const int pf = [] { const char *e = std::getenv("HIMG_PREFETCH_ROWS"); return e ? atoi(e) : 1; }(); g->prefetch_rows = pf; }
   g->frame_bytes = (long long)width * height * pixel_stride;
   g->fres_size = fres;
   return true;

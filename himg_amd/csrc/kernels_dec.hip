@@ -2700,7 +2700,8 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
                                                      const uint8_t *low, const int16_t *s_unmap,
                                                      const uint8_t *s_shift, const uint32_t *s_shiftp,
                                                      int ycbcr, int u, int s, int v, uint8_t *img,
-                                                     const uint32_t *pre_lr = nullptr, bool store_ok = true) {
+                                                     const uint32_t *pre_lr = nullptr, bool store_ok = true,
+                                                     bool touched_on = false, uint32_t touched = 0) {
   const int cols = COLS > 0 ? COLS : cols_rt;
   const int C = FULL4 ? 4 : g.C;
   const int v2 = min(v + 1, g.rows - 1);
@@ -2754,6 +2755,13 @@ __device__ __forceinline__ void transform_store_pair(const Geom &g, int cols_rt,
     }
     const int bw = FULL4 ? 8 : min(8, g.W - 8 * u);
     const int bh = FULL4 ? 8 : min(8, g.H - 8 * v);
+    if (touched_on) {
+      // (k_dec_row_fused's touch loads for the next row: issued before the gather, long landed --
+      // their registers are given back here, in front of the pixel stores, so that nothing waits
+      // for a store.)
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+      asm volatile("" :: "v"(touched));
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int y = 4 * s + rr;
@@ -3024,6 +3032,32 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   }
 
   const long long c_p2 = clock64();
+  // What the workgroup that takes this CU next will ask for first -- the packed bytes of the row 256
+  // workgroups on (workgroups go to the XCDs round robin, so that one shares this one's L2) -- is
+  // touched now, a line per lane of wavefronts 1..5: its first steps then wait for the L2 instead of
+  // the HBM (decode of 128 frames 10.13 -> 9.95 ms; touching that row's lane record as well gains
+  // nothing).  Loads nobody reads: the register is kept out of the compiler's hands until the
+  // explicit wait in front of the pixel stores (transform_store_pair).
+  uint32_t pf_a = 0;
+  bool pf_on = false;
+  {
+    // (one workgroup per CU at 4096 pixels, two where two fit: the CU's next one is 256 / 512 on)
+    const size_t lin = (size_t)f * gridDim.x + blockIdx.x + (L.total <= 80u * 1024u ? 512u : 256u);
+    const int fn = (int)(lin / gridDim.x), rn = r0 + (int)(lin % gridDim.x) * rpw;
+    pf_on = g.prefetch_rows != 0 && fn < (int)gridDim.y && rn < r1;
+    if (pf_on) {
+      const int wv = tid >> 6, ln = tid & 63;
+      // (how many bytes: this workgroup's own rows are the best guess -- 4096 pixels: the row's length
+      // is at hand; other widths: the frame's mean)
+      const uint32_t guess = COLS == 512 ? pre_len0 : (uint32_t)((unsigned long long)sizes[f] * (uint32_t)nr / (uint32_t)g.rows);
+      const uint32_t o = 128u * (uint32_t)((wv - 1) * 64 + ln);
+      if (wv >= 1 && wv <= 5 && o < guess + 256u) {
+        const uint8_t *a = packed + (size_t)fn * in_stride + ws.row_off[(size_t)fn * g.rows + (size_t)rn] + o;
+        const uint8_t *al = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf_a) : "v"(al) : "memory");
+      }
+    }
+  }
   const int ycbcr = df->ycbcr;
   const int cols = COLS > 0 ? COLS : g.cols;
   // ---- phase 2: inverse transform, colour inverse and stores ----
@@ -3041,7 +3075,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
     const bool in_row = pair_tile(il) < cols;
     transform_store_pair<COLS, COLS != 0>(g, cols, sym0 + (size_t)i * rb16, low, s_unmap, s_shift, s_shiftp, ycbcr,
                                             in_row ? pair_tile(il) : cols - 1, pair_half(il), rb + i, img,
-                                            COLS == 512 ? pre_lr : nullptr, in_row);
+                                            COLS == 512 ? pre_lr : nullptr, in_row, pf_on && it == tid, pf_a);
   }
   HIMG_REGION_END("dec.transform");
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
