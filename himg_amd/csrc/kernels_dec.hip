@@ -3052,9 +3052,14 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       const uint32_t guess = COLS == 512 ? pre_len0 : (uint32_t)((unsigned long long)sizes[f] * (uint32_t)nr / (uint32_t)g.rows);
       const uint32_t o = 128u * (uint32_t)((wv - 1) * 64 + ln);
       if (wv >= 1 && wv <= 5 && o < guess + 256u) {
-        const uint8_t *a = packed + (size_t)fn * in_stride + ws.row_off[(size_t)fn * g.rows + (size_t)rn] + o;
-        const uint8_t *al = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pf_a) : "v"(al) : "memory");
+        // Never beyond that frame's stream: its rows may be shorter than this one's, and a frame
+        // that failed to parse has no index at all (whatever the slot holds is compared, not trusted).
+        const unsigned long long at = (unsigned long long)ws.row_off[(size_t)fn * g.rows + (size_t)rn] + o;
+        if (at + 4ull <= (unsigned long long)sizes[fn]) {
+          const uint8_t *a = packed + (size_t)fn * in_stride + at;
+          const uint8_t *al = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+          asm volatile("global_load_dword %0, %1, off" : "=v"(pf_a) : "v"(al) : "memory");
+        }
       }
     }
   }
