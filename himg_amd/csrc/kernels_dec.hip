@@ -2890,12 +2890,11 @@ __global__ __launch_bounds__(256) void k_tile_inv(Geom g, DecWs ws, uint8_t *out
 // pixels), so as many rows as fit the LDS -- and the lanes -- are entropy-decoded one
 // after the other (each by all 1024 lanes) and then transformed together.
 template <int COLS>
-__global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
-                                                               const uint8_t *packed,
-                                                               size_t in_stride,
-                                                               const uint32_t *sizes,
-                                                               uint8_t *out_frames, int r0, int r1,
-                                                               int rpw) {
+__device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &ws, const uint8_t *packed,
+                                                   size_t in_stride, const uint32_t *sizes,
+                                                   uint8_t *out_frames, int r0, int r1, int rpw,
+                                                   const int bx, const int f, const int gx, const int gy,
+                                                   const uint32_t next_dist, const bool again) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (COLS == 512) rpw = 1;   // 4096-pixel rows: one row fills the lanes and the LDS (known at compile time)
   const FusedLayout L = fused_layout(g.row_block, rpw);
@@ -2907,7 +2906,12 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint8_t *s_shift = smem + L.shift;
   uint32_t *s_shiftp = reinterpret_cast<uint32_t *>(smem + L.shiftp);
 
-  const int f = blockIdx.y, tid = threadIdx.x;
+  // (opaque per row: what depends on the lane alone would otherwise be computed once in front of
+  // the persistent loop and stay in registers across the whole body)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  __builtin_assume(tid_ >= 0 && tid_ < kDecThreads);   // (the range the compiler knew of threadIdx.x)
+  const int tid = tid_;
   const long long c_in = clock64();
   DecFrame *df = ws.frames + f;
   const uint8_t *low = ws.low + (size_t)f * ws.plane_stride;
@@ -2919,13 +2923,13 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   PreLane pl = {};
   uint32_t pre_lr[4] = {0, 0, 0, 0}, pre_off0 = 0, pre_len0 = 0;
   if constexpr (COLS == 512) {
-    const size_t ri = (size_t)f * g.rows + (size_t)(r0 + (int)blockIdx.x);
+    const size_t ri = (size_t)f * g.rows + (size_t)(r0 + bx);
     const uint32_t *ps = ws.lane_start + ri * kDecThreads, *po = ws.lane_off + ri * (kDecThreads + kRecHdr);
     pl.start = ps[tid]; pl.off = po[tid]; pl.nxt = po[tid + 1];
     pl.nstart = tid + 1 < kDecThreads ? ps[tid + 1] : ~0u;
     pl.tot = po[kDecThreads]; pl.endrel = po[kDecThreads + 1]; pl.valid = po[kDecThreads + 2]; pl.rounds = po[kDecThreads + 3];
     pre_off0 = ws.row_off[ri]; pre_len0 = ws.row_len[ri];
-    const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + (int)blockIdx.x;
+    const int u = pair_tile(tid), hs = pair_half(tid), v = r0 + bx;
     const int u2 = min(u + 1, COLS - 1), v2 = min(v + 1, g.rows - 1);
     // (32-bit offsets from the frame's plane: a low-res plane set is C * rows * cols bytes)
     const uint32_t pstride = (uint32_t)g.rows * COLS, o1 = (uint32_t)v * COLS, o2 = (uint32_t)v2 * COLS;
@@ -2964,8 +2968,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint4 t_row = make_uint4(0, 0, 0, 0);
   if (tid < kRowTabWords / 4) t_row = reinterpret_cast<const uint4 *>(df->row_tabs)[tid];
   const GrpTables tb = tables_of(&T);
-  const int rb = r0 + (int)blockIdx.x * rpw;
+  const int rb = r0 + bx * rpw;
   const int nr = COLS == 512 ? 1 : min(rpw, r1 - rb);
+  // A persistent workgroup's next row: the loads above are in flight while the slowest wavefront
+  // still transforms the row before; nothing of the LDS is written before it is done.
+  if (again) __syncthreads();
   {
     uint4 z;
     z.x = z.y = z.z = z.w = 0;
@@ -3041,10 +3048,11 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
   uint32_t pf_a = 0;
   bool pf_on = false;
   {
-    // (one workgroup per CU at 4096 pixels, two where two fit: the CU's next one is 256 / 512 on)
-    const size_t lin = (size_t)f * gridDim.x + blockIdx.x + (L.total <= 80u * 1024u ? 512u : 256u);
-    const int fn = (int)(lin / gridDim.x), rn = r0 + (int)(lin % gridDim.x) * rpw;
-    pf_on = g.prefetch_rows != 0 && fn < (int)gridDim.y && rn < r1;
+    // (next_dist: how many workgroups on this one's successor on its CU is -- its own next row
+    // when the workgroups are persistent)
+    const size_t lin = (size_t)f * gx + bx + next_dist;
+    const int fn = (int)(lin / gx), rn = r0 + (int)(lin % gx) * rpw;
+    pf_on = g.prefetch_rows != 0 && fn < gy && rn < r1;
     if (pf_on) {
       const int wv = tid >> 6, ln = tid & 63;
       // (how many bytes: this workgroup's own rows are the best guess -- 4096 pixels: the row's length
@@ -3092,6 +3100,55 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(Geom g, DecWs ws,
       atomicMax(&st[2], (uint32_t)((c_out - c_p2) >> 4));   // transform + stores
       atomicMax(&st[3], (uint32_t)((c_out - c_in) >> 4));   // the whole workgroup
     }
+  }
+}
+
+
+// The kernel: a workgroup takes the rows bx = blockIdx.x, blockIdx.x + gridDim.x, ... of the
+// launch's (rows / rpw) x batch grid, frame after frame.  With as many workgroups as the GPU
+// holds at once (launch_decode) a CU does not wait for a new workgroup -- its LDS, its
+// wavefronts, their arguments -- between two rows (~3.6 k of a row's 61 k cycles), and the next
+// row's records are requested while the last wavefronts of this row still transform.
+// A kernel-argument struct into registers, word by word (a struct in the constant address space has
+// no copy constructor the host pass accepts).
+template <class W, class T>
+__device__ __forceinline__ void karg_copy(T *dst, const __attribute__((address_space(4))) T *src) {
+  static_assert(sizeof(T) % sizeof(W) == 0 && alignof(T) >= alignof(W), "whole words");
+  const __attribute__((address_space(4))) W *sw = (const __attribute__((address_space(4))) W *)src;
+  W *dw = reinterpret_cast<W *>(dst);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(T) / sizeof(W); ++i) dw[i] = sw[i];
+}
+struct RowArgs {
+  Geom g;
+  DecWs ws;
+  const uint8_t *packed;
+  size_t in_stride;
+  const uint32_t *sizes;
+  uint8_t *out_frames;
+  int r0, r1, rpw, gx, gy, next_dist;
+};
+// (The arguments are read from the kernel-argument segment anew for every row, through a pointer
+// the compiler cannot see through: read once in front of the loop they all stay live across the
+// body -- 104 scalar registers spilled instead of 36, the row kernel 9 % slower.)
+template <int COLS>
+__global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(RowArgs) {
+  typedef const __attribute__((address_space(4))) RowArgs *KArgs;
+  KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t total = (uint32_t)ka->gx * (uint32_t)ka->gy;
+  bool again = false;
+#pragma unroll 1
+  for (uint32_t lin = blockIdx.x; lin < total; lin += gridDim.x) {
+    asm volatile("" : "+s"(ka));
+    Geom g;
+    DecWs ws;
+    karg_copy<uint32_t>(&g, &ka->g);
+    karg_copy<unsigned long long>(&ws, &ka->ws);
+    const int gx = ka->gx;
+    dec_row_fused_body<COLS>(g, ws, ka->packed, ka->in_stride, ka->sizes, ka->out_frames, ka->r0, ka->r1, ka->rpw,
+                             (int)(lin % (uint32_t)gx), (int)(lin / (uint32_t)gx), gx, ka->gy,
+                             (uint32_t)ka->next_dist, again);
+    again = true;
   }
 }
 
@@ -4188,13 +4245,29 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     if (rpw_env > 0 && rpw_env < rpw) rpw = rpw_env;
     if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) rpw = 1;
     const uint32_t lds = fused_layout(g.row_block, rpw).total;
+    // Persistent workgroups (HIMG_PERSIST_ROWS=0: one workgroup per grid element as before): as
+    // many as run at once -- one per CU, two where two fit the LDS.
+    static const int persist_env = getenv("HIMG_PERSIST_ROWS") ? atoi(getenv("HIMG_PERSIST_ROWS")) : 1;
+    static const int n_cu = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n;
+    }();
+    const int per_cu = lds <= 80u * 1024u ? 2 : 1;
 #define HIMG_FUSED_LAUNCH(COLS, A, B)                                                           \
   do {                                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<COLS>),           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3(((B) - (A) + rpw - 1) / rpw, batch),       \
-                       dim3(kDecThreads), lds, stream, g, ws, d_packed, in_stride, d_sizes,     \
-                       d_out, (A), (B), rpw);                                                   \
+    const int gx_ = ((B) - (A) + rpw - 1) / rpw;                                                \
+    const long long all_ = (long long)gx_ * batch;                                              \
+    const int slots_ = persist_env > 1 ? persist_env : n_cu * per_cu;                           \
+    const bool pers_ = persist_env != 0 && all_ > slots_;                                       \
+    RowArgs ra_;                                                                                \
+    ra_.g = g; ra_.ws = ws; ra_.packed = d_packed; ra_.in_stride = in_stride; ra_.sizes = d_sizes; \
+    ra_.out_frames = d_out; ra_.r0 = (A); ra_.r1 = (B); ra_.rpw = rpw; ra_.gx = gx_; ra_.gy = batch; \
+    ra_.next_dist = pers_ ? slots_ : n_cu * per_cu;                                             \
+    hipLaunchKernelGGL((k_dec_row_fused<COLS>), dim3((unsigned)(pers_ ? slots_ : all_)),        \
+                       dim3(kDecThreads), lds, stream, ra_);                                    \
   } while (0)
     for (int k = 0; k < nseg; ++k) {
       const int a = seg_lo(k), b = seg_lo(k + 1);
