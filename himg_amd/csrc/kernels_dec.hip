@@ -2894,7 +2894,7 @@ __device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &w
                                                    size_t in_stride, const uint32_t *sizes,
                                                    uint8_t *out_frames, int r0, int r1, int rpw,
                                                    const int bx, const int f, const int gx, const int gy,
-                                                   const uint32_t next_lin, const bool again) {
+                                                   const uint32_t next_lin, const bool again, const bool same_tables) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (COLS == 512) rpw = 1;   // 4096-pixel rows: one row fills the lanes and the LDS (known at compile time)
   const FusedLayout L = fused_layout(g.row_block, rpw);
@@ -2958,15 +2958,18 @@ __device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &w
   // are in flight, then the stores.
   static_assert((1 << kLutBits) / 2 == kDecThreads && kSubEntries / 2 <= kDecThreads && kMaxNodes + 1 <= kDecThreads,
                 "one table element per lane");
-  const uint4 t_grp = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits))[tid];
-  uint4 t_sub = make_uint4(0, 0, 0, 0);
-  if (tid < kSubEntries / 2) t_sub = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries)[tid];
+  // (A persistent workgroup whose last row was of the same frame still holds them.)
+  const bool ld_tab = !(COLS == 512 && same_tables);
+  uint4 t_grp = make_uint4(0, 0, 0, 0), t_sub = t_grp, t_row = t_grp;
   uint32_t t_nd = 0;
-  if (tid < kMaxNodes + 1) t_nd = (ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1))[tid];
-  // The transform's tables: one 16-byte word per lane of wave 0 from the frame's copy (k_dec_parse).
   static_assert(kRowTabWords / 4 <= 64, "one wavefront copies them");
-  uint4 t_row = make_uint4(0, 0, 0, 0);
-  if (tid < kRowTabWords / 4) t_row = reinterpret_cast<const uint4 *>(df->row_tabs)[tid];
+  if (ld_tab) {
+    t_grp = reinterpret_cast<const uint4 *>(ws.grp + ((size_t)f * 2 + 1) * (1u << kLutBits))[tid];
+    if (tid < kSubEntries / 2) t_sub = reinterpret_cast<const uint4 *>(ws.sub + ((size_t)f * 2 + 1) * kSubEntries)[tid];
+    if (tid < kMaxNodes + 1) t_nd = (ws.nodes + ((size_t)f * 2 + 1) * (kMaxNodes + 1))[tid];
+    // The transform's tables: one 16-byte word per lane of wave 0 from the frame's copy (k_dec_parse).
+    if (tid < kRowTabWords / 4) t_row = reinterpret_cast<const uint4 *>(df->row_tabs)[tid];
+  }
   const GrpTables tb = tables_of(&T);
   const int rb = r0 + bx * rpw;
   const int nr = COLS == 512 ? 1 : min(rpw, r1 - rb);
@@ -2979,10 +2982,12 @@ __device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &w
     const int n16 = (int)(rb16 >> 4) * nr;
     for (int k = tid; k < n16; k += kDecThreads) reinterpret_cast<uint4 *>(sym0)[k] = z;
   }
-  reinterpret_cast<uint4 *>(T.grp)[tid] = t_grp;
-  if (tid < kRowTabWords / 4) reinterpret_cast<uint4 *>(smem + L.unmap)[tid] = t_row;   // unmap, shift, shiftp: contiguous
-  if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(T.grp + (1 << kLutBits))[tid] = t_sub;
-  if (tid < kMaxNodes + 1) T.nd[tid] = t_nd;
+  if (ld_tab) {
+    reinterpret_cast<uint4 *>(T.grp)[tid] = t_grp;
+    if (tid < kRowTabWords / 4) reinterpret_cast<uint4 *>(smem + L.unmap)[tid] = t_row;   // unmap, shift, shiftp: contiguous
+    if (tid < kSubEntries / 2) reinterpret_cast<uint4 *>(T.grp + (1 << kLutBits))[tid] = t_sub;
+    if (tid < kMaxNodes + 1) T.nd[tid] = t_nd;
+  }
   if constexpr (COLS == 512) {
     if (tid == 0) { sh->flag = st0; sh->err = 0; sh->endbit = ~0ull; }   // (decode_stream<.., PRIMED>)
   }
@@ -3140,6 +3145,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(RowArgs) {
   // 128 identical frames 10.28 ms against 10.01 with a workgroup per row.
   auto element = [&](uint32_t i) { return i * S + (blockIdx.x + 37u * i) % S; };
   bool again = false;
+  int f_prev = -1;
 #pragma unroll 1
   for (uint32_t i = 0; i * S < total; ++i) {
     const uint32_t lin = element(i);
@@ -3149,12 +3155,12 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_row_fused(RowArgs) {
     DecWs ws;
     karg_copy<uint32_t>(&g, &ka->g);
     karg_copy<unsigned long long>(&ws, &ka->ws);
-    const int gx = ka->gx;
+    const int gx = ka->gx, f = (int)(lin / (uint32_t)gx);
     const uint32_t nd = (uint32_t)ka->next_dist;
     dec_row_fused_body<COLS>(g, ws, ka->packed, ka->in_stride, ka->sizes, ka->out_frames, ka->r0, ka->r1, ka->rpw,
-                             (int)(lin % (uint32_t)gx), (int)(lin / (uint32_t)gx), gx, ka->gy,
-                             nd ? lin + nd : element(i + 1), again);
+                             (int)(lin % (uint32_t)gx), f, gx, ka->gy, nd ? lin + nd : element(i + 1), again, f == f_prev);
     again = true;
+    f_prev = f;
   }
 }
 
