@@ -3081,7 +3081,7 @@ __device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &w
   // stay read-only in LDS: no barrier, no second pass over them.
   uint8_t *img = out_frames + (size_t)f * ((size_t)g.W * g.H * g.C);
   const int per_row = ((cols + 31) >> 5) * 64;   // whole wavefronts: a lane pair never straddles rows
-  HIMG_REGION_BEGIN("dec.transform");
+  HIMG_SPAN_BEGIN("dec.transform");
 #pragma unroll 1
   for (int it = tid; it < per_row * nr; it += kDecThreads) {
     const int i = COLS == 512 ? 0 : it / per_row, il = it - i * per_row;
@@ -3093,7 +3093,7 @@ __device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &w
                                             in_row ? pair_tile(il) : cols - 1, pair_half(il), rb + i, img,
                                             COLS == 512 ? pre_lr : nullptr, in_row, pf_on && it == tid, pf_a);
   }
-  HIMG_REGION_END("dec.transform");
+  HIMG_SPAN_END("dec.transform");
   // Cycle stamps: the slowest wave counts (the SIMDs issue oldest-first, so the
   // first wave finishes long before the last one).
   if ((tid & 63) == 0) {

@@ -17,6 +17,10 @@
 // (the compiler moves unlikely blocks out of line).
 #define HIMG_REGION_BEGIN(name) asm volatile("; HIMG_REGION_BEGIN " name)
 #define HIMG_REGION_END(name) asm volatile("; HIMG_REGION_END " name)
+// A straight-line span that may sit INSIDE a loop (the persistent row kernel's transform: once per
+// pass through the loop body); tools/isa_mix.py lists it under "regions" like a span outside loops.
+#define HIMG_SPAN_BEGIN(name) asm volatile("; HIMG_SPAN_BEGIN " name)
+#define HIMG_SPAN_END(name) asm volatile("; HIMG_SPAN_END " name)
 
 namespace himg_dev {
 #ifdef HIMG_LOOP_COUNTS

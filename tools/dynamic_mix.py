@@ -124,7 +124,7 @@ def analyse(counts_path, out_path):
                 continue
             m = st["regions"][name]
             v = w_once * m["valu"]
-            parts.append({"part": name + " (straight-line, once per wavefront)", "valu_static": m["valu"],
+            parts.append({"part": name + " (straight-line, once per wavefront and row)", "valu_static": m["valu"],
                           "valu_per_frame": v, "mean_cost": m["mean_cost_per_valu"]})
             used_valu += v
             used_cost += w_once * cost(m)

@@ -134,6 +134,13 @@ def analyse(body, fast_c, slow_c):
             else:
                 h = re.search(r"in Loop: Header=(BB\d+_\d+)", ann)
                 cur = h.group(1) if h else None
+        sp = re.match(r"^;\s*HIMG_SPAN_(BEGIN|END)\s+(\S+)", s)
+        if sp:   # a straight-line span, inside a loop or not
+            if sp.group(1) == "BEGIN":
+                regions.setdefault(sp.group(2), [len(insts), None])
+            elif sp.group(2) in regions:
+                regions[sp.group(2)][1] = len(insts)
+            continue
         mk = re.match(r"^;\s*HIMG_REGION_(BEGIN|END)\s+(\S+)", s)
         if mk:
             (begin_at if mk.group(1) == "BEGIN" else end_at)[mk.group(2)].append(len(insts))
