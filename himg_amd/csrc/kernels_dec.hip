@@ -3109,7 +3109,7 @@ __device__ __forceinline__ void dec_row_fused_body(const Geom &g, const DecWs &w
 
 // The kernel: a workgroup takes the rows bx = blockIdx.x, blockIdx.x + gridDim.x, ... of the
 // launch's (rows / rpw) x batch grid, frame after frame.  With as many workgroups as the GPU
-// holds at once (launch_decode) a CU does not wait for a new workgroup -- its LDS, its
+// holds at once (launch_decode: one per CU) a CU does not wait for a new workgroup -- its LDS, its
 // wavefronts, their arguments -- between two rows (~3.6 k of a row's 61 k cycles), and the next
 // row's records are requested while the last wavefronts of this row still transform.
 // A kernel-argument struct into registers, word by word (a struct in the constant address space has
@@ -4258,14 +4258,15 @@ void launch_decode(const Geom &g, const DecWs &ws, int batch, const uint8_t *d_p
     if (g.W == 4096 && g.C == 4 && (g.H & 7) == 0) rpw = 1;
     const uint32_t lds = fused_layout(g.row_block, rpw).total;
     // Persistent workgroups (HIMG_PERSIST_ROWS=0: one workgroup per grid element as before): as
-    // many as run at once -- one per CU, two where two fit the LDS.
+    // many as run at once -- one per CU.
     static const int persist_env = getenv("HIMG_PERSIST_ROWS") ? atoi(getenv("HIMG_PERSIST_ROWS")) : 1;
     static const int n_cu = [] {
       int dev = 0, n = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
       return n;
     }();
-    const int per_cu = lds <= 80u * 1024u ? 2 : 1;
+    // (Sixteen wavefronts of 120+ registers each: one workgroup per CU whatever the LDS leaves.)
+    const int per_cu = 1;
 #define HIMG_FUSED_LAUNCH(COLS, A, B)                                                           \
   do {                                                                                          \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dec_row_fused<COLS>),           \
