@@ -1176,14 +1176,15 @@ __device__ __forceinline__ void emit_run(int len, F &&f) {
 // Bit k of the result is set when symbol k (byte k of the 16-byte chunk) is
 // non-zero; symbols at or beyond nvalid read as zero.
 __device__ __forceinline__ uint32_t nonzero_mask16(const uint32_t w[4], int nvalid) {
-  uint32_t m = 0;
+  // Byte k of f = 0x80 where byte k != 0; eight flags become eight mask bits with two dot
+  // products (weights 1, 2, 4, 8 and 16, 32, 64, 128, chained through the accumulator): 128 x the
+  // byte of the mask, shifted down once for all sixteen.
+  uint32_t f[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    // Byte k of t = (byte k != 0), then the four flags as a nibble: a dot product with
-    // the bit weights 1, 2, 4, 8.
-    const uint32_t t = ((((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u) >> 7;
-    m |= __builtin_amdgcn_udot4(t, 0x08040201u, 0u, false) << (4 * q);
-  }
+  for (int q = 0; q < 4; ++q) f[q] = (((w[q] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[q]) & 0x80808080u;
+  const uint32_t lo = __builtin_amdgcn_udot4(f[1], 0x80402010u, __builtin_amdgcn_udot4(f[0], 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(f[3], 0x80402010u, __builtin_amdgcn_udot4(f[2], 0x08040201u, 0u, false), false);
+  const uint32_t m = (lo | (hi << 8)) >> 7;
   return nvalid >= 16 ? m : (m & ((1u << nvalid) - 1u));
 }
 
