@@ -1667,7 +1667,9 @@ __global__ __launch_bounds__(kTokThreads) void k_tok(Geom g, EncWs ws, int r0) {
         }
       };
       const uint32_t n = nA + nB;
-      const uint32_t incl = wave_scan_add(n);
+      uint32_t incl_ = wave_scan_add(n);
+      asm volatile("" : "+v"(incl_));   // (or `incl - n` is re-associated into the sum of the scan's six shifted parts: six moves and three adds more)
+      const uint32_t incl = incl_;
       const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       // A dense iteration (more slots than the buffer holds) is staged in two parts: lanes 0..31,
       // then lanes 32..63 -- the slots of a part are consecutive in the stream (lane-major order).
